@@ -1,0 +1,207 @@
+/*
+ * sgs_raster.h -- C-ABI of libsgs_hip.so, the MI355X (gfx950) N-channel
+ * Gaussian-splat rasteriser + Morton kNN.
+ *
+ * This is the drop-in boundary for the hot path of sharinka0715/semantic-gaussians:
+ * every entry point replaces one native entry point of the reference's three CUDA
+ * extensions (CR = submodules/channel-rasterization, RR = submodules/rgbd-rasterization,
+ * SK = submodules/simple-knn).  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions (same as the reference):
+ *   - all float data is fp32, all pointers are DEVICE pointers on the GPU that
+ *     `stream` belongs to, unless marked [host];
+ *   - a NULL pointer for an optional input means "not provided"
+ *     (reference: empty tensor -> nullptr, CR/cuda_rasterizer/forward.cu:205,241);
+ *   - viewmatrix / projmatrix are the 16 floats of the reference's transposed
+ *     matrices (scene/camera.py:87-93; CR/cuda_rasterizer/auxiliary.h:58-77);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  The
+ *     reference launches on the legacy default stream; here every kernel, scan and
+ *     sort is enqueued on `stream`;
+ *   - functions return >= 0 on success and a negative SGS_E* code on failure;
+ *     sgs_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef SGS_RASTER_H_INCLUDED
+#define SGS_RASTER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGS_ABI_VERSION 1
+
+#define SGS_EINVAL (-1)   /* bad argument (reference: AT_ERROR / std::runtime_error) */
+#define SGS_EHIP (-2)     /* HIP runtime / kernel error */
+#define SGS_EALLOC (-3)   /* allocator callback returned NULL */
+#define SGS_ETRAP (-4)    /* prefiltered=1 but a point was culled (reference: __trap(),
+                             CR/cuda_rasterizer/auxiliary.h:156-160) */
+
+/* Resizable scratch buffer callback.  Replaces std::function<char*(size_t)>
+ * (CR/cuda_rasterizer/rasterizer.h:24-26, built by resizeFunctional,
+ * CR/rasterize_points.cu:28-36): must return a device pointer to at least `bytes`
+ * bytes (128-B aligned) that stays valid until the caller releases it.  */
+typedef void *(*sgs_alloc_fn)(void *user, size_t bytes);
+
+int sgs_abi_version(void);
+const char *sgs_last_error(void);
+
+/* ---- forward ---------------------------------------------------------------
+ * Replaces CudaRasterizer::Rasterizer::forward
+ *   (CR/cuda_rasterizer/rasterizer_impl.cu:198-341, declared rasterizer.h:34-58;
+ *    RR/cuda_rasterizer/rasterizer_impl.cu:198-338 when out_depth != NULL).
+ * Pipeline: preprocess -> inclusive scan -> (4-byte D2H) -> duplicateWithKeys ->
+ * stable 64-bit radix sort on bits [0, 32+msb(tiles)) -> tile ranges -> blend.
+ *   P,D,M          #Gaussians, active SH degree, SH coeffs per Gaussian (0 if no shs)
+ *   background     (C) floats
+ *   means3D (P,3) shs (P,M,3)|NULL colors_precomp (P,C)|NULL opacities (P)
+ *   scales (P,3)|NULL rotations (P,4)|NULL cov3D_precomp (P,6)|NULL
+ *   out_color      (C,H,W) written in full
+ *   out_depth      (1,H,W) or NULL: the RGB-D median depth of RR/forward.cu:308,368-372,391
+ *   radii          (P) int32, or NULL (internal)
+ *   debug          !=0: synchronise and check after every stage (CHECK_CUDA,
+ *                  CR/cuda_rasterizer/auxiliary.h:166-173)
+ * Returns num_rendered (Sum of tiles touched) >= 0, or a negative error code.
+ * Blocks the host once (the 4-byte read of num_rendered), like the reference. */
+int sgs_rasterize_forward(
+	sgs_alloc_fn geometry_buffer, void *geometry_user,
+	sgs_alloc_fn binning_buffer, void *binning_user,
+	sgs_alloc_fn image_buffer, void *image_user,
+	int P, int D, int M,
+	const float *background,
+	int width, int height,
+	const float *means3D,
+	const float *shs,
+	const float *colors_precomp,
+	const float *opacities,
+	const float *scales,
+	float scale_modifier,
+	const float *rotations,
+	const float *cov3D_precomp,
+	const float *viewmatrix,
+	const float *projmatrix,
+	const float *cam_pos,
+	float tan_fovx, float tan_fovy,
+	int prefiltered,
+	int num_channels,
+	float *out_color,
+	float *out_depth,
+	int *radii,
+	int debug,
+	void *stream);
+
+/* ---- backward --------------------------------------------------------------
+ * Replaces CudaRasterizer::Rasterizer::backward
+ *   (CR/cuda_rasterizer/rasterizer_impl.cu:345-441, rasterizer.h:60-86), with the
+ * colour-channel count a RUNTIME argument: the reference instantiates its backward on
+ * the compile-time NUM_CHANNELS=3 (CR/cuda_rasterizer/config.h:15, backward.cu:599,636);
+ * num_channels==3 reproduces it, other values are its runtime-C generalisation.
+ *   R                         num_rendered returned by the forward
+ *   geom/binning/image_buffer the three buffers the forward filled (opaque layout)
+ *   dL_dpix                   (C,H,W)
+ * Outputs must be zero-initialised by the caller (reference: torch::zeros,
+ * CR/rasterize_points.cu:157-165):
+ *   dL_dmean2D (P,3) dL_dconic (P,4) dL_dopacity (P) dL_dcolor (P,C) dL_dmean3D (P,3)
+ *   dL_dcov3D (P,6) dL_dsh (P,M,3) dL_dscale (P,3) dL_drot (P,4) */
+int sgs_rasterize_backward(
+	int P, int D, int M, int R,
+	const float *background,
+	int width, int height,
+	const float *means3D,
+	const float *shs,
+	const float *colors_precomp,
+	const float *scales,
+	float scale_modifier,
+	const float *rotations,
+	const float *cov3D_precomp,
+	const float *viewmatrix,
+	const float *projmatrix,
+	const float *campos,
+	float tan_fovx, float tan_fovy,
+	const int *radii,
+	char *geom_buffer,
+	char *binning_buffer,
+	char *image_buffer,
+	const float *dL_dpix,
+	int num_channels,
+	float *dL_dmean2D,
+	float *dL_dconic,
+	float *dL_dopacity,
+	float *dL_dcolor,
+	float *dL_dmean3D,
+	float *dL_dcov3D,
+	float *dL_dsh,
+	float *dL_dscale,
+	float *dL_drot,
+	int debug,
+	void *stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible
+ * (CR/cuda_rasterizer/rasterizer_impl.cu:141-153).  present: (P) bytes, 1 = view z > 0.2. */
+int sgs_mark_visible(int P, const float *means3D, const float *viewmatrix,
+		     const float *projmatrix, uint8_t *present, void *stream);
+
+/* Replaces SimpleKNN::knn (SK/simple_knn.cu:186-220, simple_knn.h:17): mean squared
+ * distance to the three nearest other points.  points (P,3), meanDists (P).
+ * Scratch comes from `scratch(scratch_user, bytes)` (one call). */
+int sgs_knn_mean_dist2(int P, const float *points, float *meanDists,
+		       sgs_alloc_fn scratch, void *scratch_user, void *stream);
+
+/* ---- introspection of the opaque buffers (debug / parity tests) --------------
+ * The reference's buffers are opaque to callers as well (only its own backward reads
+ * them, CR/cuda_rasterizer/rasterizer_impl.cu:376-378); these accessors exist so the
+ * bit-exactness of tile ids / sort keys can be tested without freezing a layout.
+ * Each writes byte offsets (relative to the buffer start) of the named arrays. */
+typedef struct {
+	size_t depths;         /* float  [P]   view-space z */
+	size_t clamped;        /* uint8  [3P]  SH clamp flags */
+	size_t radii;          /* int32  [P]   internal radii (when caller passed NULL) */
+	size_t means2D;        /* float2 [P]   pixel centre */
+	size_t cov3D;          /* float  [6P]  */
+	size_t conic_opacity;  /* float4 [P]   */
+	size_t rgb;            /* float  [3P]  SH->RGB result */
+	size_t tiles_touched;  /* uint32 [P]   */
+	size_t point_offsets;  /* uint32 [P]   inclusive scan of tiles_touched */
+	size_t total;          /* bytes required */
+} sgs_geometry_layout;
+
+typedef struct {
+	size_t keys_unsorted;  /* uint64 [L] (tile<<32 | depth bits), emission order */
+	size_t vals_unsorted;  /* uint32 [L] */
+	size_t keys_sorted;    /* uint64 [L] */
+	size_t point_list;     /* uint32 [L] sorted Gaussian ids */
+	size_t total;
+} sgs_binning_layout;
+
+typedef struct {
+	size_t accum_alpha;    /* float  [H*W] final T */
+	size_t n_contrib;      /* uint32 [H*W] */
+	size_t ranges;         /* uint2  [tiles] */
+	size_t total;
+} sgs_image_layout;
+
+int sgs_geometry_layout_of(int P, sgs_geometry_layout *out);
+int sgs_binning_layout_of(int num_rendered, sgs_binning_layout *out);
+int sgs_image_layout_of(int width, int height, sgs_image_layout *out);
+
+/* Number of key bits the forward sorts on: 32 + getHigherMsb(tiles)
+ * (CR/cuda_rasterizer/rasterizer_impl.cu:35-50,302). */
+int sgs_sort_bits(int width, int height);
+
+/* Device exp() used by the blend kernels, exposed for the numerics contract test
+ * (DESIGN.md "exp contract"): out[i] = sgs_expf(in[i]). */
+int sgs_debug_expf(int n, const float *in, float *out, void *stream);
+
+/* Tuning / measurement hooks (not part of the reference's interface). */
+/* Selects the blend-forward kernel variant (0 = default).  Returns previous value. */
+int sgs_set_blend_variant(int variant);
+/* Device time (ms, hipEvent on `stream`) of each stage of the LAST forward call made
+ * with timing enabled.  stages: 0 preprocess 1 scan 2 duplicate 3 sort 4 ranges 5 blend */
+int sgs_set_stage_timing(int enable);
+int sgs_get_stage_ms(float *ms6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

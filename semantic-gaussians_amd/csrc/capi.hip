@@ -1,0 +1,443 @@
+// capi.hip -- extern "C" entry points of libsgs_hip.so (see include/sgs_raster.h) and the
+// host-side orchestration that the reference keeps in
+// CR/cuda_rasterizer/rasterizer_impl.cu:141-441 (Rasterizer::{markVisible,forward,backward})
+// and SK/simple_knn.cu:186-220 (SimpleKNN::knn).
+//
+// Differences from the reference that are deliberate (DESIGN.md "host orchestration"):
+//  * every launch, scan, sort, memset and copy goes to the caller's stream (the reference
+//    uses the legacy null stream) -- required for one-process-per-GPU view sharding and for
+//    overlapping views on several streams;
+//  * the image-state `ranges` array is sized by the tile count, not H*W entries;
+//  * prefiltered-but-culled is reported as SGS_ETRAP instead of a device trap;
+//  * per-stage hipEvent timing is available for bench.py (off by default).
+#include "../../include/sgs_raster.h"
+#include "sgs_kernels.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+std::atomic<int> g_blend_variant{0};
+std::atomic<int> g_stage_timing{0};
+float g_stage_ms[6] = {0, 0, 0, 0, 0, 0};
+
+int fail(int code, const std::string& msg)
+{
+	g_err = msg;
+	return code;
+}
+
+int fail_hip(hipError_t e, const char* what)
+{
+	g_err = std::string(what) + ": " + hipGetErrorString(e);
+	return SGS_EHIP;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
+
+// 128-B aligned carving of an opaque chunk (the reference's `obtain`,
+// CR/cuda_rasterizer/rasterizer_impl.h:21-27).
+struct Carver {
+	size_t off = 0;
+	size_t take(size_t bytes)
+	{
+		off = align_up(off, 128);
+		const size_t o = off;
+		off += bytes;
+		return o;
+	}
+};
+
+struct GeomLayout {
+	sgs_geometry_layout pub;
+	size_t scan_temp, scan_temp_bytes, trap_flag, total;
+};
+
+GeomLayout geom_layout(int P)
+{
+	GeomLayout g;
+	Carver c;
+	const size_t p = (size_t)P;
+	g.pub.depths = c.take(p * 4);
+	g.pub.clamped = c.take(p * 3);
+	g.pub.radii = c.take(p * 4);
+	g.pub.means2D = c.take(p * 8);
+	g.pub.cov3D = c.take(p * 24);
+	g.pub.conic_opacity = c.take(p * 16);
+	g.pub.rgb = c.take(p * 12);
+	g.pub.tiles_touched = c.take(p * 4);
+	g.pub.point_offsets = c.take(p * 4);
+	g.scan_temp_bytes = sgs::scan_temp_bytes(P);
+	g.scan_temp = c.take(g.scan_temp_bytes);
+	g.trap_flag = c.take(4);
+	g.total = align_up(c.off, 128) + 128;
+	g.pub.total = g.total;
+	return g;
+}
+
+struct BinLayout {
+	sgs_binning_layout pub;
+	size_t sort_temp, sort_temp_bytes, total;
+};
+
+BinLayout bin_layout(size_t L, int sort_bits)
+{
+	BinLayout b;
+	Carver c;
+	b.pub.keys_unsorted = c.take(L * 8);
+	b.pub.vals_unsorted = c.take(L * 4);
+	b.pub.keys_sorted = c.take(L * 8);
+	b.pub.point_list = c.take(L * 4);
+	b.sort_temp_bytes = L ? sgs::sort_temp_bytes(L, sort_bits) : 0;
+	b.sort_temp = c.take(b.sort_temp_bytes);
+	b.total = align_up(c.off, 128) + 128;
+	b.pub.total = b.total;
+	return b;
+}
+
+sgs_image_layout img_layout(int W, int H)
+{
+	sgs_image_layout im;
+	Carver c;
+	const size_t n = (size_t)W * H;
+	const size_t tiles = (size_t)((W + SGS_TILE - 1) / SGS_TILE) * ((H + SGS_TILE - 1) / SGS_TILE);
+	im.accum_alpha = c.take(n * 4);
+	im.n_contrib = c.take(n * 4);
+	im.ranges = c.take(tiles * 8);
+	im.total = align_up(c.off, 128) + 128;
+	return im;
+}
+
+// CR/cuda_rasterizer/rasterizer_impl.cu:35-50
+uint32_t higher_msb(uint32_t n)
+{
+	uint32_t msb = sizeof(n) * 4;
+	uint32_t step = msb;
+	while (step > 1) {
+		step /= 2;
+		if (n >> msb) msb += step;
+		else msb -= step;
+	}
+	if (n >> msb) msb++;
+	return msb;
+}
+
+// the caller's chunk may be unaligned (torch guarantees 512 B, others may not)
+inline char* align_ptr(char* p) { return (char*)align_up((size_t)p, 128); }
+
+struct StageTimer {
+	bool on;
+	hipStream_t st;
+	hipEvent_t ev[7];
+	int n = 0;
+	StageTimer(bool enable, hipStream_t s) : on(enable), st(s)
+	{
+		if (on)
+			for (auto& e : ev) (void)hipEventCreate(&e);
+	}
+	void mark()
+	{
+		if (on && n < 7) (void)hipEventRecord(ev[n++], st);
+	}
+	void finish()
+	{
+		if (!on) return;
+		(void)hipEventSynchronize(ev[n - 1]);
+		for (int i = 0; i < 6; i++) {
+			g_stage_ms[i] = 0.f;
+			if (i + 1 < n) (void)hipEventElapsedTime(&g_stage_ms[i], ev[i], ev[i + 1]);
+		}
+		for (auto& e : ev) (void)hipEventDestroy(e);
+	}
+};
+
+#define SGS_CHECK_STAGE(what)                                                             \
+	do {                                                                              \
+		hipError_t e_ = hipGetLastError();                                        \
+		if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(st);             \
+		if (e_ != hipSuccess) return fail_hip(e_, what);                          \
+	} while (0)
+
+} // namespace
+
+extern "C" {
+
+int sgs_abi_version(void) { return SGS_ABI_VERSION; }
+const char* sgs_last_error(void) { return g_err.c_str(); }
+
+int sgs_set_blend_variant(int variant) { return g_blend_variant.exchange(variant); }
+int sgs_set_stage_timing(int enable) { return g_stage_timing.exchange(enable); }
+int sgs_get_stage_ms(float* ms6)
+{
+	for (int i = 0; i < 6; i++) ms6[i] = g_stage_ms[i];
+	return 0;
+}
+
+int sgs_geometry_layout_of(int P, sgs_geometry_layout* out)
+{
+	if (P < 0 || !out) return fail(SGS_EINVAL, "bad argument");
+	*out = geom_layout(P).pub;
+	return 0;
+}
+int sgs_binning_layout_of(int num_rendered, sgs_binning_layout* out)
+{
+	if (num_rendered < 0 || !out) return fail(SGS_EINVAL, "bad argument");
+	// sort temp size does not depend on the number of key bits for the layout's public part
+	*out = bin_layout((size_t)num_rendered, 64).pub;
+	return 0;
+}
+int sgs_image_layout_of(int width, int height, sgs_image_layout* out)
+{
+	if (width < 0 || height < 0 || !out) return fail(SGS_EINVAL, "bad argument");
+	*out = img_layout(width, height);
+	return 0;
+}
+int sgs_sort_bits(int width, int height)
+{
+	const uint32_t gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
+	return 32 + (int)higher_msb(gx * gy);
+}
+
+int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
+			  sgs_alloc_fn binning_buffer, void* binning_user,
+			  sgs_alloc_fn image_buffer, void* image_user, int P, int D, int M,
+			  const float* background, int width, int height, const float* means3D,
+			  const float* shs, const float* colors_precomp, const float* opacities,
+			  const float* scales, float scale_modifier, const float* rotations,
+			  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+			  const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+			  int num_channels, float* out_color, float* out_depth, int* radii, int debug,
+			  void* stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+	if (P < 0 || width <= 0 || height <= 0 || num_channels <= 0)
+		return fail(SGS_EINVAL, "bad sizes");
+	if (!geometry_buffer || !binning_buffer || !image_buffer || !out_color)
+		return fail(SGS_EINVAL, "null buffer callback / output");
+	if (num_channels != 3 && colors_precomp == nullptr)   // rasterizer_impl.cu:243-246
+		return fail(SGS_EINVAL, "For non-RGB, provide precomputed Gaussian colors!");
+	if (out_depth && num_channels != 3)
+		return fail(SGS_EINVAL, "the RGB-D variant renders exactly 3 channels");
+	if (P == 0) return 0;   // caller returns zeros (rasterize_points.cu:85-120)
+	if (!means3D || !opacities || !viewmatrix || !projmatrix || !background)
+		return fail(SGS_EINVAL, "null required input");
+	if (!cov3D_precomp && (!scales || !rotations))
+		return fail(SGS_EINVAL, "need scales+rotations or cov3D_precomp");
+	if (!colors_precomp && (!shs || !cam_pos)) return fail(SGS_EINVAL, "need shs+campos or colors_precomp");
+
+	const float focal_y = height / (2.0f * tan_fovy);   // rasterizer_impl.cu:223-224
+	const float focal_x = width / (2.0f * tan_fovx);
+	const int gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
+	const int ntiles = gx * gy;
+
+	StageTimer tm(g_stage_timing.load() != 0, st);
+
+	const GeomLayout gl = geom_layout(P);
+	char* gchunk = (char*)geometry_buffer(geometry_user, gl.total);
+	if (!gchunk) return fail(SGS_EALLOC, "geometry buffer allocation failed");
+	gchunk = align_ptr(gchunk);
+	const sgs_image_layout il = img_layout(width, height);
+	char* ichunk = (char*)image_buffer(image_user, il.total);
+	if (!ichunk) return fail(SGS_EALLOC, "image buffer allocation failed");
+	ichunk = align_ptr(ichunk);
+
+	float* depths = (float*)(gchunk + gl.pub.depths);
+	uint8_t* clamped = (uint8_t*)(gchunk + gl.pub.clamped);
+	int* radii_int = (int*)(gchunk + gl.pub.radii);
+	float2* means2D = (float2*)(gchunk + gl.pub.means2D);
+	float* cov3D = (float*)(gchunk + gl.pub.cov3D);
+	float4* conic_opacity = (float4*)(gchunk + gl.pub.conic_opacity);
+	float* rgb = (float*)(gchunk + gl.pub.rgb);
+	uint32_t* tiles_touched = (uint32_t*)(gchunk + gl.pub.tiles_touched);
+	uint32_t* point_offsets = (uint32_t*)(gchunk + gl.pub.point_offsets);
+	int* trap_flag = (int*)(gchunk + gl.trap_flag);
+	if (radii == nullptr) radii = radii_int;
+
+	hipError_t e = hipMemsetAsync(trap_flag, 0, 4, st);
+	if (e != hipSuccess) return fail_hip(e, "memset");
+
+	tm.mark();
+	sgs::launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities,
+				   shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos,
+				   width, height, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy,
+				   prefiltered, num_channels, radii, means2D, depths, cov3D, rgb, clamped,
+				   conic_opacity, tiles_touched, trap_flag);
+	SGS_CHECK_STAGE("preprocess");
+	tm.mark();
+	e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, tiles_touched,
+				       point_offsets, P);
+	if (e != hipSuccess) return fail_hip(e, "inclusive scan");
+	SGS_CHECK_STAGE("inclusive scan");
+
+	// the one blocking read-back of the forward (rasterizer_impl.cu:283)
+	int host_vals[2] = {0, 0};
+	e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) return fail_hip(e, "num_rendered read-back");
+	if (host_vals[1] != 0)
+		return fail(SGS_ETRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
+	const uint32_t L = (uint32_t)host_vals[0];
+	if (L > 0x7fffffffu) return fail(SGS_EINVAL, "num_rendered exceeds 2^31-1");
+	tm.mark();
+
+	const int sort_bits = 32 + (int)higher_msb((uint32_t)ntiles);
+	const BinLayout bl = bin_layout(L, sort_bits);
+	char* bchunk = (char*)binning_buffer(binning_user, bl.total);
+	if (!bchunk) return fail(SGS_EALLOC, "binning buffer allocation failed");
+	bchunk = align_ptr(bchunk);
+	uint64_t* keys_u = (uint64_t*)(bchunk + bl.pub.keys_unsorted);
+	uint32_t* vals_u = (uint32_t*)(bchunk + bl.pub.vals_unsorted);
+	uint64_t* keys_s = (uint64_t*)(bchunk + bl.pub.keys_sorted);
+	uint32_t* point_list = (uint32_t*)(bchunk + bl.pub.point_list);
+
+	sgs::launch_duplicate_with_keys(st, P, means2D, depths, point_offsets, radii, gx, gy, keys_u,
+					vals_u, L);
+	SGS_CHECK_STAGE("duplicateWithKeys");
+	tm.mark();
+	if (L > 0) {
+		e = sgs::launch_sort_pairs(st, bchunk + bl.sort_temp, bl.sort_temp_bytes, keys_u, keys_s,
+					   vals_u, point_list, L, sort_bits);
+		if (e != hipSuccess) return fail_hip(e, "radix sort");
+	}
+	SGS_CHECK_STAGE("radix sort");
+	tm.mark();
+	uint2* ranges = (uint2*)(ichunk + il.ranges);
+	sgs::launch_tile_ranges(st, L, keys_s, ranges, ntiles);
+	SGS_CHECK_STAGE("identifyTileRanges");
+	tm.mark();
+
+	sgs::BlendFwdArgs a;
+	a.ranges = ranges;
+	a.point_list = point_list;
+	a.W = width;
+	a.H = height;
+	a.C = num_channels;
+	a.gx = gx;
+	a.gy = gy;
+	a.means2D = means2D;
+	a.features = colors_precomp ? colors_precomp : rgb;
+	a.conic_opacity = conic_opacity;
+	a.depths = depths;
+	a.bg = background;
+	a.final_T = (float*)(ichunk + il.accum_alpha);
+	a.n_contrib = (uint32_t*)(ichunk + il.n_contrib);
+	a.out = out_color;
+	a.out_depth = out_depth;
+	e = sgs::launch_blend_forward(st, a, g_blend_variant.load());
+	if (e != hipSuccess) return fail_hip(e, "blend forward");
+	SGS_CHECK_STAGE("blend forward");
+	tm.mark();
+	tm.finish();
+	return (int)L;
+}
+
+int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, int width,
+			   int height, const float* means3D, const float* shs,
+			   const float* colors_precomp, const float* scales, float scale_modifier,
+			   const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+			   const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+			   const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+			   const float* dL_dpix, int num_channels, float* dL_dmean2D, float* dL_dconic,
+			   float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+			   float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+	if (P < 0 || R < 0 || width <= 0 || height <= 0 || num_channels <= 0)
+		return fail(SGS_EINVAL, "bad sizes");
+	if (P == 0) return 0;
+	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
+		return fail(SGS_EINVAL, "null state buffer");
+	if (!dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
+	    !dL_dcov3D || !dL_dscale || !dL_drot)
+		return fail(SGS_EINVAL, "null gradient buffer");
+	if (shs && num_channels != 3) return fail(SGS_EINVAL, "SH colours imply 3 channels");
+
+	const int gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
+	const GeomLayout gl = geom_layout(P);
+	const sgs_image_layout il = img_layout(width, height);
+	const BinLayout bl = bin_layout((size_t)R, 64);
+	char* gchunk = align_ptr(geom_buffer);
+	char* ichunk = align_ptr(image_buffer);
+	char* bchunk = binning_buffer ? align_ptr(binning_buffer) : nullptr;
+	if (radii == nullptr) radii = (const int*)(gchunk + gl.pub.radii);
+
+	const float focal_y = height / (2.0f * tan_fovy);
+	const float focal_x = width / (2.0f * tan_fovx);
+
+	sgs::BlendBwdArgs a;
+	a.ranges = (const uint2*)(ichunk + il.ranges);
+	a.point_list = bchunk ? (const uint32_t*)(bchunk + bl.pub.point_list) : nullptr;
+	a.W = width;
+	a.H = height;
+	a.C = num_channels;
+	a.gx = gx;
+	a.gy = gy;
+	a.bg = background;
+	a.means2D = (const float2*)(gchunk + gl.pub.means2D);
+	a.conic_opacity = (const float4*)(gchunk + gl.pub.conic_opacity);
+	a.colors = colors_precomp ? colors_precomp : (const float*)(gchunk + gl.pub.rgb);
+	a.final_T = (const float*)(ichunk + il.accum_alpha);
+	a.n_contrib = (const uint32_t*)(ichunk + il.n_contrib);
+	a.dL_dpix = dL_dpix;
+	a.dL_dmean2D = dL_dmean2D;
+	a.dL_dconic = dL_dconic;
+	a.dL_dopacity = dL_dopacity;
+	a.dL_dcolors = dL_dcolor;
+	if (R > 0) {
+		hipError_t e = sgs::launch_blend_backward(st, a);
+		if (e != hipSuccess) return fail_hip(e, "blend backward");
+	}
+	SGS_CHECK_STAGE("blend backward");
+
+	const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : (const float*)(gchunk + gl.pub.cov3D);
+	sgs::launch_preprocess_bwd(st, P, D, M, means3D, radii, shs,
+				   (const uint8_t*)(gchunk + gl.pub.clamped), scales, rotations,
+				   scale_modifier, cov3D_ptr, viewmatrix, projmatrix, focal_x, focal_y,
+				   tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor,
+				   dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+	SGS_CHECK_STAGE("preprocess backward");
+	return 0;
+}
+
+int sgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+		     uint8_t* present, void* stream)
+{
+	(void)projmatrix;
+	if (P < 0) return fail(SGS_EINVAL, "bad sizes");
+	if (P == 0) return 0;
+	if (!means3D || !viewmatrix || !present) return fail(SGS_EINVAL, "null argument");
+	sgs::launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail_hip(e, "markVisible");
+	return 0;
+}
+
+int sgs_knn_mean_dist2(int P, const float* points, float* meanDists, sgs_alloc_fn scratch,
+		       void* scratch_user, void* stream)
+{
+	if (P < 0) return fail(SGS_EINVAL, "bad sizes");
+	if (P == 0) return 0;
+	if (!points || !meanDists || !scratch) return fail(SGS_EINVAL, "null argument");
+	const size_t bytes = sgs::knn_scratch_bytes(P);
+	char* s = (char*)scratch(scratch_user, bytes + 128);
+	if (!s) return fail(SGS_EALLOC, "scratch allocation failed");
+	hipError_t e = sgs::launch_knn((hipStream_t)stream, P, points, meanDists, align_ptr(s), bytes);
+	if (e != hipSuccess) return fail_hip(e, "knn");
+	return 0;
+}
+
+int sgs_debug_expf(int n, const float* in, float* out, void* stream)
+{
+	if (n < 0 || (n > 0 && (!in || !out))) return fail(SGS_EINVAL, "bad argument");
+	sgs::launch_debug_expf((hipStream_t)stream, n, in, out);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail_hip(e, "debug_expf");
+	return 0;
+}
+
+} // extern "C"

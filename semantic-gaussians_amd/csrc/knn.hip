@@ -1,0 +1,288 @@
+// knn.hip -- distCUDA2: mean squared distance to the three nearest other points (gfx950).
+//
+// Result restated from SK/simple_knn.cu:147-183 (boxMeanDist) / :186-220 (SimpleKNN::knn):
+// for point i, (d1 + d2 + d3) / 3 with d1 <= d2 <= d3 the three smallest squared Euclidean
+// distances to points at OTHER indices (duplicates count), d = dx*dx + dy*dy + dz*dz
+// evaluated left to right without FMA contraction.  The answer is the exact 3-NN; the
+// spatial structure only prunes, so it is free to differ from the reference's:
+//
+//  * bounding box by order-preserving integer atomics, kept ON DEVICE (the reference does
+//    two blocking D2H copies, simple_knn.cu:197,200);
+//  * 30-bit Morton codes + rocPRIM radix sort of (code, index) on the caller's stream;
+//  * points gathered into Morton order as float4 (coalesced 16-B reads);
+//  * a two-level box hierarchy: 64-point leaves (one wave of Morton-consecutive points) under
+//    1024-point super boxes -- the reference has the 1024-point level only, so a surviving
+//    box costs it 1024 distance tests where this costs ~64-200;
+//  * one lane per query in Morton order: the 64 lanes of a wave are spatial neighbours and
+//    walk almost the same boxes, so box tests are near-uniform branches and leaf reads hit L1.
+#include "sgs_kernels.h"
+#include <cstring>   // rocPRIM's texture iterator calls host memset
+#include <rocprim/rocprim.hpp>
+#include <float.h>
+
+namespace sgs {
+
+namespace {
+
+constexpr int LEAF = 64;
+constexpr int SUPER = 1024;
+
+__device__ __forceinline__ uint32_t enc(float f)
+{
+	const uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec(uint32_t e)
+{
+	const uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+	return __uint_as_float(u);
+}
+
+__global__ void bbox_init_kernel(uint32_t* __restrict__ bb)
+{
+	// the reference reduces with init {0,0,0} (simple_knn.cu:192): min <= 0 <= max
+	if (threadIdx.x < 6) bb[threadIdx.x] = enc(0.0f);
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(int P, const float* __restrict__ pts,
+						    uint32_t* __restrict__ bb)
+{
+	float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+	for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			const float v = pts[3 * (size_t)i + k];
+			mn[k] = v < mn[k] ? v : mn[k];
+			mx[k] = v > mx[k] ? v : mx[k];
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			const float a = __shfl_xor(mn[k], off), b = __shfl_xor(mx[k], off);
+			mn[k] = a < mn[k] ? a : mn[k];
+			mx[k] = b > mx[k] ? b : mx[k];
+		}
+	}
+	if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			atomicMin(&bb[k], enc(mn[k]));
+			atomicMax(&bb[3 + k], enc(mx[k]));
+		}
+	}
+}
+
+// SK/simple_knn.cu:45-61
+__device__ __forceinline__ uint32_t prep_morton(uint32_t x)
+{
+	x = (x | (x << 16)) & 0x030000FF;
+	x = (x | (x << 8)) & 0x0300F00F;
+	x = (x | (x << 4)) & 0x030C30C3;
+	x = (x | (x << 2)) & 0x09249249;
+	return x;
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(int P, const float* __restrict__ pts,
+						      const uint32_t* __restrict__ bb,
+						      uint32_t* __restrict__ codes,
+						      uint32_t* __restrict__ idx)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P) return;
+	uint32_t c[3];
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const float mn = dec(bb[k]), mx = dec(bb[3 + k]);
+		const float t = ((pts[3 * (size_t)i + k] - mn) / (mx - mn)) * (float)((1 << 10) - 1);
+		// degenerate axis (max == min) gives NaN; codes only steer pruning, any value is valid
+		c[k] = (t >= 0.f && t <= 1023.f) ? (uint32_t)t : 0u;
+	}
+	codes[i] = prep_morton(c[0]) | (prep_morton(c[1]) << 1) | (prep_morton(c[2]) << 2);
+	idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(int P, const float* __restrict__ pts,
+						      const uint32_t* __restrict__ idx_sorted,
+						      float4* __restrict__ sorted)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P) return;
+	const uint32_t j = idx_sorted[i];
+	sorted[i] = make_float4(pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2],
+				__uint_as_float(j));
+}
+
+struct Box {
+	float mnx, mny, mnz, mxx, mxy, mxz;
+};
+
+// one wave per leaf (64 Morton-consecutive points); 16 leaves per 1024-thread block whose
+// union is the super box.
+__global__ __launch_bounds__(1024) void boxes_kernel(int P, const float4* __restrict__ sorted,
+						      Box* __restrict__ leaves, Box* __restrict__ supers)
+{
+	const int i = blockIdx.x * SUPER + threadIdx.x;
+	float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+	if (i < P) {
+		const float4 p = sorted[i];
+		mn[0] = mx[0] = p.x;
+		mn[1] = mx[1] = p.y;
+		mn[2] = mx[2] = p.z;
+	}
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			const float a = __shfl_xor(mn[k], off), b = __shfl_xor(mx[k], off);
+			mn[k] = a < mn[k] ? a : mn[k];
+			mx[k] = b > mx[k] ? b : mx[k];
+		}
+	}
+	__shared__ Box s_b[SUPER / LEAF];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (lane == 0) {
+		const Box b = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
+		s_b[wave] = b;
+		const int leaf = blockIdx.x * (SUPER / LEAF) + wave;
+		if ((size_t)leaf * LEAF < (size_t)P) leaves[leaf] = b;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		Box u = s_b[0];
+		for (int w = 1; w < SUPER / LEAF; w++) {
+			const Box b = s_b[w];
+			u.mnx = b.mnx < u.mnx ? b.mnx : u.mnx;
+			u.mny = b.mny < u.mny ? b.mny : u.mny;
+			u.mnz = b.mnz < u.mnz ? b.mnz : u.mnz;
+			u.mxx = b.mxx > u.mxx ? b.mxx : u.mxx;
+			u.mxy = b.mxy > u.mxy ? b.mxy : u.mxy;
+			u.mxz = b.mxz > u.mxz ? b.mxz : u.mxz;
+		}
+		supers[blockIdx.x] = u;
+	}
+}
+
+// SK/simple_knn.cu:119-129
+__device__ __forceinline__ float dist_box_point(const Box& b, float x, float y, float z)
+{
+	float dx = 0.f, dy = 0.f, dz = 0.f;
+	if (x < b.mnx || x > b.mxx) dx = fmin_(fabsf(x - b.mnx), fabsf(x - b.mxx));
+	if (y < b.mny || y > b.mxy) dy = fmin_(fabsf(y - b.mny), fabsf(y - b.mxy));
+	if (z < b.mnz || z > b.mxz) dz = fmin_(fabsf(z - b.mnz), fabsf(z - b.mxz));
+	return dx * dx + dy * dy + dz * dz;
+}
+
+// SK/simple_knn.cu:131-145
+__device__ __forceinline__ void update3(float dist, float& b0, float& b1, float& b2)
+{
+	if (b0 > dist) { const float t = b0; b0 = dist; dist = t; }
+	if (b1 > dist) { const float t = b1; b1 = dist; dist = t; }
+	if (b2 > dist) { const float t = b2; b2 = dist; dist = t; }
+}
+
+__global__ __launch_bounds__(256) void knn_kernel(int P, const float4* __restrict__ sorted,
+						   const Box* __restrict__ leaves,
+						   const Box* __restrict__ supers, float* __restrict__ out)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P) return;
+	const float4 q = sorted[i];
+	float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+	// seed with the +-3 Morton neighbours (simple_knn.cu:156-161): an upper bound on d3
+	for (int j = (i - 3 < 0 ? 0 : i - 3); j <= (i + 3 > P - 1 ? P - 1 : i + 3); j++) {
+		if (j == i) continue;
+		const float4 p = sorted[j];
+		const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+		update3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+	}
+	const float reject = b2;
+	b0 = b1 = b2 = FLT_MAX;
+	const int nsuper = (P + SUPER - 1) / SUPER;
+	const int nleaf = (P + LEAF - 1) / LEAF;
+	for (int s = 0; s < nsuper; s++) {
+		const Box sb = supers[s];
+		const float ds = dist_box_point(sb, q.x, q.y, q.z);
+		if (ds > reject || ds > b2) continue;
+		const int l1 = (s + 1) * (SUPER / LEAF) < nleaf ? (s + 1) * (SUPER / LEAF) : nleaf;
+		for (int l = s * (SUPER / LEAF); l < l1; l++) {
+			const Box lb = leaves[l];
+			const float dl = dist_box_point(lb, q.x, q.y, q.z);
+			if (dl > reject || dl > b2) continue;
+			const int j1 = (l + 1) * LEAF < P ? (l + 1) * LEAF : P;
+			for (int j = l * LEAF; j < j1; j++) {
+				if (j == i) continue;
+				const float4 p = sorted[j];
+				const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+				update3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+			}
+		}
+	}
+	out[__float_as_uint(q.w)] = (b0 + b1 + b2) / 3.0f;
+}
+
+struct KnnLayout {
+	size_t bb, codes, idx, codes_sorted, idx_sorted, sorted, leaves, supers, sort_temp,
+		sort_temp_bytes, total;
+};
+
+inline size_t al(size_t x) { return (x + 127) & ~(size_t)127; }
+
+KnnLayout knn_layout(int P)
+{
+	KnnLayout l;
+	size_t off = 0;
+	auto take = [&](size_t bytes) { off = al(off); const size_t o = off; off += bytes; return o; };
+	const size_t p = (size_t)P;
+	l.bb = take(6 * 4);
+	l.codes = take(p * 4);
+	l.idx = take(p * 4);
+	l.codes_sorted = take(p * 4);
+	l.idx_sorted = take(p * 4);
+	l.sorted = take(p * 16);
+	l.leaves = take(((p + LEAF - 1) / LEAF) * sizeof(Box));
+	l.supers = take(((p + SUPER - 1) / SUPER) * sizeof(Box));
+	l.sort_temp_bytes = 0;
+	(void)rocprim::radix_sort_pairs(nullptr, l.sort_temp_bytes, (uint32_t*)nullptr,
+					(uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, p,
+					0u, 30u, (hipStream_t)0);
+	l.sort_temp = take(l.sort_temp_bytes);
+	l.total = al(off);
+	return l;
+}
+
+} // namespace
+
+size_t knn_scratch_bytes(int P) { return knn_layout(P).total; }
+
+hipError_t launch_knn(hipStream_t st, int P, const float* points, float* out, void* scratch,
+		      size_t scratch_bytes)
+{
+	const KnnLayout l = knn_layout(P);
+	if (scratch_bytes < l.total) return hipErrorInvalidValue;
+	char* s = (char*)scratch;
+	uint32_t* bb = (uint32_t*)(s + l.bb);
+	uint32_t* codes = (uint32_t*)(s + l.codes);
+	uint32_t* idx = (uint32_t*)(s + l.idx);
+	uint32_t* codes_sorted = (uint32_t*)(s + l.codes_sorted);
+	uint32_t* idx_sorted = (uint32_t*)(s + l.idx_sorted);
+	float4* sorted = (float4*)(s + l.sorted);
+	Box* leaves = (Box*)(s + l.leaves);
+	Box* supers = (Box*)(s + l.supers);
+	const int nb = (P + 255) / 256;
+	hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, bb);
+	hipLaunchKernelGGL(bbox_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, st, P, points, bb);
+	hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(256), 0, st, P, points, bb, codes, idx);
+	hipError_t e = rocprim::radix_sort_pairs(s + l.sort_temp, const_cast<size_t&>(l.sort_temp_bytes),
+						 codes, codes_sorted, idx, idx_sorted, (size_t)P, 0u, 30u,
+						 st);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(256), 0, st, P, points, idx_sorted, sorted);
+	hipLaunchKernelGGL(boxes_kernel, dim3((P + SUPER - 1) / SUPER), dim3(SUPER), 0, st, P, sorted,
+			   leaves, supers);
+	hipLaunchKernelGGL(knn_kernel, dim3(nb), dim3(256), 0, st, P, sorted, leaves, supers, out);
+	return hipGetLastError();
+}
+
+} // namespace sgs

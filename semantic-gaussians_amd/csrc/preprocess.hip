@@ -1,0 +1,156 @@
+// preprocess.hip -- per-Gaussian forward preprocess and frustum marking (gfx950).
+//
+// One lane per Gaussian, 256-lane workgroups (4 wave64).  The work is ~100 flops and
+// <= 123 B of traffic per Gaussian, i.e. HBM-trivial (0.1 GB at 1M Gaussians); the only
+// requirement here is bit-exact integer outputs (radii, tiles_touched, depth bits), so
+// the arithmetic follows sgs_device.h's contract with contraction disabled.
+//
+// Behaviour restated from CR/cuda_rasterizer/forward.cu:155-256 (preprocessCUDA),
+// auxiliary.h:139-164 (in_frustum) and rasterizer_impl.cu:54-66 (checkFrustum).
+#include "sgs_kernels.h"
+
+namespace sgs {
+
+// SH -> RGB for one Gaussian (forward.cu:20-71).  sh points at (M,3) coefficients.
+__device__ __forceinline__ void sh_to_rgb(int deg, float px, float py, float pz,
+					  const float* __restrict__ campos,
+					  const float* __restrict__ sh, float* __restrict__ rgb,
+					  uint8_t* __restrict__ clamped)
+{
+	const float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
+	const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+	const float x = dx / len, y = dy / len, z = dz / len;
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+#define SGS_S(i) sh[3 * (i) + c]
+		float r = SH_C0 * SGS_S(0);
+		if (deg > 0) {
+			r = r - SH_C1 * y * SGS_S(1) + SH_C1 * z * SGS_S(2) - SH_C1 * x * SGS_S(3);
+			if (deg > 1) {
+				const float xx = x * x, yy = y * y, zz = z * z;
+				const float xy = x * y, yz = y * z, xz = x * z;
+				r = r + SH_C2[0] * xy * SGS_S(4) + SH_C2[1] * yz * SGS_S(5) +
+				    SH_C2[2] * (2.0f * zz - xx - yy) * SGS_S(6) +
+				    SH_C2[3] * xz * SGS_S(7) + SH_C2[4] * (xx - yy) * SGS_S(8);
+				if (deg > 2) {
+					r = r + SH_C3[0] * y * (3.0f * xx - yy) * SGS_S(9) +
+					    SH_C3[1] * xy * z * SGS_S(10) +
+					    SH_C3[2] * y * (4.0f * zz - xx - yy) * SGS_S(11) +
+					    SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SGS_S(12) +
+					    SH_C3[4] * x * (4.0f * zz - xx - yy) * SGS_S(13) +
+					    SH_C3[5] * z * (xx - yy) * SGS_S(14) +
+					    SH_C3[6] * x * (xx - 3.0f * yy) * SGS_S(15);
+				}
+			}
+		}
+#undef SGS_S
+		r += 0.5f;
+		clamped[c] = (r < 0) ? 1 : 0;
+		rgb[c] = fmax_(r, 0.0f);
+	}
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+	int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+	float mod, const float* __restrict__ rotations, const float* __restrict__ opacities,
+	const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+	const float* __restrict__ colors_precomp, const float* __restrict__ view,
+	const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, float tanx,
+	float tany, float fx, float fy, int gx, int gy, int prefiltered, int num_channels,
+	int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depths,
+	float* __restrict__ cov3Ds, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
+	float4* __restrict__ conic_opacity, uint32_t* __restrict__ tiles_touched,
+	int* __restrict__ trap_flag)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P) return;
+	radii[i] = 0;
+	tiles_touched[i] = 0;
+
+	const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1],
+		    pz = means3D[3 * (size_t)i + 2];
+	const f4 ph = xf4x4(proj, px, py, pz);
+	const f3 pv = xf4x3(view, px, py, pz);
+	if (pv.z <= 0.2f) {
+		// reference: printf + __trap() (auxiliary.h:156-160); here: flag, the host
+		// turns it into SGS_ETRAP.
+		if (prefiltered) atomicOr(trap_flag, 1);
+		return;
+	}
+	const float pw = 1.0f / (ph.w + 0.0000001f);
+	const float ppx = ph.x * pw, ppy = ph.y * pw;
+
+	float cov3D[6];
+	if (cov3D_precomp) {
+#pragma unroll
+		for (int k = 0; k < 6; k++) cov3D[k] = cov3D_precomp[6 * (size_t)i + k];
+	} else {
+		cov3d_from_scale_rot(scales[3 * (size_t)i], scales[3 * (size_t)i + 1],
+				     scales[3 * (size_t)i + 2], mod, rotations[4 * (size_t)i],
+				     rotations[4 * (size_t)i + 1], rotations[4 * (size_t)i + 2],
+				     rotations[4 * (size_t)i + 3], cov3D);
+#pragma unroll
+		for (int k = 0; k < 6; k++) cov3Ds[6 * (size_t)i + k] = cov3D[k];
+	}
+	const Cov2D c2 = cov2d_parts(px, py, pz, fx, fy, tanx, tany, cov3D, view);
+	const float det = c2.a * c2.c - c2.b * c2.b;
+	if (det == 0.0f) return;
+	const float det_inv = 1.f / det;
+	const float conx = c2.c * det_inv, cony = -c2.b * det_inv, conz = c2.a * det_inv;
+	const float mid = 0.5f * (c2.a + c2.c);
+	const float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
+	const float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
+	const float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
+	const float pix_x = ndc2pix(ppx, W), pix_y = ndc2pix(ppy, H);
+	uint32_t x0, y0, x1, y1;
+	get_rect(pix_x, pix_y, (int)my_radius, gx, gy, x0, y0, x1, y1);
+	if ((x1 - x0) * (y1 - y0) == 0) return;
+
+	if (!colors_precomp)
+		sh_to_rgb(D, px, py, pz, campos, shs + (size_t)i * M * 3,
+			  rgb + (size_t)i * num_channels, clamped + 3 * (size_t)i);
+
+	depths[i] = pv.z;
+	radii[i] = (int)my_radius;
+	means2D[i] = make_float2(pix_x, pix_y);
+	conic_opacity[i] = make_float4(conx, cony, conz, opacities[i]);
+	tiles_touched[i] = (y1 - y0) * (x1 - x0);
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P,
+							    const float* __restrict__ means3D,
+							    const float* __restrict__ view,
+							    uint8_t* __restrict__ present)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P) return;
+	const f3 pv = xf4x3(view, means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1],
+			    means3D[3 * (size_t)i + 2]);
+	present[i] = !(pv.z <= 0.2f);
+}
+
+void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* means3D,
+			   const float* scales, float mod, const float* rotations,
+			   const float* opacities, const float* shs, const float* cov3D_precomp,
+			   const float* colors_precomp, const float* view, const float* proj,
+			   const float* campos, int W, int H, float tanx, float tany, float fx,
+			   float fy, int gx, int gy, int prefiltered, int num_channels, int* radii,
+			   float2* means2D, float* depths, float* cov3Ds, float* rgb,
+			   uint8_t* clamped, float4* conic_opacity, uint32_t* tiles_touched,
+			   int* trap_flag)
+{
+	hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, D, M,
+			   means3D, scales, mod, rotations, opacities, shs, cov3D_precomp,
+			   colors_precomp, view, proj, campos, W, H, tanx, tany, fx, fy, gx, gy,
+			   prefiltered, num_channels, radii, means2D, depths, cov3Ds, rgb, clamped,
+			   conic_opacity, tiles_touched, trap_flag);
+}
+
+void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view,
+			 uint8_t* present)
+{
+	hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, means3D,
+			   view, present);
+}
+
+} // namespace sgs

@@ -1,0 +1,184 @@
+// sgs_device.h -- device-side arithmetic contract shared by all gfx950 kernels.
+//
+// Everything here is evaluated in fp32, left to right as written, with no implicit FMA
+// contraction (the build passes -ffp-contract=off); fmaf() appears only where the
+// contract (DESIGN.md "arithmetic contract") says "fma".  The CPU oracle restates the
+// same formulas independently (oracle/sgs_oracle.c); integer outputs (radii, tiles
+// touched, keys, sorted lists, n_contrib) must agree bit for bit.
+//
+// Reference semantics restated (not copied): CR/cuda_rasterizer/auxiliary.h:41-164,
+// forward.cu:20-151 (CR = submodules/channel-rasterization of the reference).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SGS_TILE 16
+#define SGS_TILE_PX 256
+
+namespace sgs {
+
+__device__ __forceinline__ float fmin_(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float fmax_(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+// out_k = m[k]x + m[4+k]y + m[8+k]z + m[12+k]   (auxiliary.h:58-77)
+__device__ __forceinline__ f3 xf4x3(const float* __restrict__ m, float x, float y, float z)
+{
+	f3 o;
+	o.x = m[0] * x + m[4] * y + m[8] * z + m[12];
+	o.y = m[1] * x + m[5] * y + m[9] * z + m[13];
+	o.z = m[2] * x + m[6] * y + m[10] * z + m[14];
+	return o;
+}
+__device__ __forceinline__ f4 xf4x4(const float* __restrict__ m, float x, float y, float z)
+{
+	f4 o;
+	o.x = m[0] * x + m[4] * y + m[8] * z + m[12];
+	o.y = m[1] * x + m[5] * y + m[9] * z + m[13];
+	o.z = m[2] * x + m[6] * y + m[10] * z + m[14];
+	o.w = m[3] * x + m[7] * y + m[11] * z + m[15];
+	return o;
+}
+
+// auxiliary.h:41-44 -- evaluated in double, rounded once to fp32.
+__device__ __forceinline__ float ndc2pix(float v, int S)
+{
+	return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+// auxiliary.h:46-56 -- fp32 arithmetic, C cast (truncation), clamp to [0, grid].
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy,
+					 uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1)
+{
+	const float r = (float)max_radius;
+	x0 = (uint32_t)imin_(gx, imax_(0, (int)((px - r) / (float)SGS_TILE)));
+	y0 = (uint32_t)imin_(gy, imax_(0, (int)((py - r) / (float)SGS_TILE)));
+	x1 = (uint32_t)imin_(gx, imax_(0, (int)((px + r + (float)(SGS_TILE - 1)) / (float)SGS_TILE)));
+	y1 = (uint32_t)imin_(gy, imax_(0, (int)((py + r + (float)(SGS_TILE - 1)) / (float)SGS_TILE)));
+}
+
+// Blend exponential ("exp contract"): range reduction by the 1.5*2^23 magic
+// add, two-term ln2, degree-5 Horner with explicit fma, exponent insertion by integer
+// add.  <= 5 ulp from exp(); reproduced bit for bit by the oracle so that the
+// alpha < 1/255 and T < 1e-4 decisions of the blend are identical on both sides.
+__device__ __forceinline__ float expf_contract(float x)
+{
+	const float LOG2E = 1.44269504088896341f;
+	const float LN2_HI = 0.693145751953125f;
+	const float LN2_LO = 1.42860682030941723e-6f;
+	const float MAGIC = 12582912.0f;
+	x = fmax_(x, -87.0f);
+	const float t = x * LOG2E;
+	float nf = t + MAGIC;
+	// keep the compiler from re-associating (t+M)-M
+	asm volatile("" : "+v"(nf));
+	const float n = nf - MAGIC;
+	float r = __builtin_fmaf(n, -LN2_HI, x);
+	r = __builtin_fmaf(n, -LN2_LO, r);
+	float p = 0.008182921446859837f;
+	p = __builtin_fmaf(p, r, 0.04184672236442566f);
+	p = __builtin_fmaf(p, r, 0.16668450832366943f);
+	p = __builtin_fmaf(p, r, 0.4999966621398926f);
+	p = __builtin_fmaf(p, r, 1.0f);
+	p = __builtin_fmaf(p, r, 1.0f);
+	return __uint_as_float(__float_as_uint(p) + (__float_as_uint(nf) << 23));
+}
+
+// Standard (w,x,y,z) rotation matrix, rows R[0..2] (forward.cu:127-137).
+__device__ __forceinline__ void rot_matrix(float r, float x, float y, float z, float R[3][3])
+{
+	R[0][0] = 1.f - 2.f * (y * y + z * z);
+	R[0][1] = 2.f * (x * y - r * z);
+	R[0][2] = 2.f * (x * z + r * y);
+	R[1][0] = 2.f * (x * y + r * z);
+	R[1][1] = 1.f - 2.f * (x * x + z * z);
+	R[1][2] = 2.f * (y * z - r * x);
+	R[2][0] = 2.f * (x * z - r * y);
+	R[2][1] = 2.f * (y * z + r * x);
+	R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R diag(mod*s)^2 R^T, accumulated as sum_k M(k,i) M(k,j) with
+// M(k,i) = (mod*s_k) * R(i,k), k ascending (forward.cu:118-151 through glm's
+// column-major algebra).  cov = xx, xy, xz, yy, yz, zz.
+__device__ __forceinline__ void cov3d_from_scale_rot(float sx, float sy, float sz, float mod,
+						     float qr, float qx, float qy, float qz,
+						     float cov[6])
+{
+	float R[3][3], M[3][3];
+	rot_matrix(qr, qx, qy, qz, R);
+	const float s[3] = {mod * sx, mod * sy, mod * sz};
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+#pragma unroll
+		for (int i = 0; i < 3; i++) M[k][i] = s[k] * R[i][k];
+#define SGS_SIG(i, j) (M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j])
+	cov[0] = SGS_SIG(0, 0);
+	cov[1] = SGS_SIG(1, 0);
+	cov[2] = SGS_SIG(2, 0);
+	cov[3] = SGS_SIG(1, 1);
+	cov[4] = SGS_SIG(2, 1);
+	cov[5] = SGS_SIG(2, 2);
+#undef SGS_SIG
+}
+
+// EWA projection pieces shared by forward (forward.cu:74-113) and backward
+// (backward.cu:163-196): clamped view-space mean t, T[i][j] = (J*Wr)(i,j) and the
+// low-pass filtered 2D covariance (a,b,c).
+struct Cov2D {
+	float t[3];
+	float txtz, tytz;
+	float T[2][3];
+	float a, b, c;
+};
+__device__ __forceinline__ Cov2D cov2d_parts(float mx, float my, float mz, float fx, float fy,
+					     float tanx, float tany, const float cov3D[6],
+					     const float* __restrict__ view)
+{
+	Cov2D o;
+	f3 t = xf4x3(view, mx, my, mz);
+	const float limx = 1.3f * tanx, limy = 1.3f * tany;
+	const float txtz = t.x / t.z, tytz = t.y / t.z;
+	t.x = fmin_(limx, fmax_(-limx, txtz)) * t.z;
+	t.y = fmin_(limy, fmax_(-limy, tytz)) * t.z;
+	o.t[0] = t.x; o.t[1] = t.y; o.t[2] = t.z;
+	o.txtz = txtz; o.tytz = tytz;
+	const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+	const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+	for (int r = 0; r < 3; r++) {
+		o.T[0][r] = view[4 * r] * J00 + view[4 * r + 2] * J02;
+		o.T[1][r] = view[4 * r + 1] * J11 + view[4 * r + 2] * J12;
+	}
+	const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]},
+			       {cov3D[1], cov3D[3], cov3D[4]},
+			       {cov3D[2], cov3D[4], cov3D[5]}};
+	float X[2][3];
+#pragma unroll
+	for (int r = 0; r < 2; r++)
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+			X[r][c] = o.T[r][0] * V[c][0] + o.T[r][1] * V[c][1] + o.T[r][2] * V[c][2];
+	o.a = X[0][0] * o.T[0][0] + X[0][1] * o.T[0][1] + X[0][2] * o.T[0][2];
+	o.b = X[1][0] * o.T[0][0] + X[1][1] * o.T[0][1] + X[1][2] * o.T[0][2];
+	o.c = X[1][0] * o.T[1][0] + X[1][1] * o.T[1][1] + X[1][2] * o.T[1][2];
+	o.a += 0.3f;
+	o.c += 0.3f;
+	return o;
+}
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f,
+				       0.31539156525252005f, -1.0925484305920792f,
+				       0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
+				       -0.4570457994644658f, 0.3731763325901154f,
+				       -0.4570457994644658f, 1.445305721320277f,
+				       -0.5900435899266435f};
+
+} // namespace sgs

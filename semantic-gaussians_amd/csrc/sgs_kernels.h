@@ -1,0 +1,88 @@
+// sgs_kernels.h -- host-side launcher declarations (internal to libsgs_hip.so).
+#pragma once
+#include "sgs_device.h"
+#include <stddef.h>
+
+namespace sgs {
+
+// ---- preprocess.hip
+void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* means3D,
+			   const float* scales, float mod, const float* rotations,
+			   const float* opacities, const float* shs, const float* cov3D_precomp,
+			   const float* colors_precomp, const float* view, const float* proj,
+			   const float* campos, int W, int H, float tanx, float tany, float fx,
+			   float fy, int gx, int gy, int prefiltered, int num_channels, int* radii,
+			   float2* means2D, float* depths, float* cov3Ds, float* rgb,
+			   uint8_t* clamped, float4* conic_opacity, uint32_t* tiles_touched,
+			   int* trap_flag);
+void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view,
+			 uint8_t* present);
+
+// ---- binning.hip
+size_t scan_temp_bytes(int P);
+hipError_t launch_inclusive_scan(hipStream_t st, void* temp, size_t temp_bytes,
+				 const uint32_t* in, uint32_t* out, int P);
+void launch_duplicate_with_keys(hipStream_t st, int P, const float2* means2D, const float* depths,
+				const uint32_t* offsets, const int* radii, int gx, int gy,
+				uint64_t* keys, uint32_t* vals, uint32_t L);
+size_t sort_temp_bytes(size_t L, int end_bit);
+hipError_t launch_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint64_t* keys_in,
+			     uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,
+			     int end_bit);
+void launch_tile_ranges(hipStream_t st, size_t L, const uint64_t* keys, uint2* ranges, int ntiles);
+
+// ---- blend_fwd.hip
+struct BlendFwdArgs {
+	const uint2* ranges;
+	const uint32_t* point_list;
+	int W, H, C;
+	int gx, gy;
+	const float2* means2D;
+	const float* features;       // (P,C) row-major
+	const float4* conic_opacity;
+	const float* depths;         // per Gaussian view z (RGB-D variant)
+	const float* bg;             // (C)
+	float* final_T;              // (H*W)
+	uint32_t* n_contrib;         // (H*W)
+	float* out;                  // (C,H,W)
+	float* out_depth;            // (H*W) or null
+};
+hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int variant);
+
+// ---- blend_bwd.hip
+struct BlendBwdArgs {
+	const uint2* ranges;
+	const uint32_t* point_list;
+	int W, H, C;
+	int gx, gy;
+	const float* bg;
+	const float2* means2D;
+	const float4* conic_opacity;
+	const float* colors;         // (P,C)
+	const float* final_T;
+	const uint32_t* n_contrib;
+	const float* dL_dpix;        // (C,H,W)
+	float* dL_dmean2D;           // (P,3)
+	float* dL_dconic;            // (P,4)
+	float* dL_dopacity;          // (P)
+	float* dL_dcolors;           // (P,C)
+};
+hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a);
+void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
+			   const int* radii, const float* shs, const uint8_t* clamped,
+			   const float* scales, const float* rotations, float mod,
+			   const float* cov3Ds, const float* view, const float* proj, float fx,
+			   float fy, float tanx, float tany, const float* campos,
+			   const float* dL_dmean2D, const float* dL_dconic, float* dL_dmeans,
+			   const float* dL_dcolor, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+			   float* dL_drot);
+
+// ---- knn.hip
+size_t knn_scratch_bytes(int P);
+hipError_t launch_knn(hipStream_t st, int P, const float* points, float* out, void* scratch,
+		      size_t scratch_bytes);
+
+// ---- misc
+void launch_debug_expf(hipStream_t st, int n, const float* in, float* out);
+
+} // namespace sgs

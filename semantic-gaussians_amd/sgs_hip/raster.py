@@ -1,0 +1,275 @@
+"""Torch-tensor front end of the C-ABI: the counterpart of the reference's C++ glue
+(CR/rasterize_points.cu:28-223, RR/rasterize_points.cu, SK/spatial.cu:15-26).
+
+PyTorch is used for device memory and streams only: outputs and the three opaque state
+buffers are torch tensors (caching allocator, current stream), everything else happens
+inside libsgs_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t, name, device, dtype=torch.float32):
+    """Device pointer of an input tensor; empty tensor -> NULL ("not provided",
+    CR/channel_rasterization/__init__.py:266-276)."""
+    if t is None or t.numel() == 0:
+        return None, None
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected scalar type {dtype} for {name} but found {t.dtype}")
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    t = t.contiguous()   # non-contiguous inputs are legal (rasterize_points.cu:99-117)
+    return t.data_ptr(), t
+
+
+class _Buffers:
+    """Growable byte buffers handed to the library through the sgs_alloc_fn callback
+    (the reference's resizeFunctional, CR/rasterize_points.cu:28-36)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensors = {}
+        self._cbs = {}
+
+    def callback(self, key):
+        def alloc(_user, nbytes):
+            try:
+                t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                self.tensors[key] = t
+                return t.data_ptr()
+            except Exception:   # noqa: BLE001 - reported as SGS_EALLOC by the library
+                return None
+        cb = _lib.ALLOC_FN(alloc)
+        self._cbs[key] = cb
+        return cb
+
+    def get(self, key):
+        t = self.tensors.get(key)
+        if t is None:
+            t = torch.empty(0, dtype=torch.uint8, device=self.device)
+        return t
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                      image_width, sh, degree, campos, prefiltered, debug, num_channels,
+                      want_depth):
+    """RasterizeGaussiansCUDA (CR/rasterize_points.cu:38-121; RR variant returns depth too).
+    Returns (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth)."""
+    lib = _lib.load()
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor (there is no CPU path)")
+    dev = means3D.device
+    P, H, W, Cn = means3D.size(0), int(image_height), int(image_width), int(num_channels)
+    keep = []
+    with torch.cuda.device(dev):
+        bufs = _Buffers(dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        depth = None
+        if P == 0:
+            # reference returns zero-filled outputs without touching bg (rasterize_points.cu:85)
+            color = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
+            if want_depth:
+                depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
+            return 0, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
+        color = torch.empty(Cn, H, W, dtype=torch.float32, device=dev)   # fully overwritten
+        if want_depth:
+            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+
+        def p(t, name):
+            ptr, kept = _ptr(t, name, dev)
+            keep.append(kept)
+            return ptr
+
+        bg = background
+        if bg is not None and bg.numel() < Cn:
+            raise RuntimeError(
+                f"bg has {bg.numel()} entries but num_channels={Cn} (the reference reads out of "
+                "bounds here, CR/cuda_rasterizer/forward.cu:373)")
+        M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+        rc = lib.sgs_rasterize_forward(
+            bufs.callback("g"), None, bufs.callback("b"), None, bufs.callback("i"), None,
+            P, int(degree), int(M), p(bg, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
+            p(colors, "colors_precomp"), p(opacity, "opacities"), p(scales, "scales"),
+            float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+            p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+            float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), Cn, color.data_ptr(),
+            depth.data_ptr() if depth is not None else None, radii.data_ptr(), int(bool(debug)),
+            _stream_ptr(dev))
+        num_rendered = _lib.check(rc, "rasterize_gaussians failed")
+    return num_rendered, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
+
+
+def rasterize_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                       sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (CR/rasterize_points.cu:123-202) with the colour channel
+    count taken from dL_dout_color (the reference hard-codes NUM_CHANNELS = 3)."""
+    lib = _lib.load()
+    dev = means3D.device
+    P = means3D.size(0)
+    Cn, H, W = dL_dout_color.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+    opts = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        dL_dmeans3D = torch.zeros(P, 3, **opts)
+        dL_dmeans2D = torch.zeros(P, 3, **opts)
+        dL_dcolors = torch.zeros(P, Cn, **opts)
+        dL_dconic = torch.zeros(P, 2, 2, **opts)
+        dL_dopacity = torch.zeros(P, 1, **opts)
+        dL_dcov3D = torch.zeros(P, 6, **opts)
+        dL_dsh = torch.zeros(P, M, 3, **opts)
+        dL_dscales = torch.zeros(P, 3, **opts)
+        dL_drotations = torch.zeros(P, 4, **opts)
+        if P != 0:
+            keep = []
+
+            def p(t, name, dtype=torch.float32):
+                ptr, kept = _ptr(t, name, dev, dtype)
+                keep.append(kept)
+                return ptr
+
+            rc = lib.sgs_rasterize_backward(
+                P, int(degree), int(M), int(R), p(background, "bg"), W, H, p(means3D, "means3D"),
+                p(sh, "sh"), p(colors, "colors_precomp"), p(scales, "scales"),
+                float(scale_modifier), p(rotations, "rotations"),
+                p(cov3D_precomp, "cov3D_precomp"), p(viewmatrix, "viewmatrix"),
+                p(projmatrix, "projmatrix"), p(campos, "campos"), float(tan_fovx),
+                float(tan_fovy), p(radii, "radii", torch.int32),
+                p(geomBuffer, "geomBuffer", torch.uint8),
+                p(binningBuffer, "binningBuffer", torch.uint8),
+                p(imageBuffer, "imageBuffer", torch.uint8), p(dL_dout_color, "dL_dout_color"),
+                Cn, dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
+                dL_drotations.data_ptr(), int(bool(debug)), _stream_ptr(dev))
+            _lib.check(rc, "rasterize_gaussians_backward failed")
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+            dL_drotations)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (CR/rasterize_points.cu:204-223)."""
+    lib = _lib.load()
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor (there is no CPU path)")
+    dev = means3D.device
+    P = means3D.size(0)
+    with torch.cuda.device(dev):
+        present = torch.zeros(P, dtype=torch.bool, device=dev)
+        if P != 0:
+            m_ptr, m = _ptr(means3D, "means3D", dev)
+            v_ptr, v = _ptr(viewmatrix, "viewmatrix", dev)
+            pr_ptr, pr = _ptr(projmatrix, "projmatrix", dev)
+            rc = lib.sgs_mark_visible(P, m_ptr, v_ptr, pr_ptr, present.data_ptr(), _stream_ptr(dev))
+            _lib.check(rc, "mark_visible failed")
+    return present
+
+
+def dist2(points):
+    """distCUDA2 (SK/spatial.cu:15-26): (P,3) f32 -> (P,) f32."""
+    lib = _lib.load()
+    if not points.is_cuda:
+        raise RuntimeError("points must be a GPU tensor (there is no CPU path)")
+    dev = points.device
+    P = points.size(0)
+    with torch.cuda.device(dev):
+        means = torch.zeros(P, dtype=torch.float32, device=dev)
+        if P != 0:
+            ptr, pts = _ptr(points, "points", dev)
+            bufs = _Buffers(dev)
+            rc = lib.sgs_knn_mean_dist2(P, ptr, means.data_ptr(), bufs.callback("s"), None,
+                                        _stream_ptr(dev))
+            _lib.check(rc, "distCUDA2 failed")
+    return means
+
+
+# ---- introspection used by the parity tests (not part of the reference's interface) --------
+def geometry_views(geomBuffer, P):
+    """Typed views into the opaque geometry buffer."""
+    lay = _lib.GeometryLayout()
+    _lib.check(_lib.load().sgs_geometry_layout_of(int(P), C.byref(lay)), "layout")
+    base = _aligned(geomBuffer)
+
+    def v(off, nbytes, dtype, shape):
+        return base[off:off + nbytes].view(dtype).view(*shape)
+    return dict(
+        depths=v(lay.depths, 4 * P, torch.float32, (P,)),
+        clamped=v(lay.clamped, 3 * P, torch.uint8, (P, 3)),
+        means2D=v(lay.means2D, 8 * P, torch.float32, (P, 2)),
+        cov3D=v(lay.cov3D, 24 * P, torch.float32, (P, 6)),
+        conic_opacity=v(lay.conic_opacity, 16 * P, torch.float32, (P, 4)),
+        rgb=v(lay.rgb, 12 * P, torch.float32, (P, 3)),
+        tiles_touched=v(lay.tiles_touched, 4 * P, torch.int32, (P,)),
+        point_offsets=v(lay.point_offsets, 4 * P, torch.int32, (P,)))
+
+
+def binning_views(binningBuffer, L):
+    lay = _lib.BinningLayout()
+    _lib.check(_lib.load().sgs_binning_layout_of(int(L), C.byref(lay)), "layout")
+    base = _aligned(binningBuffer)
+
+    def v(off, nbytes, dtype):
+        return base[off:off + nbytes].view(dtype)
+    return dict(
+        keys_unsorted=v(lay.keys_unsorted, 8 * L, torch.int64),
+        vals_unsorted=v(lay.vals_unsorted, 4 * L, torch.int32),
+        keys_sorted=v(lay.keys_sorted, 8 * L, torch.int64),
+        point_list=v(lay.point_list, 4 * L, torch.int32))
+
+
+def image_views(imgBuffer, W, H):
+    lay = _lib.ImageLayout()
+    _lib.check(_lib.load().sgs_image_layout_of(int(W), int(H), C.byref(lay)), "layout")
+    base = _aligned(imgBuffer)
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def v(off, nbytes, dtype, shape):
+        return base[off:off + nbytes].view(dtype).view(*shape)
+    return dict(
+        final_T=v(lay.accum_alpha, 4 * W * H, torch.float32, (H, W)),
+        n_contrib=v(lay.n_contrib, 4 * W * H, torch.int32, (H, W)),
+        ranges=v(lay.ranges, 8 * tiles, torch.int32, (tiles, 2)))
+
+
+def _aligned(buf):
+    """The library carves from the 128-B aligned address inside the caller's chunk."""
+    off = (-buf.data_ptr()) % 128
+    return buf[off:]
+
+
+def sort_bits(W, H):
+    return int(_lib.load().sgs_sort_bits(int(W), int(H)))
+
+
+def debug_expf(x):
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.sgs_debug_expf(x.numel(), x.data_ptr(), out.data_ptr(),
+                                      _stream_ptr(x.device)), "debug_expf")
+    return out
+
+
+def set_blend_variant(v):
+    return int(_lib.load().sgs_set_blend_variant(int(v)))
+
+
+def set_stage_timing(on):
+    return int(_lib.load().sgs_set_stage_timing(int(bool(on))))
+
+
+def get_stage_ms():
+    arr = (C.c_float * 6)()
+    _lib.load().sgs_get_stage_ms(arr)
+    return [float(a) for a in arr]
