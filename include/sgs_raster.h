@@ -196,9 +196,13 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
 /* Tuning / measurement hooks (not part of the reference's interface). */
 /* Selects the blend-forward kernel variant (0 = default).  Returns previous value. */
 int sgs_set_blend_variant(int variant);
-/* Device time (ms, hipEvent on `stream`) of each stage of the LAST forward call made
- * with timing enabled.  stages: 0 preprocess 1 scan 2 duplicate 3 sort 4 ranges 5 blend */
-int sgs_set_stage_timing(int enable);
+/* Device time (ms, hipEvents on `stream`) of each stage of the forward.
+ * stages: 0 preprocess 1 scan+readback 2 duplicate 3 sort 4 ranges 5 blend
+ * mode 0 off; 1 = resolve at the end of each call (adds a host sync per forward);
+ * 2 = deferred: events are parked and sgs_get_stage_ms() returns the MEAN over all
+ * forwards since the last query (no extra synchronisation inside the timed region).
+ * sgs_get_stage_ms returns the number of forwards averaged (0 in mode 1). */
+int sgs_set_stage_timing(int mode);
 int sgs_get_stage_ms(float *ms6);
 
 #ifdef __cplusplus

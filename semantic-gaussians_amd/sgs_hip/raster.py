@@ -266,7 +266,7 @@ def set_blend_variant(v):
 
 
 def set_stage_timing(on):
-    return int(_lib.load().sgs_set_stage_timing(int(bool(on))))
+    return int(_lib.load().sgs_set_stage_timing(int(on)))
 
 
 def get_stage_ms():
