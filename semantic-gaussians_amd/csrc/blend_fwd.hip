@@ -183,8 +183,9 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 	const float2* __restrict__ means2D, const float* __restrict__ features,
 	const float4* __restrict__ conic_opacity, const float* __restrict__ bg,
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out, int W,
-	int H, int C, int gx, int nchunks, int per_xcd, int total)
+	int H, int C, int gx, int nchunks, int per_xcd, int total, const uint32_t* __restrict__ gate)
 {
+	if (gate && gate[1] == 0u) return;   // fallback instance: runs only if the split path overflowed
 	const int b = blockIdx.x;
 	const int v = (b & 7) * per_xcd + (b >> 3);
 	if (v >= total) return;
@@ -306,32 +307,35 @@ static void launch_px1(hipStream_t st, const BlendFwdArgs& a, int c_begin, int n
 }
 
 template <int CW, int BATCH>
-static void launch_px4(hipStream_t st, const BlendFwdArgs& a, int nchunks)
+static void launch_px4(hipStream_t st, const BlendFwdArgs& a, int nchunks, const uint32_t* gate)
 {
 	const int total = a.gx * a.gy * nchunks;
 	const int per_xcd = (total + 7) / 8;
 	hipLaunchKernelGGL((blend_fwd_px4_kernel<CW, BATCH>), dim3(per_xcd * 8), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.bg,
-			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);
+			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate);
 }
 
 // variant: 0 = default (px4 CW=32 for the 128-channel-aligned part, px1 for the rest)
 //          1 = px1 CC=64   2 = px1 CC=128   3 = px1 CC=32   4 = px4 CW=32 BATCH=64
 //          5 = px4 CW=16
-hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int variant)
+hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int variant,
+				const uint32_t* gate, int c_skip)
 {
 	const int ntiles = a.gx * a.gy;
 	if (ntiles == 0 || a.C == 0) return hipSuccess;
 	const bool depth = a.out_depth != nullptr;
 	int c_done = 0;
-	if (!depth) {
+	if (c_skip > 0 && !gate) {
+		c_done = c_skip;   // channels [0, c_skip) were rendered by the split path
+	} else if (!depth) {
 		if (variant == 0 || variant == 4 || variant == 5) {
 			const int width = (variant == 5) ? 64 : 128;
 			const int nch = a.C / width;
 			if (nch > 0) {
-				if (variant == 0) launch_px4<32, 32>(st, a, nch);
-				else if (variant == 4) launch_px4<32, 64>(st, a, nch);
-				else launch_px4<16, 32>(st, a, nch);
+				if (variant == 0) launch_px4<32, 32>(st, a, nch, gate);
+				else if (variant == 4) launch_px4<32, 64>(st, a, nch, nullptr);
+				else launch_px4<16, 32>(st, a, nch, nullptr);
 				c_done = nch * width;
 			}
 		} else {
@@ -345,6 +349,7 @@ hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int varia
 			}
 		}
 	}
+	if (gate) return hipGetLastError();   // gated call renders only the 128-aligned part
 	const int rem = a.C - c_done;
 	if (rem > 0) {
 		const int write_aux = (c_done == 0) ? 1 : 0;

@@ -1,0 +1,351 @@
+// blend_fwd_split.hip -- the C>=128 headline path: the forward blend as TWO kernels.
+//
+//   1. blend_weights_kernel   one workgroup per 16x16 tile, lane = pixel.  Walks the tile's
+//      sorted list exactly like the reference's renderCUDA (CR/cuda_rasterizer/forward.cu:
+//      300-364: power, alpha, the three skips, T update, n_contrib, final_T) but instead of
+//      touching any feature it emits, per list entry that contributes to at least one pixel,
+//      the 256 blend weights w = alpha*T (0 for pixels that skip it) and the Gaussian id, into
+//      a compact "work list" in HBM.  This is the only place exp() and the sequential
+//      transmittance chain are evaluated: once per tile instead of once per channel chunk.
+//
+//   2. blend_accum_kernel     one wave = one tile x CW channels, 4 pixels per lane.  A pure
+//      streaming weighted sum  acc[px][ch] += w[px] * feature[id][ch]  over the work list:
+//      weights arrive as one coalesced 1-KB vector load per entry, the wave-uniform feature
+//      slice as scalar loads (s_load_dwordx16) consumed as the SGPR-pair operand of
+//      v_pk_fma_f32 -- the 143 TFLOP/s form measured by tools/ubench_fma.hip.  No LDS, no
+//      barriers, no data-dependent branches inside the loop; both streams are prefetched one
+//      entry ahead.  Each feature byte is fetched once per tile, each weight once per
+//      128 channels (from L2).
+//
+// Results are bit-identical to the single-kernel paths (same contract arithmetic, same
+// accumulation order; adding w = 0 is exact).
+//
+// Work-list storage ("arena") is carved from the binning buffer.  A tile's entries are kept
+// contiguous in chunks of 128 slots, bump-allocated with one atomicAdd per chunk (most tiles
+// need one); chunk c of tile t starts at table[(range.x >> 7) + t + c] -- that index is
+// collision free without any scan -- and nact[t] is the tile's entry count.
+// If the arena overflows, a device flag makes the accumulate kernel exit immediately and the
+// single-kernel path (launched right after it) take over, so no host round trip is needed;
+// the host grows the arena for the next frame.
+#include "sgs_kernels.h"
+
+#ifndef SGS_ACC_PREFETCH
+#define SGS_ACC_PREFETCH 1
+#endif
+
+namespace sgs {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct StagedEntryW {   // 32 B per list entry in LDS
+	float a2, b2, c2, o;
+	float x, y;
+	uint32_t id;
+	float pad;
+};
+
+constexpr int WB = 32;    // list entries per batch
+constexpr int ACH = 128;  // work-list slots per chunk
+
+} // namespace
+
+__global__ __launch_bounds__(256) void blend_weights_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+	const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
+	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+	uint32_t* __restrict__ act_id, float* __restrict__ wgt, uint32_t* __restrict__ table,
+	uint32_t* __restrict__ nact, uint32_t* __restrict__ counter, uint32_t capacity, int W,
+	int H, int gx, int per_xcd, int ntiles)
+{
+	const int b = blockIdx.x;
+	const int tile = (b & 7) * per_xcd + (b >> 3);
+	if (tile >= ntiles) return;
+	const int tx = tile % gx, ty = tile / gx;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int px = tx * SGS_TILE + (lane & 15);
+	const int py = ty * SGS_TILE + wave * 4 + (lane >> 4);
+	const bool inside = px < W && py < H;
+	const float pxf = (float)px, pyf = (float)py;
+	const uint2 range = ranges[tile];
+	const int n_total = (int)(range.y - range.x);
+	const uint32_t chunk_base = (range.x >> 7) + (uint32_t)tile;
+
+	__shared__ StagedEntryW s_e[WB];
+	__shared__ float s_wt[WB * 256];       // [entry][strip*64 + lane]
+	__shared__ unsigned s_active[WB];
+	__shared__ int s_alive[4];
+	__shared__ uint32_t s_cnt, s_mask, s_ovf;
+	__shared__ uint32_t s_chunk[64];   // first slot of each chunk (re-read from `table` beyond 64)
+
+	float T = 1.0f;
+	uint32_t last = 0;
+	bool done = !inside;
+	uint32_t total = 0;     // active entries emitted so far (tile-uniform)
+	uint32_t nchunks = 0;   // chunks reserved so far (only thread 0's copy is authoritative)
+	if (threadIdx.x == 0) s_ovf = 0u;
+
+	for (int base = 0; base < n_total; base += WB) {
+		const bool wave_alive = __ballot(!done) != 0ull;
+		if (lane == 0) s_alive[wave] = wave_alive ? 1 : 0;
+		__syncthreads();   // also: previous batch's copy-out has finished reading LDS
+		const int alive = s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3];
+		if (!alive) break;
+		const int n = (n_total - base) < WB ? (n_total - base) : WB;
+		if ((int)threadIdx.x < n) {
+			const uint32_t id = point_list[range.x + base + threadIdx.x];
+			const float2 xy = means2D[id];
+			const float4 co = conic_opacity[id];
+			StagedEntryW e;
+			e.a2 = -0.5f * co.x;
+			e.b2 = -co.y;
+			e.c2 = -0.5f * co.z;
+			e.o = co.w;
+			e.x = xy.x;
+			e.y = xy.y;
+			e.id = id;
+			e.pad = 0.f;
+			s_e[threadIdx.x] = e;
+		}
+		if (threadIdx.x < WB) s_active[threadIdx.x] = 0u;
+		__syncthreads();
+		// ---- weight phase: wave w evaluates strip w for the whole batch
+		for (int j = 0; j < n; j++) {
+			float w = 0.0f;
+			if (wave_alive) {
+				const StagedEntryW e = s_e[j];
+				const float dx = e.x - pxf, dy = e.y - pyf;
+				const float power = __builtin_fmaf(
+					e.b2 * dx, dy, __builtin_fmaf(e.c2 * dy, dy, (e.a2 * dx) * dx));
+				const float alpha = fmin_(0.99f, e.o * expf_contract(power));
+				const float test_T = T * (1.0f - alpha);
+				const bool cand = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+				const bool stop = cand && (test_T < 0.0001f);
+				const bool take = cand && !stop;
+				done = done || stop;
+				if (take) {
+					w = alpha * T;
+					T = test_T;
+					last = (uint32_t)(base + j + 1);
+				}
+				const bool any_take = __ballot(take) != 0ull;
+				if (lane == 0 && any_take) s_active[j] = 1u;   // benign same-value race
+			}
+			s_wt[j * 256 + wave * 64 + lane] = w;
+		}
+		__syncthreads();
+		// ---- compaction into the tile's contiguous chunks
+		if (wave == 0) {
+			const bool a = (lane < n) && (s_active[lane & (WB - 1)] != 0u);
+			const unsigned long long m = __ballot(a);
+			if (lane == 0) {
+				const uint32_t cnt = (uint32_t)__popcll(m);
+				// reserve chunks until [total, total+cnt) is covered
+				while (nchunks * ACH < total + cnt && s_ovf == 0u) {
+					const uint32_t start = atomicAdd(&counter[0], (uint32_t)ACH);
+					if (start + ACH > capacity) {   // arena overflow: flag it, emit nothing more
+						atomicExch(&counter[1], 1u);
+						s_ovf = 1u;
+						break;
+					}
+					table[chunk_base + nchunks] = start;
+					if (nchunks < 64) s_chunk[nchunks] = start;
+					nchunks++;
+				}
+				s_cnt = cnt;
+				s_mask = (uint32_t)m;
+			}
+		}
+		__syncthreads();
+		{
+			const uint32_t cnt = s_cnt;
+			if (s_ovf == 0u) {
+				uint32_t m = s_mask;
+				for (uint32_t r = 0; r < cnt; r++) {
+					const int e = __builtin_ctz(m);
+					m &= m - 1;
+					const uint32_t g = total + r, ci = g / ACH;
+					const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+					const uint32_t slot = cstart + (g % ACH);
+					wgt[(size_t)slot * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
+					if (threadIdx.x == 0) act_id[slot] = s_e[e].id;
+				}
+			}
+			total += cnt;
+		}
+	}
+	if (threadIdx.x == 0) nact[tile] = total;
+	if (inside) {
+		const size_t pix = (size_t)py * W + px;
+		final_T[pix] = T;
+		n_contrib[pix] = last;
+	}
+}
+
+// One wave: tile x CW channels, 4 pixels per lane.  Lane l owns work-list pixel indices
+// 4l..4l+3, i.e. strip l>>4, positions 4(l&15)..+3: four consecutive x of one image row.
+//
+// Scalar loads return out of order, so a wave can only wait for ALL of its outstanding ones
+// (lgkmcnt(0)); a measured ~1500-cycle HBM-miss latency per feature fetch therefore cannot be
+// pipelined entry by entry.  Instead the loop works on groups of G entries: issue the G feature
+// slices (G*CW SGPRs), wait once, then run G*CW*2 packed FMAs -- one exposed latency per G
+// entries, hidden by the other resident waves.
+template <int CW, int G>
+__global__ __launch_bounds__(256) void blend_accum_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float4* __restrict__ wgt, const float* __restrict__ features,
+	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
+	int total_blocks, int dbg)
+{
+	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
+	const int b = blockIdx.x;
+	const int v = (b & 7) * per_xcd + (b >> 3);
+	if (v >= total_blocks) return;
+	const int tile = v / nchunks_c;
+	const int chunk = v - tile * nchunks_c;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int c0 = (chunk * 4 + wave) * CW;
+	const int tx = tile % gx, ty = tile / gx;
+	const size_t HW = (size_t)H * W;
+	const uint32_t total = nact[tile];
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+
+	f2 acc[4][CW / 2];
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+#pragma unroll
+		for (int c = 0; c < CW / 2; c++) acc[p][c] = (f2){0.f, 0.f};
+
+	for (uint32_t done = 0; done < total; done += ACH) {
+		const uint32_t slot0 = table[chunk_base + done / ACH];
+		const uint32_t cnt = (total - done) < (uint32_t)ACH ? (total - done) : (uint32_t)ACH;
+		// ids of the whole chunk in two coalesced loads; id k is readlane(ids[k>>6], k&63).
+		// Lanes past the end repeat the chunk's first id: a valid row whose weight is 0.
+		const uint32_t idf = act_id[slot0];
+		const uint32_t ids0 = (uint32_t)lane < cnt ? act_id[slot0 + lane] : idf;
+		const uint32_t ids1 = (uint32_t)lane + 64u < cnt ? act_id[slot0 + 64 + lane] : idf;
+		const float4* __restrict__ wrow = wgt + (size_t)slot0 * 64 + lane;
+		// Weights run three entries ahead in four explicitly rotated register sets (vector
+		// loads return in order, so the compiler's counted vmcnt waits expose none of them).
+		// Loads are unconditional with a clamped row index: a conditional float4 load would be
+		// split into four branchy dword loads.
+		const uint32_t last = cnt - 1u;
+#define SGS_WLOAD(k_) wrow[(dbg & 2) ? (size_t)0 : (size_t)((k_) < last ? (k_) : last) * 64]
+#define SGS_STEP(k_, w_)                                                                            \
+	if ((k_) < cnt) {                                                                           \
+		const uint32_t kk_ = (k_);                                                          \
+		const uint32_t idv_ = (kk_ & 64u) ? ids1 : ids0;                                    \
+		const uint32_t id_ = (dbg & 1) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)idv_, (int)(kk_ & 63u)); \
+		const f2* __restrict__ f_ = reinterpret_cast<const f2*>(features + (size_t)id_ * C + c0); \
+		const f2 w0_ = {w_.x, w_.x}, w1_ = {w_.y, w_.y}, w2_ = {w_.z, w_.z}, w3_ = {w_.w, w_.w}; \
+		_Pragma("unroll") for (int c = 0; c < CW / 2; c++) {                                \
+			const f2 fv_ = f_[c];                                                       \
+			acc[0][c] = __builtin_elementwise_fma(fv_, w0_, acc[0][c]);                 \
+			acc[1][c] = __builtin_elementwise_fma(fv_, w1_, acc[1][c]);                 \
+			acc[2][c] = __builtin_elementwise_fma(fv_, w2_, acc[2][c]);                 \
+			acc[3][c] = __builtin_elementwise_fma(fv_, w3_, acc[3][c]);                 \
+		}                                                                                   \
+	}
+		float4 wA = SGS_WLOAD(0u), wB = SGS_WLOAD(1u), wC = SGS_WLOAD(2u), wD;
+		for (uint32_t k = 0; k < cnt; k += 4) {
+			wD = SGS_WLOAD(k + 3u);
+			SGS_STEP(k, wA)
+			wA = SGS_WLOAD(k + 4u);
+			SGS_STEP(k + 1u, wB)
+			wB = SGS_WLOAD(k + 5u);
+			SGS_STEP(k + 2u, wC)
+			wC = SGS_WLOAD(k + 6u);
+			SGS_STEP(k + 3u, wD)
+		}
+#undef SGS_STEP
+#undef SGS_WLOAD
+	}
+
+	// epilogue: lane's 4 pixels are x0..x0+3 of row y -> one 16-B store per channel
+	const int x0 = tx * SGS_TILE + 4 * (lane & 3);
+	const int y = ty * SGS_TILE + (lane >> 4) * 4 + ((lane & 15) >> 2);
+	if (y < H && x0 < W) {
+		const size_t pix = (size_t)y * W + x0;
+		float Tp[4];
+#pragma unroll
+		for (int p = 0; p < 4; p++) Tp[p] = (x0 + p < W) ? final_T[pix + p] : 0.f;
+		const bool full = (x0 + 3 < W) && ((W & 3) == 0);   // 16-B aligned, fully inside
+#pragma unroll
+		for (int c = 0; c < CW; c++) {
+			const float bgc = bg[c0 + c];
+			float o[4];
+#pragma unroll
+			for (int p = 0; p < 4; p++) o[p] = __builtin_fmaf(Tp[p], bgc, acc[p][c >> 1][c & 1]);
+			float* dst = out + (size_t)(c0 + c) * HW + pix;
+			if (full) {
+				*reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+			} else {
+#pragma unroll
+				for (int p = 0; p < 4; p++)
+					if (x0 + p < W) dst[p] = o[p];
+			}
+		}
+	}
+}
+
+size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
+{
+	size_t off = 0;
+	auto take = [&](size_t bytes) { off = (off + 127) & ~(size_t)127; const size_t o = off; off += bytes; return o; };
+	SplitArena a;
+	a.capacity = capacity;
+	a.counter = take(8);
+	a.nbatches = take((size_t)ntiles * 4);                       // nact[tile]
+	a.table = take(((L >> 7) + (size_t)ntiles + 1) * 4);           // chunk starts
+	a.act_id = take((size_t)capacity * 4);
+	a.wgt = take((size_t)capacity * 1024);
+	a.total = (off + 127) & ~(size_t)127;
+	if (lay) *lay = a;
+	return a.total;
+}
+
+hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
+				      const SplitArena& lay, int split_mode)
+{
+	const int ntiles = a.gx * a.gy;
+	uint32_t* counter = (uint32_t*)(arena + lay.counter);
+	uint32_t* nbatches = (uint32_t*)(arena + lay.nbatches);
+	uint32_t* table = (uint32_t*)(arena + lay.table);
+	uint32_t* act_id = (uint32_t*)(arena + lay.act_id);
+	float* wgt = (float*)(arena + lay.wgt);
+	hipError_t e = hipMemsetAsync(counter, 0, 8, st);
+	if (e != hipSuccess) return e;
+	{
+		const int per_xcd = (ntiles + 7) / 8;
+		hipLaunchKernelGGL(blend_weights_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
+				   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,
+				   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd,
+				   ntiles);
+	}
+	{
+		// split_mode: 0 = 32 channels per wave, 1 entry per scalar wait (default);
+		//             1 = (32, 2);  2 = (16, 4)
+		const int sm = split_mode & 15;
+		const int cw = (sm == 2) ? 16 : 32;
+		const int nchunks = a.C / 128 * (32 / cw);
+		const int total = ntiles * nchunks;
+		const int per_xcd = (total + 7) / 8;
+#define SGS_LAUNCH_ACC(CW_, G_)                                                                   \
+	hipLaunchKernelGGL((blend_accum_kernel<CW_, G_>), dim3(per_xcd * 8), dim3(256), 0, st,       \
+			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
+			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
+			   total, (split_mode >> 4))
+		if (sm == 2) SGS_LAUNCH_ACC(16, 4);
+		else if (sm == 1) SGS_LAUNCH_ACC(32, 2);
+		else SGS_LAUNCH_ACC(32, 1);
+#undef SGS_LAUNCH_ACC
+	}
+	return hipGetLastError();
+}
+
+} // namespace sgs

@@ -83,10 +83,15 @@ GeomLayout geom_layout(int P)
 
 struct BinLayout {
 	sgs_binning_layout pub;
-	size_t sort_temp, sort_temp_bytes, total;
+	size_t sort_temp, sort_temp_bytes, arena, total;
+	sgs::SplitArena arena_lay;
 };
 
-BinLayout bin_layout(size_t L, int sort_bits)
+// Work-list capacity of the split blend (slots of 1 KB): adaptive, grown after an overflow.
+std::atomic<uint32_t> g_arena_hint{0};
+uint32_t* g_usage_host = nullptr;   // pinned: {slots used, overflow flag} of the last split forward
+
+BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int ntiles = 0)
 {
 	BinLayout b;
 	Carver c;
@@ -96,6 +101,11 @@ BinLayout bin_layout(size_t L, int sort_bits)
 	b.pub.point_list = c.take(L * 4);
 	b.sort_temp_bytes = L ? sgs::sort_temp_bytes(L, sort_bits) : 0;
 	b.sort_temp = c.take(b.sort_temp_bytes);
+	b.arena = 0;
+	if (arena_capacity) {
+		const size_t bytes = sgs::split_arena_bytes(arena_capacity, L, ntiles, &b.arena_lay);
+		b.arena = c.take(bytes);
+	}
 	b.total = align_up(c.off, 128) + 128;
 	b.pub.total = b.total;
 	return b;
@@ -328,7 +338,31 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	tm.mark();
 
 	const int sort_bits = 32 + (int)higher_msb((uint32_t)ntiles);
-	const BinLayout bl = bin_layout(L, sort_bits);
+	// split blend (weights pre-pass + streaming accumulate) for the 128-channel-aligned part
+	const int variant = g_blend_variant.load();
+	const bool use_split = (variant == 0 || variant == 7 || variant == 8 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
+	uint32_t arena_cap = 0;
+	uint64_t arena_max = 0;
+	if (use_split) {
+		if (!g_usage_host) {
+			if (hipHostMalloc((void**)&g_usage_host, 8, hipHostMallocDefault) != hipSuccess)
+				g_usage_host = nullptr;
+			else g_usage_host[0] = g_usage_host[1] = 0;
+		}
+		uint32_t hint = g_arena_hint.load();
+		if (g_usage_host) {   // feedback from the previous split forward (complete: we just synced)
+			const uint32_t used = g_usage_host[0], ovf = g_usage_host[1];
+			if (ovf) hint = used + used / 2;            // `used` counts every request, also the refused ones
+			else if (used) hint = hint > used + used / 4 ? hint : used + used / 4;
+		}
+		if (hint < (uint32_t)ntiles * 192u) hint = (uint32_t)ntiles * 192u;   // chunks of 128 slots
+		hint = (hint + 0xffffu) & ~0xffffu;   // 64k-slot granularity keeps the buffer size stable
+		g_arena_hint.store(hint);
+		// a tile can never need more than its list length rounded up to whole chunks
+		arena_max = (uint64_t)L + 128ull * (uint64_t)ntiles;
+		arena_cap = (uint64_t)hint < arena_max ? hint : (uint32_t)arena_max;
+	}
+	const BinLayout bl = bin_layout(L, sort_bits, arena_cap, ntiles);
 	char* bchunk = (char*)binning_buffer(binning_user, bl.total);
 	if (!bchunk) return fail(SGS_EALLOC, "binning buffer allocation failed");
 	bchunk = align_ptr(bchunk);
@@ -370,7 +404,21 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.n_contrib = (uint32_t*)(ichunk + il.n_contrib);
 	a.out = out_color;
 	a.out_depth = out_depth;
-	e = sgs::launch_blend_forward(st, a, g_blend_variant.load());
+	if (use_split) {
+		char* arena = bchunk + bl.arena;
+		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, variant >= 16 ? variant : (variant == 7 ? 1 : (variant == 8 ? 2 : 0)));
+		if (e != hipSuccess) return fail_hip(e, "blend forward (split)");
+		const uint32_t* counter = (const uint32_t*)(arena + bl.arena_lay.counter);
+		const int c_split = (num_channels / 128) * 128;
+		if ((uint64_t)arena_cap < arena_max)   // overflow possible: gated single-kernel fallback
+			e = sgs::launch_blend_forward(st, a, 0, counter, 0);
+		if (e == hipSuccess && c_split < num_channels)
+			e = sgs::launch_blend_forward(st, a, 0, nullptr, c_split);
+		if (e == hipSuccess && g_usage_host)
+			e = hipMemcpyAsync(g_usage_host, counter, 8, hipMemcpyDeviceToHost, st);
+	} else {
+		e = sgs::launch_blend_forward(st, a, variant == 6 ? 0 : variant);   // 6 = px4 without the split
+	}
 	if (e != hipSuccess) return fail_hip(e, "blend forward");
 	SGS_CHECK_STAGE("blend forward");
 	tm.mark();

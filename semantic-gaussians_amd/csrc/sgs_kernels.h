@@ -47,7 +47,19 @@ struct BlendFwdArgs {
 	float* out;                  // (C,H,W)
 	float* out_depth;            // (H*W) or null
 };
-hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int variant);
+// gate: optional device word; when non-null the 128-channel-aligned kernels exit unless
+// *gate != 0 (used as the arena-overflow fallback of the split path).
+hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int variant,
+				const uint32_t* gate = nullptr, int c_skip = 0);
+
+// ---- blend_fwd_split.hip (weights pre-pass + streaming accumulate)
+struct SplitArena {   // byte offsets inside the arena chunk
+	size_t counter, nbatches, table, act_id, wgt, total;
+	uint32_t capacity;   // work-list slots (1 KB of weights + 4 B id each)
+};
+size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay);
+hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
+				      const SplitArena& lay, int split_mode);
 
 // ---- blend_bwd.hip
 struct BlendBwdArgs {
