@@ -95,7 +95,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--points", type=int, default=None, help="override P (debug)")
     ap.add_argument("--channels", type=int, default=None, help="override C (debug)")
@@ -148,11 +148,17 @@ def main():
     raster.get_stage_ms()            # drop anything parked by earlier calls
     raster.set_stage_timing(2)       # deferred hipEvent timing of the stages, no extra syncs
     barrier()
+    step_marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+        step_marks.append(time.perf_counter())
     barrier()
     t = time.perf_counter() - t0
+    if rank == 0:   # host-side enqueue cadence (diagnostic only; the metric uses t / steps)
+        prev = t0
+        log("per-step host ms: " + " ".join(f"{(m - prev) * 1e3:.2f}" for prev, m in zip([t0] + step_marks[:-1], step_marks)))
+        log(f"torch reserved {torch.cuda.memory_reserved(dev) / 1e9:.2f} GB")
     raster.set_stage_timing(0)
     stage_ms = raster.get_stage_ms()
     if world > 1:

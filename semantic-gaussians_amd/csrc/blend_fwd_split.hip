@@ -293,6 +293,159 @@ __global__ __launch_bounds__(256) void blend_accum_kernel(
 	}
 }
 
+// -------------------------------------------------------------------------------------
+// LDS-fed accumulate: one workgroup = tile x 128 channels (4 waves x 32 channels, 4 pixels
+// per lane).  The work list is consumed in batches of AB entries; while batch q is being
+// accumulated, the feature slices (AB x 512 B) and weight rows (AB x 1 KB) of batch q+1 are
+// in flight as LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, one barrier per batch,
+// a whole batch of compute to land) -- this hides the ~1500-cycle HBM-miss latency of the
+// feature gather that per-wave scalar loads cannot pipeline.  Features are then broadcast
+// from LDS (ds_read_b128, 16 FMAs per read with 4 pixels per lane = 48 % LDS utilisation) and
+// consumed by plain v_fmac_f32, which sustains a higher rate than v_pk_fma_f32 at the 3
+// waves/SIMD that 128 accumulators allow (tools/ubench_fma.hip).
+constexpr int AB = 16;   // work-list entries per batch (divides ACH)
+
+__global__ __launch_bounds__(256) void blend_accum_lds_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float4* __restrict__ wgt, const float* __restrict__ features,
+	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
+	int total_blocks)
+{
+	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
+	const int b = blockIdx.x;
+	const int v = (b & 7) * per_xcd + (b >> 3);
+	if (v >= total_blocks) return;
+	const int tile = v / nchunks_c;
+	const int chunk = v - tile * nchunks_c;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int cbase = chunk * 128;          // the workgroup's 128 channels
+	const int c0 = cbase + wave * 32;       // this wave's 32 channels
+	const int tx = tile % gx, ty = tile / gx;
+	const size_t HW = (size_t)H * W;
+	const uint32_t total = nact[tile];
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const uint32_t Q = (total + AB - 1) / AB;   // batches; AB divides ACH so none straddles a chunk
+
+	// two buffers as four distinct LDS objects: the waitcnt pass can then prove that the
+	// ds_reads of one buffer do not alias the LDS-DMA in flight to the other
+	__shared__ float4 s_featA[AB * 32], s_featB[AB * 32];   // [entry][128 floats]
+	__shared__ float4 s_wA[AB * 64], s_wB[AB * 64];         // [entry][256 floats]
+
+	float acc[4][32];
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+#pragma unroll
+		for (int c = 0; c < 32; c++) acc[p][c] = 0.f;
+
+	// first slot and entry count of batch q
+	auto batch_slot = [&](uint32_t q) -> uint32_t {
+		const uint32_t first = q * AB;
+		return table[chunk_base + (first >> 7)] + (first & 127u);
+	};
+	// ids of the two entries whose feature rows this thread fetches in batch q
+	const int sub = threadIdx.x >> 5;   // 0..7
+	auto load_ids = [&](uint32_t q, uint32_t& i0, uint32_t& i1) {
+		const uint32_t slot = batch_slot(q);
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		const uint32_t e0 = (uint32_t)sub < n ? (uint32_t)sub : n - 1u;
+		const uint32_t e1 = (uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u;
+		i0 = act_id[slot + e0];
+		i1 = act_id[slot + e1];
+	};
+	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
+		const uint32_t slot = batch_slot(q);
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		// features: instruction j covers entries 8j..8j+7, this wave lands 8j+2w, 8j+2w+1
+		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
+		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
+						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32],
+						 16, 0, 0);
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
+						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32],
+						 16, 0, 0);
+		// weights: instruction j lands entry 4j + w (one 1-KB row per wave)
+#pragma unroll
+		for (int j = 0; j < AB / 4; j++) {
+			const uint32_t e = (uint32_t)(4 * j + wave);
+			const uint32_t ec = e < n ? e : n - 1u;
+			const float4* src = wgt + (size_t)(slot + ec) * 64 + lane;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+							 (__attribute__((address_space(3))) void*)&s_w[e * 64],
+							 16, 0, 0);
+		}
+	};
+	auto compute = [&](uint32_t q, const float4* s_feat, const float4* s_w) {
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		for (uint32_t e = 0; e < n; e++) {
+			const float4 w4 = s_w[e * 64 + lane];
+			const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+			for (int c4 = 0; c4 < 8; c4++) {
+				const float4 f4 = s_feat[e * 32 + wave * 8 + c4];
+				const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+#pragma unroll
+					for (int p = 0; p < 4; p++)
+						acc[p][4 * c4 + i] = __builtin_fmaf(fv[i], wv[p], acc[p][4 * c4 + i]);
+			}
+		}
+	};
+
+	if (Q > 0) {
+		uint32_t i0, i1, n0 = 0, n1 = 0;
+		load_ids(0, i0, i1);
+		issue(0, s_featA, s_wA, i0, i1);
+		if (Q > 1) load_ids(1, n0, n1);
+		for (uint32_t q = 0; q < Q; q += 2) {
+			__syncthreads();   // batch q has landed in A (vmcnt drained); B is free
+			if (q + 1 < Q) {
+				issue(q + 1, s_featB, s_wB, n0, n1);
+				if (q + 2 < Q) load_ids(q + 2, n0, n1);
+			}
+			compute(q, s_featA, s_wA);
+			if (q + 1 < Q) {
+				__syncthreads();   // batch q+1 has landed in B; A is free
+				if (q + 2 < Q) {
+					issue(q + 2, s_featA, s_wA, n0, n1);
+					if (q + 3 < Q) load_ids(q + 3, n0, n1);
+				}
+				compute(q + 1, s_featB, s_wB);
+			}
+		}
+	}
+
+	// epilogue: lane's 4 pixels are x0..x0+3 of row y -> one 16-B store per channel
+	const int x0 = tx * SGS_TILE + 4 * (lane & 3);
+	const int y = ty * SGS_TILE + (lane >> 4) * 4 + ((lane & 15) >> 2);
+	if (y < H && x0 < W) {
+		const size_t pix = (size_t)y * W + x0;
+		float Tp[4];
+#pragma unroll
+		for (int p = 0; p < 4; p++) Tp[p] = (x0 + p < W) ? final_T[pix + p] : 0.f;
+		const bool full = (x0 + 3 < W) && ((W & 3) == 0);
+#pragma unroll
+		for (int c = 0; c < 32; c++) {
+			const float bgc = bg[c0 + c];
+			float o[4];
+#pragma unroll
+			for (int p = 0; p < 4; p++) o[p] = __builtin_fmaf(Tp[p], bgc, acc[p][c]);
+			float* dst = out + (size_t)(c0 + c) * HW + pix;
+			if (full) {
+				*reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+			} else {
+#pragma unroll
+				for (int p = 0; p < 4; p++)
+					if (x0 + p < W) dst[p] = o[p];
+			}
+		}
+	}
+}
+
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
 {
 	size_t off = 0;
@@ -340,7 +493,11 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
 			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
 			   total, (split_mode >> 4))
-		if (sm == 2) SGS_LAUNCH_ACC(16, 4);
+		if (sm == 3)
+			hipLaunchKernelGGL(blend_accum_lds_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
+					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
+					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);
+		else if (sm == 2) SGS_LAUNCH_ACC(16, 4);
 		else if (sm == 1) SGS_LAUNCH_ACC(32, 2);
 		else SGS_LAUNCH_ACC(32, 1);
 #undef SGS_LAUNCH_ACC
