@@ -207,6 +207,12 @@ int sgs_set_blend_variant(int variant);
  * forwards since the last query (no extra synchronisation inside the timed region).
  * sgs_get_stage_ms returns the number of forwards averaged (0 in mode 1). */
 int sgs_set_stage_timing(int mode);
+/* Binning algorithm: 0 (default) = Gaussians presorted by depth, instances emitted in that
+ * order, stable instance sort on the tile bits only; 1 = the reference's order of operations
+ * (emit in index order, sort on all 32+msb(tiles) key bits).  Sorted keys, lists and ranges are
+ * bit-identical in both modes; point_offsets and the UNSORTED key/value arrays follow the
+ * reference's emission order only in mode 1.  Returns the previous mode. */
+int sgs_set_binning_mode(int mode);
 int sgs_get_stage_ms(float *ms6);
 
 #ifdef __cplusplus

@@ -8,7 +8,18 @@
 //   ranges[tile] = [first, one-past-last) index               (rasterizer_impl.cu:116-138)
 // (all citations: CR/cuda_rasterizer/ of the reference).
 //
-// MI355X notes.  The reference emits keys with one thread per Gaussian looping over its
+// MI355X notes.
+//
+// (1) Depth-presorted emission (default, binning mode 0).  The reference radix-sorts all
+// L = sum(tiles touched) instances on 32+13 key bits: six 8-bit passes that each move 24 B per
+// instance (2.4 GB at L = 16.5M -- as expensive on MI355X as the whole C=512 blend).  The
+// required result is a total order: ascending (tile, depth bits, Gaussian index).  Here the
+// P Gaussians (not the L instances) are first sorted by depth bits (a stable sort keeps
+// ascending index inside equal depths); instances are then EMITTED in that order, so the
+// big sort only has to be stable on the 13 tile bits: two passes instead of six, and the
+// outcome is bit-identical.
+//
+// (2) The reference emits keys with one thread per Gaussian looping over its
 // rect: lanes of a wave then write 64 unrelated 12-byte records per iteration and the
 // wave runs as long as its largest Gaussian.  Here emission is instance-parallel: one lane
 // per OUTPUT slot, which finds its Gaussian by a binary search over the (L2-resident)
@@ -36,11 +47,13 @@ hipError_t launch_inclusive_scan(hipStream_t st, void* temp, size_t temp_bytes,
 				       rocprim::plus<uint32_t>(), st);
 }
 
-// One lane per emitted (tile, Gaussian) instance.
+// One lane per emitted (tile, Gaussian) instance.  `perm` (optional) maps emission rank ->
+// Gaussian index: null = the reference's emission order (ascending index), else the
+// depth-sorted order of mode 0 (offsets are then the scan over the permuted tile counts).
 __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(
 	int P, uint32_t L, const float2* __restrict__ means2D, const float* __restrict__ depths,
 	const uint32_t* __restrict__ offsets, const int* __restrict__ radii, int gx, int gy,
-	uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+	uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, const uint32_t* __restrict__ perm)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= L) return;
@@ -52,8 +65,8 @@ __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(
 		if (offsets[mid] > i) hi = mid;
 		else lo = mid + 1;
 	}
-	const int g = lo;
-	const uint32_t base = (g == 0) ? 0u : offsets[g - 1];
+	const uint32_t base = (lo == 0) ? 0u : offsets[lo - 1];
+	const int g = perm ? (int)perm[lo] : lo;
 	const uint32_t k = i - base;
 	const float2 p = means2D[g];
 	uint32_t x0, y0, x1, y1;
@@ -69,28 +82,65 @@ __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(
 
 void launch_duplicate_with_keys(hipStream_t st, int P, const float2* means2D, const float* depths,
 				const uint32_t* offsets, const int* radii, int gx, int gy,
-				uint64_t* keys, uint32_t* vals, uint32_t L)
+				uint64_t* keys, uint32_t* vals, uint32_t L, const uint32_t* perm)
 {
 	if (L == 0) return;
 	hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((L + 255u) / 256u), dim3(256), 0, st, P,
-			   L, means2D, depths, offsets, radii, gx, gy, keys, vals);
+			   L, means2D, depths, offsets, radii, gx, gy, keys, vals, perm);
 }
 
-size_t sort_temp_bytes(size_t L, int end_bit)
+// ---- depth presort of the Gaussians (mode 0)
+size_t gaussian_sort_temp_bytes(int P)
+{
+	size_t bytes = 0;
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+					rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr,
+					(size_t)P, 0u, 32u, (hipStream_t)0);
+	return bytes;
+}
+
+// depth_bits: the fp32 view-space depths reinterpreted (positive floats order like integers;
+// culled Gaussians hold garbage but emit nothing).  perm[r] = index of the r-th Gaussian.
+hipError_t launch_gaussian_depth_sort(hipStream_t st, void* temp, size_t temp_bytes,
+				      const uint32_t* depth_bits, uint32_t* keys_out, uint32_t* perm,
+				      int P)
+{
+	return rocprim::radix_sort_pairs(temp, temp_bytes, depth_bits, keys_out,
+					 rocprim::counting_iterator<uint32_t>(0), perm, (size_t)P, 0u, 32u,
+					 st);
+}
+
+__global__ __launch_bounds__(256) void gather_counts_kernel(int P, const uint32_t* __restrict__ perm,
+							     const uint32_t* __restrict__ tiles_touched,
+							     uint32_t* __restrict__ counts_sorted)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < P) counts_sorted[i] = tiles_touched[perm[i]];
+}
+
+void launch_gather_counts(hipStream_t st, int P, const uint32_t* perm, const uint32_t* tiles_touched,
+			  uint32_t* counts_sorted)
+{
+	hipLaunchKernelGGL(gather_counts_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, perm,
+			   tiles_touched, counts_sorted);
+}
+
+size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit)
 {
 	size_t bytes = 0;
 	(void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr,
-					(uint32_t*)nullptr, (uint32_t*)nullptr, L, 0u,
+					(uint32_t*)nullptr, (uint32_t*)nullptr, L, (unsigned)begin_bit,
 					(unsigned)end_bit, (hipStream_t)0);
 	return bytes;
 }
 
+// stable sort on key bits [begin_bit, end_bit)
 hipError_t launch_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint64_t* keys_in,
 			     uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,
-			     int end_bit)
+			     int begin_bit, int end_bit)
 {
-	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, L, 0u,
-					 (unsigned)end_bit, st);
+	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, L,
+					 (unsigned)begin_bit, (unsigned)end_bit, st);
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t L,

@@ -25,6 +25,7 @@ namespace {
 thread_local std::string g_err;
 std::atomic<int> g_blend_variant{0};
 std::atomic<int> g_stage_timing{0};
+std::atomic<int> g_binning_mode{0};   // 0 = depth-presorted emission (default), 1 = reference order
 float g_stage_ms[6] = {0, 0, 0, 0, 0, 0};
 
 int fail(int code, const std::string& msg)
@@ -57,6 +58,8 @@ struct Carver {
 struct GeomLayout {
 	sgs_geometry_layout pub;
 	size_t scan_temp, scan_temp_bytes, trap_flag, total;
+	// depth presort of the Gaussians (binning mode 0)
+	size_t perm, gkeys, counts_sorted, gsort_temp, gsort_temp_bytes;
 };
 
 GeomLayout geom_layout(int P)
@@ -76,6 +79,11 @@ GeomLayout geom_layout(int P)
 	g.scan_temp_bytes = sgs::scan_temp_bytes(P);
 	g.scan_temp = c.take(g.scan_temp_bytes);
 	g.trap_flag = c.take(4);
+	g.perm = c.take(p * 4);
+	g.gkeys = c.take(p * 4);
+	g.counts_sorted = c.take(p * 4);
+	g.gsort_temp_bytes = sgs::gaussian_sort_temp_bytes(P);
+	g.gsort_temp = c.take(g.gsort_temp_bytes);
 	g.total = align_up(c.off, 128) + 128;
 	g.pub.total = g.total;
 	return g;
@@ -99,7 +107,7 @@ BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int n
 	b.pub.vals_unsorted = c.take(L * 4);
 	b.pub.keys_sorted = c.take(L * 8);
 	b.pub.point_list = c.take(L * 4);
-	b.sort_temp_bytes = L ? sgs::sort_temp_bytes(L, sort_bits) : 0;
+	b.sort_temp_bytes = L ? sgs::sort_temp_bytes(L, 0, sort_bits) : 0;   // upper bound for both modes
 	b.sort_temp = c.take(b.sort_temp_bytes);
 	b.arena = 0;
 	if (arena_capacity) {
@@ -209,6 +217,7 @@ const char* sgs_last_error(void) { return g_err.c_str(); }
 
 int sgs_set_blend_variant(int variant) { return g_blend_variant.exchange(variant); }
 int sgs_set_stage_timing(int enable) { return g_stage_timing.exchange(enable); }
+int sgs_set_binning_mode(int mode) { return g_binning_mode.exchange(mode); }
 int sgs_get_stage_ms(float* ms6)
 {
 	std::vector<EventSet> parked;
@@ -320,8 +329,23 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 				   conic_opacity, tiles_touched, trap_flag);
 	SGS_CHECK_STAGE("preprocess");
 	tm.mark();
-	e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, tiles_touched,
-				       point_offsets, P);
+	// binning mode 0: sort the P Gaussians by depth bits and emit instances in that order, so
+	// that the big instance sort only has to be stable on the tile bits (binning.hip)
+	const bool presort = g_binning_mode.load() == 0;
+	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
+	if (presort) {
+		uint32_t* counts_sorted = (uint32_t*)(gchunk + gl.counts_sorted);
+		e = sgs::launch_gaussian_depth_sort(st, gchunk + gl.gsort_temp, gl.gsort_temp_bytes,
+						    (const uint32_t*)depths, (uint32_t*)(gchunk + gl.gkeys),
+						    perm, P);
+		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
+		sgs::launch_gather_counts(st, P, perm, tiles_touched, counts_sorted);
+		e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, counts_sorted,
+					       point_offsets, P);
+	} else {
+		e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, tiles_touched,
+					       point_offsets, P);
+	}
 	if (e != hipSuccess) return fail_hip(e, "inclusive scan");
 	SGS_CHECK_STAGE("inclusive scan");
 
@@ -372,12 +396,12 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	uint32_t* point_list = (uint32_t*)(bchunk + bl.pub.point_list);
 
 	sgs::launch_duplicate_with_keys(st, P, means2D, depths, point_offsets, radii, gx, gy, keys_u,
-					vals_u, L);
+					vals_u, L, perm);
 	SGS_CHECK_STAGE("duplicateWithKeys");
 	tm.mark();
 	if (L > 0) {
 		e = sgs::launch_sort_pairs(st, bchunk + bl.sort_temp, bl.sort_temp_bytes, keys_u, keys_s,
-					   vals_u, point_list, L, sort_bits);
+					   vals_u, point_list, L, presort ? 32 : 0, sort_bits);
 		if (e != hipSuccess) return fail_hip(e, "radix sort");
 	}
 	SGS_CHECK_STAGE("radix sort");

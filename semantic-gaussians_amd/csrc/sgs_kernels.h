@@ -24,11 +24,17 @@ hipError_t launch_inclusive_scan(hipStream_t st, void* temp, size_t temp_bytes,
 				 const uint32_t* in, uint32_t* out, int P);
 void launch_duplicate_with_keys(hipStream_t st, int P, const float2* means2D, const float* depths,
 				const uint32_t* offsets, const int* radii, int gx, int gy,
-				uint64_t* keys, uint32_t* vals, uint32_t L);
-size_t sort_temp_bytes(size_t L, int end_bit);
+				uint64_t* keys, uint32_t* vals, uint32_t L, const uint32_t* perm);
+size_t gaussian_sort_temp_bytes(int P);
+hipError_t launch_gaussian_depth_sort(hipStream_t st, void* temp, size_t temp_bytes,
+				      const uint32_t* depth_bits, uint32_t* keys_out, uint32_t* perm,
+				      int P);
+void launch_gather_counts(hipStream_t st, int P, const uint32_t* perm, const uint32_t* tiles_touched,
+			  uint32_t* counts_sorted);
+size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit);
 hipError_t launch_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint64_t* keys_in,
 			     uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,
-			     int end_bit);
+			     int begin_bit, int end_bit);
 void launch_tile_ranges(hipStream_t st, size_t L, const uint64_t* keys, uint2* ranges, int ntiles);
 
 // ---- blend_fwd.hip

@@ -273,3 +273,9 @@ def get_stage_ms():
     arr = (C.c_float * 6)()
     _lib.load().sgs_get_stage_ms(arr)
     return [float(a) for a in arr]
+
+
+def set_binning_mode(mode):
+    """0 = depth-presorted emission (default); 1 = reference order of operations (also makes
+    point_offsets and the unsorted key/value arrays follow the reference's emission order)."""
+    return int(_lib.load().sgs_set_binning_mode(int(mode)))

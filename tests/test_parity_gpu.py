@@ -36,11 +36,15 @@ def _hip_forward(scene, cam, C=None, want_depth=False, colors=None, variant=0, d
     return out
 
 
-def _check_forward(orc, scene, cam, want_depth=False, variant=0, **kw):
+def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0, **kw):
     from sgs_hip import raster
     fw = oracle_forward(orc, scene, cam, want_depth=want_depth, **kw)
-    n, color, radii, geom, binn, img, depth = _hip_forward(scene, cam, want_depth=want_depth,
-                                                           variant=variant, **kw)
+    raster.set_binning_mode(binning_mode)
+    try:
+        n, color, radii, geom, binn, img, depth = _hip_forward(scene, cam, want_depth=want_depth,
+                                                               variant=variant, **kw)
+    finally:
+        raster.set_binning_mode(0)
     P = scene.means3D.shape[0]
     W, H = cam.image_width, cam.image_height
     assert n == fw["num_rendered"]
@@ -48,13 +52,19 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, **kw):
     g = {k: v.cpu().numpy() for k, v in raster.geometry_views(geom, P).items()}
     vis = fw["radii"] > 0
     assert np.array_equal(g["tiles_touched"].view(np.uint32), fw["tiles_touched"])
-    assert np.array_equal(g["point_offsets"].view(np.uint32), fw["point_offsets"])
+    if binning_mode == 1:   # mode 0 scans the tile counts in depth-sorted Gaussian order
+        assert np.array_equal(g["point_offsets"].view(np.uint32), fw["point_offsets"])
     assert np.array_equal(g["depths"][vis].view(np.uint32), fw["depths"][vis].view(np.uint32))
     assert np.array_equal(g["means2D"][vis].view(np.uint32), fw["means2D"][vis].view(np.uint32))
     assert np.array_equal(g["conic_opacity"][vis].view(np.uint32), fw["conic_opacity"][vis].view(np.uint32))
     b = {k: v.cpu().numpy() for k, v in raster.binning_views(binn, n).items()}
-    assert np.array_equal(b["keys_unsorted"].view(np.uint64), fw["keys_unsorted"])
-    assert np.array_equal(b["vals_unsorted"].view(np.uint32), fw["vals_unsorted"])
+    if binning_mode == 1:   # only the reference order of operations emits in index order
+        assert np.array_equal(b["keys_unsorted"].view(np.uint64), fw["keys_unsorted"])
+        assert np.array_equal(b["vals_unsorted"].view(np.uint32), fw["vals_unsorted"])
+    else:                   # same multiset of (key, value) pairs, emitted in depth order
+        ku, vu = b["keys_unsorted"].view(np.uint64), b["vals_unsorted"].view(np.uint32)
+        o1, o2 = np.lexsort((vu, ku)), np.lexsort((fw["vals_unsorted"], fw["keys_unsorted"]))
+        assert np.array_equal(ku[o1], fw["keys_unsorted"][o2]) and np.array_equal(vu[o1], fw["vals_unsorted"][o2])
     assert np.array_equal(b["keys_sorted"].view(np.uint64), fw["keys_sorted"])
     assert np.array_equal(b["point_list"].view(np.uint32), fw["point_list"])
     im = {k: v.cpu().numpy() for k, v in raster.image_views(img, W, H).items()}
@@ -90,6 +100,20 @@ def test_forward_c128_all_variants(orc, variant):
 def test_forward_channel_counts(orc, C):
     scene, cam = small_scene(P=1200, C=C, W=100, H=70, fx=90.0, seed=C)
     _check_forward(orc, scene, cam)
+
+
+@pytest.mark.parametrize("binning_mode", [0, 1])
+def test_binning_modes_bit_exact(orc, binning_mode):
+    """Both binning algorithms give the oracle's sorted keys / lists / ranges; the reference-order
+    mode additionally reproduces point_offsets and the emission-order (unsorted) arrays."""
+    scene, cam = small_scene(P=6000, C=4, W=330, H=200, fx=300.0, seed=12)
+    # exact duplicates: equal (tile, depth) keys must keep ascending Gaussian index
+    m = scene.means3D.clone()
+    m[1000:1400] = m[100:500]
+    scene = scene._replace(means3D=m)
+    fw = _check_forward(orc, scene, cam, binning_mode=binning_mode)
+    ks = fw["keys_sorted"]
+    assert (ks[1:] == ks[:-1]).sum() > 100      # ties really occur
 
 
 def test_forward_rgbd_depth(orc):
