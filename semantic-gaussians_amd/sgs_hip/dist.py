@@ -1,0 +1,97 @@
+"""Multi-GPU use of the rasteriser: one process per GPU, `torch.distributed` (backend "nccl" =
+RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+The hot path shards without any data-path collective: frames are independent
+given a read-only scene, so the scene is replicated and the VIEW list is split round-robin.
+For scenes whose feature table does not fit one GPU the exact alternative is CHANNEL sharding:
+geometry is replicated, rank r holds feature columns [r*C/w, (r+1)*C/w), every rank runs the
+identical preprocess/sort and blends its own channel slice -- bit-identical to the single-GPU
+render with zero reduction; one all_gather only if a single rank needs the full map.
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_views(n_views, rank=None, world_size=None):
+    """Round-robin view indices of this rank."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return list(range(rank, n_views, world_size))
+
+
+def render_views_sharded(render_fn, views, gather_to=0):
+    """Each rank renders views[rank::world]; results are gathered (as CPU tensors) on
+    `gather_to` in view order (None elsewhere).  No collective touches the render itself."""
+    rank, w = world()
+    mine = {i: render_fn(views[i]) for i in shard_views(len(views), rank, w)}
+    if w == 1:
+        return [mine[i] for i in range(len(views))]
+    payload = {i: t.detach().cpu() for i, t in mine.items()}
+    gathered = [None] * w if rank == gather_to else None
+    dist.gather_object(payload, gathered, dst=gather_to)
+    if rank != gather_to:
+        return None
+    merged = {}
+    for part in gathered:
+        merged.update(part)
+    return [merged[i] for i in range(len(views))]
+
+
+def channel_slice(C, rank=None, world_size=None):
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    if C % world_size:
+        raise ValueError(f"C={C} must be divisible by the world size {world_size}")
+    per = C // world_size
+    return rank * per, (rank + 1) * per
+
+
+def render_channel_sharded(render_fn, features, bg, all_gather=True):
+    """Exact channel sharding.  `render_fn(features_slice, bg_slice) -> (c,H,W)` renders this
+    rank's columns; with all_gather=True every rank returns the full (C,H,W) map."""
+    rank, w = world()
+    lo, hi = channel_slice(features.shape[1], rank, w)
+    part = render_fn(features[:, lo:hi].contiguous(), bg[lo:hi].contiguous())
+    if w == 1 or not all_gather:
+        return part
+    parts = [torch.empty_like(part) for _ in range(w)]
+    dist.all_gather(parts, part.contiguous())
+    return torch.cat(parts, dim=0)
+
+
+def timed_steps(step_fn, steps, warmup, sync_fn=None):
+    """The bench contract: `warmup` untimed steps, then exactly `steps` steps bracketed by a
+    barrier (+ device sync) on both sides; returns the MAX over ranks of the elapsed seconds."""
+    rank, w = world()
+
+    def barrier():
+        if w > 1:
+            dist.barrier()
+        if sync_fn is not None:
+            sync_fn()
+
+    for _ in range(warmup):
+        step_fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    barrier()
+    t = time.perf_counter() - t0
+    if w > 1:
+        tt = torch.tensor([t], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            tt = tt.cuda()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    return t

@@ -1,0 +1,76 @@
+"""Committed golden vector (tests/golden/small_scene.npz, made by gen_oracle_goldens.py):
+the oracle must keep reproducing it (CPU), and the HIP path must match it (GPU)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import small_scene, oracle_forward
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_scene.npz"))
+P, C, W, H = [int(v) for v in G["params"]]
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _scene():
+    return small_scene(P=P, C=C, W=W, H=H, fx=float(G["fx"]), seed=int(G["seed"]))
+
+
+def test_oracle_reproduces_golden(orc):
+    scene, cam = _scene()
+    fw = oracle_forward(orc, scene, cam, bg=G["bg"])
+    assert fw["num_rendered"] == int(G["num_rendered"])
+    assert np.array_equal(fw["radii"], G["radii"]) and np.array_equal(fw["ranges"], G["ranges"])
+    assert _digest(fw["keys_sorted"]) == str(G["keys_sorted_sha256"])
+    assert _digest(fw["point_list"]) == str(G["point_list_sha256"])
+    assert np.array_equal(fw["out"], G["out"]) and np.array_equal(fw["n_contrib"], G["n_contrib"])
+    assert np.array_equal(orc.dist2(scene.means3D.numpy()), G["dist2"])
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden():
+    from sgs_hip import raster
+    scene, cam = _scene()
+    dev = "cuda:0"
+    s, c = scene.to(dev), cam.to(dev)
+    e = torch.Tensor([])
+    bg = torch.from_numpy(G["bg"]).to(dev)
+    n, color, radii, geom, binn, img, _ = raster.rasterize_forward(
+        bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e, c.world_view_transform,
+        c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, e, 0, c.camera_center, False, False, C, False)
+    assert n == int(G["num_rendered"])
+    assert np.array_equal(radii.cpu().numpy(), G["radii"])
+    b = raster.binning_views(binn, n)
+    assert _digest(b["keys_sorted"].cpu().numpy().view(np.uint64)) == str(G["keys_sorted_sha256"])
+    assert _digest(b["point_list"].cpu().numpy().view(np.uint32)) == str(G["point_list_sha256"])
+    iv = raster.image_views(img, W, H)
+    assert np.array_equal(iv["ranges"].cpu().numpy().view(np.uint32), G["ranges"])
+    assert np.array_equal(iv["n_contrib"].cpu().numpy().view(np.uint32), G["n_contrib"])
+    out = color.cpu().numpy()
+    assert np.abs(out - G["out"]).max() <= 1e-4 * np.abs(G["out"]).max()
+    assert np.array_equal(out, G["out"])
+    # RGB-D variant
+    _, rgb, _, _, _, _, depth = raster.rasterize_forward(
+        bg[:3], s.means3D, s.features[:, :3], s.opacities, s.scales, s.rotations, 1.0, e,
+        c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, e, 0,
+        c.camera_center, False, False, 3, True)
+    assert np.array_equal(rgb.cpu().numpy(), G["rgb_out"]) and np.array_equal(depth.cpu().numpy(), G["depth"])
+    # backward (fp32 atomics: tolerance)
+    grads = raster.rasterize_backward(bg, s.means3D, radii, s.features, s.scales, s.rotations, 1.0, e,
+                                      c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy,
+                                      torch.from_numpy(G["dL"]).to(dev), e, 0, c.camera_center, geom, n,
+                                      binn, img, False)
+    names = ["dL_dmean2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", None, None, "dL_dscales", "dL_drotations"]
+    for name, t in zip(names, grads):
+        if name is None:
+            continue
+        want = G[name]
+        got = t.cpu().numpy().reshape(want.shape)
+        assert np.abs(got - want).max() <= 1e-4 * (np.abs(want).max() + 1e-20), name
+    from simple_knn._C import distCUDA2
+    assert np.array_equal(distCUDA2(s.means3D).cpu().numpy(), G["dist2"])
