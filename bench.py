@@ -32,6 +32,11 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# keep the caching allocator from splitting the multi-GB output / scratch blocks (otherwise it
+# needs tens of frames of hipMalloc before it settles)
+os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "max_split_size_mb:256")
+os.environ.setdefault("PYTORCH_CUDA_ALLOC_CONF", os.environ["PYTORCH_HIP_ALLOC_CONF"])
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -132,11 +137,13 @@ def main():
     empty = torch.Tensor([])
     raster.set_blend_variant(args.variant)
 
+    pool = raster.ScratchPool()   # inference: state buffers stay resident (as under torch.no_grad)
+
     def step():
         return raster.rasterize_forward(
             s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, empty,
             c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, empty, 0,
-            c.camera_center, False, False, C, False)
+            c.camera_center, False, False, C, False, pool=pool)
 
     def barrier():
         if world > 1:

@@ -195,9 +195,10 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
 
 /* Tuning / measurement hooks (not part of the reference's interface). */
 /* Selects the blend-forward kernel variant (tuning / A-B measurements; all variants are
- * bit-identical).  0 = default: weights pre-pass + LDS-fed streaming accumulate for the
+ * bit-identical).  0 = default: weights pre-pass + LDS-DMA-fed f32-MFMA accumulate for the
  * 128-channel-aligned part, px1 for the rest.  1/2/3 = px1 with 64/128/32 channels per
- * workgroup; 4/5/6 = single-kernel px4 forms; 7/8/9 = split path with scalar-fed accumulate.
+ * workgroup; 4/5/6 = single-kernel px4 forms; 7/8/9 = split path with scalar-fed VALU
+ * accumulate; 10 = split path with LDS-fed VALU accumulate.
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.

@@ -446,6 +446,170 @@ __global__ __launch_bounds__(256) void blend_accum_lds_kernel(
 	}
 }
 
+// -------------------------------------------------------------------------------------
+// MFMA accumulate.  The accumulate step IS a matrix product per tile:
+//     out[ch][px] = sum_k F[k][ch] * W[k][px]        (k = work-list entry, in list order)
+// and rocprof shows the VALU version pinned at the vector-FMA issue rate (profiles/r01a), not
+// at HBM.  gfx950's f32-input MFMA (v_mfma_f32_32x32x2_f32) evaluates exactly a k-ordered
+// fmaf chain -- D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per product, no wider
+// accumulation -- so it returns the SAME BITS as the scalar contract (and as the oracle) at
+// the full 64 FLOP/clk/SIMD rate that plain v_fmac_f32 cannot sustain.  Zero weights (pixels
+// an entry does not touch, odd-tail padding) add exactly +0.
+//
+// One workgroup = tile x 128 channels; wave w owns channels [32w, 32w+32) for all 256 pixels:
+// 8 MFMA blocks of 32 channels x 32 pixels (8 x 16 accumulator VGPRs).  Per pair of entries:
+// 1 ds_read_b32 of features (A: lane l -> channel l&31 of entry l>>5), 8 ds_read_b32 of
+// weights (B: lane l -> pixel 32*nb + (l&31) of entry l>>5), 8 MFMAs.  Operands are staged by
+// LDS-DMA one batch ahead exactly as in blend_accum_lds_kernel.  D has pixels along lanes, so
+// the epilogue stores 32 consecutive pixels of one channel per half wave (2 x 64-B rows).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float4* __restrict__ wgt, const float* __restrict__ features,
+	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
+	int total_blocks, int dbg)
+{
+	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
+	const int b = blockIdx.x;
+	const int v = (b & 7) * per_xcd + (b >> 3);
+	if (v >= total_blocks) return;
+	const int tile = v / nchunks_c;
+	const int chunk = v - tile * nchunks_c;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int cbase = chunk * 128;
+	const int c0 = cbase + wave * 32;
+	const int tx = tile % gx, ty = tile / gx;
+	const size_t HW = (size_t)H * W;
+	const uint32_t total = nact[tile];
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const uint32_t Q = (total + AB - 1) / AB;
+
+	__shared__ float4 s_featA[AB * 32], s_featB[AB * 32];   // [entry][128 floats]
+	__shared__ float4 s_wA[AB * 64], s_wB[AB * 64];         // [entry][256 floats]
+
+	f32x16 acc[8];
+#pragma unroll
+	for (int nb = 0; nb < 8; nb++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) acc[nb][r] = 0.f;
+
+	auto batch_slot = [&](uint32_t q) -> uint32_t {
+		const uint32_t first = q * AB;
+		return table[chunk_base + (first >> 7)] + (first & 127u);
+	};
+	const int sub = threadIdx.x >> 5;
+	auto load_ids = [&](uint32_t q, uint32_t& i0, uint32_t& i1) {
+		const uint32_t slot = batch_slot(q);
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		const uint32_t e0 = (uint32_t)sub < n ? (uint32_t)sub : n - 1u;
+		const uint32_t e1 = (uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u;
+		i0 = act_id[slot + e0];
+		i1 = act_id[slot + e1];
+	};
+	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
+		const uint32_t slot = batch_slot(q);
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
+		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
+						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32],
+						 16, 0, 0);
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
+						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32],
+						 16, 0, 0);
+#pragma unroll
+		for (int j = 0; j < AB / 4; j++) {
+			const uint32_t e = (uint32_t)(4 * j + wave);
+			const uint32_t ec = e < n ? e : n - 1u;
+			const float4* src = wgt + (size_t)(slot + ec) * 64 + lane;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+							 (__attribute__((address_space(3))) void*)&s_w[e * 64],
+							 16, 0, 0);
+		}
+	};
+	const int half = lane >> 5, l31 = lane & 31;
+	// Software-pipelined at half-pair granularity: the four B operands of the next group are
+	// in flight (ds_read_b32) while the four MFMAs of the current group occupy the matrix pipe
+	// (4 x 64 cycles >> LDS latency), so one wave alone can keep the pipe busy.
+	auto compute = [&](uint32_t q, const float4* s_feat4, const float4* s_w4) {
+		const float* s_feat = reinterpret_cast<const float*>(s_feat4);
+		const float* s_w = reinterpret_cast<const float*>(s_w4);
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		const float* fcol = s_feat + half * 128 + wave * 32 + l31;   // + e*128
+		const float* wcol = s_w + half * 256 + l31;                   // + e*256 + nb*32
+		float a = fcol[0];
+		float b0 = wcol[0], b1 = wcol[32], b2 = wcol[64], b3 = wcol[96];
+		for (uint32_t e = 0; e < n; e += 2) {
+			const bool live = e + (uint32_t)half < n;   // odd tail: the second entry is padding
+			const float* wr = (dbg & 1) ? wcol : wcol + e * 256;
+			const float c0_ = wr[128], c1_ = wr[160], c2_ = wr[192], c3_ = wr[224];
+			const float z0 = live ? b0 : 0.f, z1 = live ? b1 : 0.f, z2 = live ? b2 : 0.f, z3 = live ? b3 : 0.f;
+			acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z0, acc[0], 0, 0, 0);
+			acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z1, acc[1], 0, 0, 0);
+			acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z2, acc[2], 0, 0, 0);
+			acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z3, acc[3], 0, 0, 0);
+			// next pair's feature column and first group (LDS rows past n hold the clamped
+			// duplicate of the last entry: finite, and masked by `live` when used)
+			const uint32_t en = (e + 2 < (uint32_t)AB) ? e + 2 : e;
+			const float an = (dbg & 1) ? a : fcol[en * 128];
+			const float* wn = (dbg & 1) ? wcol : wcol + en * 256;
+			b0 = wn[0]; b1 = wn[32]; b2 = wn[64]; b3 = wn[96];
+			const float y0 = live ? c0_ : 0.f, y1 = live ? c1_ : 0.f, y2 = live ? c2_ : 0.f, y3 = live ? c3_ : 0.f;
+			acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y0, acc[4], 0, 0, 0);
+			acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y1, acc[5], 0, 0, 0);
+			acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y2, acc[6], 0, 0, 0);
+			acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y3, acc[7], 0, 0, 0);
+			a = an;
+		}
+	};
+
+	if (Q > 0) {
+		uint32_t i0, i1, n0 = 0, n1 = 0;
+		load_ids(0, i0, i1);
+		issue(0, s_featA, s_wA, i0, i1);
+		if (Q > 1) load_ids(1, n0, n1);
+		for (uint32_t q = 0; q < Q; q += 2) {
+			__syncthreads();
+			if (q + 1 < Q && !(dbg & 2)) {
+				issue(q + 1, s_featB, s_wB, n0, n1);
+				if (q + 2 < Q) load_ids(q + 2, n0, n1);
+			}
+			compute(q, s_featA, s_wA);
+			if (q + 1 < Q) {
+				__syncthreads();
+				if (q + 2 < Q && !(dbg & 2)) {
+					issue(q + 2, s_featA, s_wA, n0, n1);
+					if (q + 3 < Q) load_ids(q + 3, n0, n1);
+				}
+				compute(q + 1, s_featB, s_wB);
+			}
+		}
+	}
+
+	// epilogue.  D layout (32x32x2, dtype-independent): column = lane & 31 -> pixel 32*nb + l31,
+	// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -> channel c0 + row.
+#pragma unroll
+	for (int nb = 0; nb < 8; nb++) {
+		const int qidx = nb * 32 + l31;              // work-list pixel index: strip*64 + pos
+		const int x = tx * SGS_TILE + (qidx & 15);
+		const int y = ty * SGS_TILE + (qidx >> 6) * 4 + ((qidx & 63) >> 4);
+		if (x < W && y < H) {
+			const size_t pix = (size_t)y * W + x;
+			const float Tp = final_T[pix];
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+				const float o = __builtin_fmaf(Tp, bg[c], acc[nb][r]);
+				if (!(dbg & 4) || o == 123.456f) out[(size_t)c * HW + pix] = o;
+			}
+		}
+	}
+}
+
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
 {
 	size_t off = 0;
@@ -493,7 +657,12 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
 			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
 			   total, (split_mode >> 4))
-		if (sm == 3)
+		if (sm == 4)
+			hipLaunchKernelGGL(blend_accum_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
+					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
+					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total,
+					   (split_mode >> 4));
+		else if (sm == 3)
 			hipLaunchKernelGGL(blend_accum_lds_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
 					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
 					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);

@@ -74,9 +74,12 @@ def _make_function(with_depth):
                     cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
                     s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
                     s.debug, channels)
+            # nothing to backpropagate (torch.no_grad / no input requires grad): the state buffers
+            # need not outlive the call, keep them in the resident inference pool
+            pool = None if any(ctx.needs_input_grad) else raster.INFERENCE_POOL
             try:
                 (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer,
-                 depth) = raster.rasterize_forward(*call, want_depth=with_depth)
+                 depth) = raster.rasterize_forward(*call, want_depth=with_depth, pool=pool)
             except Exception:
                 if s.debug:
                     _snapshot(call, "snapshot_fw.dump")

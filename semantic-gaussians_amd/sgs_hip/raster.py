@@ -25,19 +25,51 @@ def _ptr(t, name, device, dtype=torch.float32):
     return t.data_ptr(), t
 
 
+class ScratchPool:
+    """Grow-only per-device scratch for the three opaque state buffers.
+
+    Inference callers (torch.no_grad, nothing to backpropagate) do not need the buffers to
+    survive the call, so re-allocating ~2 GB of scratch per frame through the caching
+    allocator is pure overhead (and makes it thrash: blocks of 2.6 GB / 1.6 GB / 0.1 GB are
+    split and re-split for many frames before it settles).  A pool keeps them resident.
+    Buffers handed out from a pool are only valid until the next forward on that pool."""
+
+    def __init__(self):
+        self._t = {}
+
+    def get(self, device, key, nbytes):
+        k = (str(device), key)
+        t = self._t.get(k)
+        if t is None or t.numel() < nbytes:
+            nb = int(nbytes * 1.25) if t is not None else int(nbytes)   # amortise growth
+            t = torch.empty(nb, dtype=torch.uint8, device=device)
+            self._t[k] = t
+        return t
+
+    def clear(self):
+        self._t.clear()
+
+
+INFERENCE_POOL = ScratchPool()
+
+
 class _Buffers:
     """Growable byte buffers handed to the library through the sgs_alloc_fn callback
     (the reference's resizeFunctional, CR/rasterize_points.cu:28-36)."""
 
-    def __init__(self, device):
+    def __init__(self, device, pool=None):
         self.device = device
+        self.pool = pool
         self.tensors = {}
         self._cbs = {}
 
     def callback(self, key):
         def alloc(_user, nbytes):
             try:
-                t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                if self.pool is not None:
+                    t = self.pool.get(self.device, key, int(nbytes))
+                else:
+                    t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
                 self.tensors[key] = t
                 return t.data_ptr()
             except Exception:   # noqa: BLE001 - reported as SGS_EALLOC by the library
@@ -60,9 +92,10 @@ def _stream_ptr(device):
 def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                       image_width, sh, degree, campos, prefiltered, debug, num_channels,
-                      want_depth):
+                      want_depth, pool=None):
     """RasterizeGaussiansCUDA (CR/rasterize_points.cu:38-121; RR variant returns depth too).
-    Returns (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth)."""
+    Returns (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth).
+    pool: optional ScratchPool for the three state buffers (inference; see ScratchPool)."""
     lib = _lib.load()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -72,7 +105,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
     P, H, W, Cn = means3D.size(0), int(image_height), int(image_width), int(num_channels)
     keep = []
     with torch.cuda.device(dev):
-        bufs = _Buffers(dev)
+        bufs = _Buffers(dev, pool)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         depth = None
         if P == 0:

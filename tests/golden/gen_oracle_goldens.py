@@ -1,5 +1,6 @@
-"""Generates tests/golden/small_scene.npz: inputs are reproduced from the seed, expected
-outputs come from the CPU oracle.  Committed so that (a) the oracle itself is regression-pinned
+"""Generates tests/golden/small_scene.npz: the INPUT tensors are stored (torch's CPU exp /
+sigmoid / norm kernels are not bit-reproducible across host CPUs, so a seed is not enough),
+expected outputs come from the CPU oracle.  Committed so that (a) the oracle itself is regression-pinned
 and (b) the GPU parity tests have a fixed vector that does not depend on building the oracle.
 
     python tests/golden/gen_oracle_goldens.py
@@ -41,6 +42,9 @@ def main():
         os.path.join(HERE, "small_scene.npz"),
         params=np.array([PARAMS[k] for k in ("P", "C", "W", "H")], np.int64), fx=PARAMS["fx"],
         seed=PARAMS["seed"], bg=bg, dL=dL,
+        in_means3D=scene.means3D.numpy(), in_scales=scene.scales.numpy(),
+        in_rotations=scene.rotations.numpy(), in_opacities=scene.opacities.numpy(),
+        in_features=scene.features.numpy(),
         num_rendered=fw["num_rendered"], radii=fw["radii"], ranges=fw["ranges"],
         keys_sorted_sha256=digest(fw["keys_sorted"]), point_list_sha256=digest(fw["point_list"]),
         keys_sorted_head=fw["keys_sorted"][:64], point_list_head=fw["point_list"][:64],

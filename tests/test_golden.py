@@ -18,7 +18,14 @@ def _digest(a):
 
 
 def _scene():
-    return small_scene(P=P, C=C, W=W, H=H, fx=float(G["fx"]), seed=int(G["seed"]))
+    # geometry of the generator (camera) + the STORED input tensors: torch's CPU exp / sigmoid /
+    # norm kernels differ in the last bit between host CPUs, a seed alone is not reproducible
+    scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=float(G["fx"]), seed=int(G["seed"]))
+    scene = scene._replace(
+        means3D=torch.from_numpy(G["in_means3D"]), scales=torch.from_numpy(G["in_scales"]),
+        rotations=torch.from_numpy(G["in_rotations"]), opacities=torch.from_numpy(G["in_opacities"]),
+        features=torch.from_numpy(G["in_features"]))
+    return scene, cam
 
 
 def test_oracle_reproduces_golden(orc):
