@@ -111,29 +111,44 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		}
 		if (threadIdx.x < WB) s_active[threadIdx.x] = 0u;
 		__syncthreads();
-		// ---- weight phase: wave w evaluates strip w for the whole batch
-		for (int j = 0; j < n; j++) {
-			float w = 0.0f;
-			if (wave_alive) {
-				const StagedEntryW e = s_e[j];
-				const float dx = e.x - pxf, dy = e.y - pyf;
-				const float power = __builtin_fmaf(
-					e.b2 * dx, dy, __builtin_fmaf(e.c2 * dy, dy, (e.a2 * dx) * dx));
-				const float alpha = fmin_(0.99f, e.o * expf_contract(power));
-				const float test_T = T * (1.0f - alpha);
-				const bool cand = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-				const bool stop = cand && (test_T < 0.0001f);
-				const bool take = cand && !stop;
-				done = done || stop;
-				if (take) {
-					w = alpha * T;
-					T = test_T;
-					last = (uint32_t)(base + j + 1);
+		// ---- weight phase: wave w evaluates strip w for the whole batch.  Four entries per
+		// step: their LDS reads, exponents and alphas are independent (ILP); only the
+		// transmittance chain (3 ops per entry) is sequential.
+		if (wave_alive) {
+			for (int j0 = 0; j0 < n; j0 += 4) {
+				float alpha[4], power[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int j = (j0 + u < n) ? j0 + u : n - 1;   // clamp: results of padding are dropped
+					const StagedEntryW e = s_e[j];
+					const float dx = e.x - pxf, dy = e.y - pyf;
+					power[u] = __builtin_fmaf(e.b2 * dx, dy,
+								  __builtin_fmaf(e.c2 * dy, dy, (e.a2 * dx) * dx));
+					alpha[u] = fmin_(0.99f, e.o * expf_contract(power[u]));
 				}
-				const bool any_take = __ballot(take) != 0ull;
-				if (lane == 0 && any_take) s_active[j] = 1u;   // benign same-value race
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int j = j0 + u;
+					if (j < n) {
+						const float test_T = T * (1.0f - alpha[u]);
+						const bool cand = !done && !(power[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
+						const bool stop = cand && (test_T < 0.0001f);
+						const bool take = cand && !stop;
+						done = done || stop;
+						float w = 0.0f;
+						if (take) {
+							w = alpha[u] * T;
+							T = test_T;
+							last = (uint32_t)(base + j + 1);
+						}
+						const bool any_take = __ballot(take) != 0ull;
+						if (lane == 0 && any_take) s_active[j] = 1u;   // benign same-value race
+						s_wt[j * 256 + wave * 64 + lane] = w;
+					}
+				}
 			}
-			s_wt[j * 256 + wave * 64 + lane] = w;
+		} else {
+			for (int j = 0; j < n; j++) s_wt[j * 256 + wave * 64 + lane] = 0.0f;
 		}
 		__syncthreads();
 		// ---- compaction into the tile's contiguous chunks
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 	const float4* __restrict__ wgt, const float* __restrict__ features,
 	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
 	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
-	int total_blocks, int dbg)
+	int total_blocks)
 {
 	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
 	const int b = blockIdx.x;
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 		float b0 = wcol[0], b1 = wcol[32], b2 = wcol[64], b3 = wcol[96];
 		for (uint32_t e = 0; e < n; e += 2) {
 			const bool live = e + (uint32_t)half < n;   // odd tail: the second entry is padding
-			const float* wr = (dbg & 1) ? wcol : wcol + e * 256;
+			const float* wr = wcol + e * 256;
 			const float c0_ = wr[128], c1_ = wr[160], c2_ = wr[192], c3_ = wr[224];
 			const float z0 = live ? b0 : 0.f, z1 = live ? b1 : 0.f, z2 = live ? b2 : 0.f, z3 = live ? b3 : 0.f;
 			acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z0, acc[0], 0, 0, 0);
@@ -555,8 +570,8 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 			// next pair's feature column and first group (LDS rows past n hold the clamped
 			// duplicate of the last entry: finite, and masked by `live` when used)
 			const uint32_t en = (e + 2 < (uint32_t)AB) ? e + 2 : e;
-			const float an = (dbg & 1) ? a : fcol[en * 128];
-			const float* wn = (dbg & 1) ? wcol : wcol + en * 256;
+			const float an = fcol[en * 128];
+			const float* wn = wcol + en * 256;
 			b0 = wn[0]; b1 = wn[32]; b2 = wn[64]; b3 = wn[96];
 			const float y0 = live ? c0_ : 0.f, y1 = live ? c1_ : 0.f, y2 = live ? c2_ : 0.f, y3 = live ? c3_ : 0.f;
 			acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y0, acc[4], 0, 0, 0);
@@ -574,14 +589,14 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 		if (Q > 1) load_ids(1, n0, n1);
 		for (uint32_t q = 0; q < Q; q += 2) {
 			__syncthreads();
-			if (q + 1 < Q && !(dbg & 2)) {
+			if (q + 1 < Q) {
 				issue(q + 1, s_featB, s_wB, n0, n1);
 				if (q + 2 < Q) load_ids(q + 2, n0, n1);
 			}
 			compute(q, s_featA, s_wA);
 			if (q + 1 < Q) {
 				__syncthreads();
-				if (q + 2 < Q && !(dbg & 2)) {
+				if (q + 2 < Q) {
 					issue(q + 2, s_featA, s_wA, n0, n1);
 					if (q + 3 < Q) load_ids(q + 3, n0, n1);
 				}
@@ -603,8 +618,7 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
 				const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-				const float o = __builtin_fmaf(Tp, bg[c], acc[nb][r]);
-				if (!(dbg & 4) || o == 123.456f) out[(size_t)c * HW + pix] = o;
+				out[(size_t)c * HW + pix] = __builtin_fmaf(Tp, bg[c], acc[nb][r]);
 			}
 		}
 	}
@@ -660,8 +674,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		if (sm == 4)
 			hipLaunchKernelGGL(blend_accum_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
 					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
-					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total,
-					   (split_mode >> 4));
+					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);
 		else if (sm == 3)
 			hipLaunchKernelGGL(blend_accum_lds_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
 					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
