@@ -624,6 +624,228 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 	}
 }
 
+// -------------------------------------------------------------------------------------
+// MFMA accumulate, 3-stage LDS ring.  Same arithmetic as blend_accum_mfma_kernel; the operand
+// bundles (features + weights + the Gaussian ids two batches ahead) run TWO batches ahead of
+// the MFMAs instead of one: with one batch in flight a workgroup spends most of its life
+// waiting for a ~3-4 us DMA round trip per 16 entries (measured: MFMA pipe 54 % busy).
+// There is no ordinary VGPR-returning load inside the loop (ids travel in the DMA bundles),
+// so the only vmcnt waits are the explicit counted ones: `s_waitcnt vmcnt(NDMA)` leaves the
+// next bundle in flight across the raw s_barrier (cdna_hip_programming.md, "glds span").
+constexpr int NDMA = 7;   // LDS-DMA instructions per wave per bundle: 2 feature + 4 weight + 1 id
+
+__global__ __launch_bounds__(256, 2) void blend_accum_mfma3_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float4* __restrict__ wgt, const float* __restrict__ features,
+	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
+	int total_blocks)
+{
+	if (counter[1] != 0u) return;
+	const int b = blockIdx.x;
+	const int v = (b & 7) * per_xcd + (b >> 3);
+	if (v >= total_blocks) return;
+	const int tile = v / nchunks_c;
+	const int chunk = v - tile * nchunks_c;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int cbase = chunk * 128;
+	const int c0 = cbase + wave * 32;
+	const int tx = tile % gx, ty = tile / gx;
+	const size_t HW = (size_t)H * W;
+	const uint32_t total = nact[tile];
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const uint32_t Q = (total + AB - 1) / AB;
+
+	// three ring stages as distinct LDS objects (alias analysis for the DMA / ds_read overlap)
+	__shared__ float4 s_f0[AB * 32], s_f1[AB * 32], s_f2[AB * 32];
+	// weight stage + 1 KB tail holding, per wave, the ids of batch q+2 (kept inside the same
+	// object: the waitcnt pass tracks at most 8 distinct LDS-DMA destinations precisely)
+	__shared__ float4 s_w0[AB * 64 + 64], s_w1[AB * 64 + 64], s_w2[AB * 64 + 64];
+
+	f32x16 acc[8];
+#pragma unroll
+	for (int nb = 0; nb < 8; nb++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) acc[nb][r] = 0.f;
+
+	auto batch_slot = [&](uint32_t q) -> uint32_t {
+		const uint32_t first = q * AB;
+		return table[chunk_base + (first >> 7)] + (first & 127u);
+	};
+	auto batch_n = [&](uint32_t q) -> uint32_t {
+		return (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+	};
+	const int sub = threadIdx.x >> 5;   // 0..7: which entry of an 8-entry group this lane fetches
+	// bundle q -> (features q, weights q, ids of batch q+2) into one ring stage
+	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
+		uint32_t* s_id = reinterpret_cast<uint32_t*>(s_w + AB * 64);
+		const uint32_t slot = batch_slot(q);
+		const uint32_t n = batch_n(q);
+		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
+		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
+						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32], 16, 0, 0);
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
+						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32], 16, 0, 0);
+#pragma unroll
+		for (int j = 0; j < AB / 4; j++) {
+			const uint32_t e = (uint32_t)(4 * j + wave);
+			const uint32_t ec = e < n ? e : n - 1u;
+			const float4* src = wgt + (size_t)(slot + ec) * 64 + lane;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+							 (__attribute__((address_space(3))) void*)&s_w[e * 64], 16, 0, 0);
+		}
+		// ids of batch q+2 (clamped to the list end; harmless duplicates when it does not exist)
+		const uint32_t q2 = q + 2 < Q ? q + 2 : Q - 1;
+		const uint32_t slot2 = batch_slot(q2);
+		const uint32_t n2 = batch_n(q2);
+		const uint32_t li = (uint32_t)(lane & 15) < n2 ? (uint32_t)(lane & 15) : n2 - 1u;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(act_id + slot2 + li),
+						 (__attribute__((address_space(3))) void*)&s_id[wave * 64], 4, 0, 0);
+	};
+	const int half = lane >> 5, l31 = lane & 31;
+	// The LDS reads of the ring are issued from inline asm: the compiler's waitcnt pass would
+	// otherwise put s_waitcnt vmcnt(0) in front of every ds_read of an object that ever was an
+	// LDS-DMA destination inside this loop and drain the bundles in flight.  Rules kept here
+	// (cdna_hip_programming.md 5.7): outputs are early-clobber, nothing consumes an output
+	// before the explicit lgkmcnt(0), and that wait takes the values as "+v" so that no use can
+	// be scheduled above it.
+	auto lds_off = [](const void* p) -> uint32_t {
+		return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
+	};
+	auto compute = [&](uint32_t q, const float4* s_feat4, const float4* s_w4) {
+		const uint32_t n = batch_n(q);
+		uint32_t fa = lds_off(s_feat4) + (uint32_t)(half * 128 + wave * 32 + l31) * 4u;   // + e*512
+		uint32_t wa = lds_off(s_w4) + (uint32_t)(half * 256 + l31) * 4u;                  // + e*1024
+		float a, b0, b1, b2, b3;
+		asm volatile(
+			"ds_read_b32 %0, %5\n\t"
+			"ds_read_b32 %1, %6\n\t"
+			"ds_read_b32 %2, %6 offset:128\n\t"
+			"ds_read_b32 %3, %6 offset:256\n\t"
+			"ds_read_b32 %4, %6 offset:384\n\t"
+			"s_waitcnt lgkmcnt(0)"
+			: "=&v"(a), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+			: "v"(fa), "v"(wa)
+			: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		for (uint32_t e = 0; e < n; e += 2) {
+			const bool live = e + (uint32_t)half < n;   // odd tail: the second entry is padding
+			float c0_, c1_, c2_, c3_;
+			asm volatile(
+				"ds_read_b32 %0, %4 offset:512\n\t"
+				"ds_read_b32 %1, %4 offset:640\n\t"
+				"ds_read_b32 %2, %4 offset:768\n\t"
+				"ds_read_b32 %3, %4 offset:896"
+				: "=&v"(c0_), "=&v"(c1_), "=&v"(c2_), "=&v"(c3_)
+				: "v"(wa)
+				: "memory");
+			const float z0 = live ? b0 : 0.f, z1 = live ? b1 : 0.f, z2 = live ? b2 : 0.f, z3 = live ? b3 : 0.f;
+			acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z0, acc[0], 0, 0, 0);
+			acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z1, acc[1], 0, 0, 0);
+			acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z2, acc[2], 0, 0, 0);
+			acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z3, acc[3], 0, 0, 0);
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0_), "+v"(c1_), "+v"(c2_), "+v"(c3_) : : "memory");
+			__builtin_amdgcn_sched_barrier(0);
+			// next pair (rows past the batch hold the clamped duplicate of the last entry:
+			// finite, masked by `live` when used; never read past the stage: en stays < AB)
+			const uint32_t step = (e + 2 < (uint32_t)AB) ? 1u : 0u;
+			fa += step * 1024u;   // 2 entries x 512 B
+			wa += step * 2048u;   // 2 entries x 1 KB
+			float an, n0, n1, n2, n3;
+			asm volatile(
+				"ds_read_b32 %0, %5\n\t"
+				"ds_read_b32 %1, %6\n\t"
+				"ds_read_b32 %2, %6 offset:128\n\t"
+				"ds_read_b32 %3, %6 offset:256\n\t"
+				"ds_read_b32 %4, %6 offset:384"
+				: "=&v"(an), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+				: "v"(fa), "v"(wa)
+				: "memory");
+			const float y0 = live ? c0_ : 0.f, y1 = live ? c1_ : 0.f, y2 = live ? c2_ : 0.f, y3 = live ? c3_ : 0.f;
+			acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y0, acc[4], 0, 0, 0);
+			acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y1, acc[5], 0, 0, 0);
+			acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y2, acc[6], 0, 0, 0);
+			acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y3, acc[7], 0, 0, 0);
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
+			__builtin_amdgcn_sched_barrier(0);
+			a = an; b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+		}
+	};
+	// this lane's two feature-row ids for a batch, read from the id slot a landed bundle carries
+	auto ids_from = [&](const float4* s_w, uint32_t& i0, uint32_t& i1) {
+		const uint32_t ia = lds_off(s_w + AB * 64) + (uint32_t)(wave * 64 + sub) * 4u;
+		asm volatile(
+			"ds_read_b32 %0, %2\n\t"
+			"ds_read_b32 %1, %2 offset:32\n\t"
+			"s_waitcnt lgkmcnt(0)"
+			: "=&v"(i0), "=&v"(i1)
+			: "v"(ia)
+			: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+	};
+
+#define SGS_WAIT_BUNDLE(n_) __builtin_amdgcn_s_waitcnt((n_) | (7 << 4) | (15 << 8))
+	if (Q > 0) {
+		// prologue: ids of batches 0 and 1 by ordinary loads (nothing in flight yet)
+		uint32_t i0, i1, j0, j1;
+		{
+			const uint32_t n = batch_n(0), slot = batch_slot(0);
+			i0 = act_id[slot + ((uint32_t)sub < n ? (uint32_t)sub : n - 1u)];
+			i1 = act_id[slot + ((uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u)];
+			const uint32_t q1 = Q > 1 ? 1u : 0u;
+			const uint32_t n1 = batch_n(q1), slot1 = batch_slot(q1);
+			j0 = act_id[slot1 + ((uint32_t)sub < n1 ? (uint32_t)sub : n1 - 1u)];
+			j1 = act_id[slot1 + ((uint32_t)sub + 8u < n1 ? (uint32_t)sub + 8u : n1 - 1u)];
+		}
+		issue(0, s_f0, s_w0, i0, i1);
+		issue(Q > 1 ? 1u : 0u, s_f1, s_w1, j0, j1);   // (a dummy re-issue of batch 0 when Q == 1)
+		// straight-line 3-stage body, no early exits: every stage issues exactly one bundle
+		// (clamped to the last batch when the list is exhausted; its data is never consumed)
+		// and computes its batch only if it exists.
+		const uint32_t QL = Q - 1;
+		for (uint32_t q = 0; q < Q; q += 3) {
+			SGS_WAIT_BUNDLE(7);                 // bundle q landed, bundle q+1 may still fly
+			__builtin_amdgcn_s_barrier();
+			ids_from(s_w0, i0, i1);
+			issue(q + 2 < Q ? q + 2 : QL, s_f2, s_w2, i0, i1);
+			compute(q, s_f0, s_w0);
+
+			SGS_WAIT_BUNDLE(7);
+			__builtin_amdgcn_s_barrier();
+			ids_from(s_w1, i0, i1);
+			issue(q + 3 < Q ? q + 3 : QL, s_f0, s_w0, i0, i1);
+			if (q + 1 < Q) compute(q + 1, s_f1, s_w1);
+
+			SGS_WAIT_BUNDLE(7);
+			__builtin_amdgcn_s_barrier();
+			ids_from(s_w2, i0, i1);
+			issue(q + 4 < Q ? q + 4 : QL, s_f1, s_w1, i0, i1);
+			if (q + 2 < Q) compute(q + 2, s_f2, s_w2);
+		}
+		__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the tail bundles before LDS is released
+	}
+#undef SGS_WAIT_BUNDLE
+
+#pragma unroll
+	for (int nb = 0; nb < 8; nb++) {
+		const int qidx = nb * 32 + l31;
+		const int x = tx * SGS_TILE + (qidx & 15);
+		const int y = ty * SGS_TILE + (qidx >> 6) * 4 + ((qidx & 63) >> 4);
+		if (x < W && y < H) {
+			const size_t pix = (size_t)y * W + x;
+			const float Tp = final_T[pix];
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+				out[(size_t)c * HW + pix] = __builtin_fmaf(Tp, bg[c], acc[nb][r]);
+			}
+		}
+	}
+}
+
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
 {
 	size_t off = 0;
@@ -671,7 +893,11 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
 			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
 			   total, (split_mode >> 4))
-		if (sm == 4)
+		if (sm == 5)
+			hipLaunchKernelGGL(blend_accum_mfma3_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
+					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
+					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);
+		else if (sm == 4)
 			hipLaunchKernelGGL(blend_accum_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
 					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
 					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);

@@ -89,7 +89,7 @@ def test_expf_contract_bit_exact(orc):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_forward_c128_all_variants(orc, variant):
     scene, cam = small_scene(P=3000, C=128, W=200, H=120, fx=170.0, seed=1)
     fw = _check_forward(orc, scene, cam, variant=variant)
