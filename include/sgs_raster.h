@@ -189,6 +189,13 @@ int sgs_image_layout_of(int width, int height, sgs_image_layout *out);
  * (CR/cuda_rasterizer/rasterizer_impl.cu:35-50,302). */
 int sgs_sort_bits(int width, int height);
 
+/* Binning mode 0 sorts 32-bit tile ids; the reference's sorted 64-bit keys
+ * (tile << 32 | depth bits) are not needed by any kernel and are materialised into the
+ * binning buffer's keys_sorted area only by this call (parity tests).  Call it only on buffers
+ * a mode-0 forward produced: a mode-1 forward has written the real sorted keys already. */
+int sgs_debug_sorted_keys(int P, int num_rendered, const char *geom_buffer,
+			  char *binning_buffer, void *stream);
+
 /* Device exp() used by the blend kernels, exposed for the numerics contract test
  * (DESIGN.md "exp contract"): out[i] = sgs_expf(in[i]). */
 int sgs_debug_expf(int n, const float *in, float *out, void *stream);

@@ -169,4 +169,147 @@ void launch_tile_ranges(hipStream_t st, size_t L, const uint64_t* keys, uint2* r
 			   (uint32_t)L, keys, ranges);
 }
 
+// ---------------------------------------------------------------------------------------
+// Mode 0 emission: 32-bit tile keys, workgroup-staged search.
+//
+// After the depth presort every Gaussian with tiles (radius > 0) precedes every culled one
+// (their depth key is 0xFFFFFFFF), so the ranks that cover a window of IPB consecutive
+// instances number at most IPB.  A workgroup therefore (1) finds the first/last rank of its
+// window with two binary searches in global memory, (2) stages those ranks' offsets and tile
+// rects in LDS once, (3) resolves each of its instances with an 11-step search in LDS instead
+// of a 20-step search through L2, and re-uses the rect instead of recomputing it per instance.
+// Only the tile id (<= 16 bits here) is emitted as the sort key: the instance sort is stable
+// on the tile bits and the depth order is already in the emission order.
+constexpr int IPB = 2048;   // instances per workgroup
+
+__global__ __launch_bounds__(256) void emit_tile_keys_kernel(
+	int P, uint32_t L, const float2* __restrict__ means2D, const uint32_t* __restrict__ offsets,
+	const int* __restrict__ radii, const uint32_t* __restrict__ perm, int gx, int gy,
+	uint32_t* __restrict__ keys32, uint32_t* __restrict__ vals)
+{
+	__shared__ uint32_t s_off[IPB + 1];    // s_off[k] = offsets[r0 + k - 1] (exclusive start of rank r0+k)
+	__shared__ uint32_t s_g[IPB];
+	__shared__ uint32_t s_rect[IPB];       // x0 | y0 << 16
+	__shared__ uint32_t s_w[IPB];          // rect width in tiles
+	__shared__ int s_r0, s_r1;
+	const uint32_t i0 = blockIdx.x * (uint32_t)IPB;
+	const uint32_t i1 = (i0 + IPB < L ? i0 + IPB : L) - 1u;   // last instance of the window
+	if (threadIdx.x < 2) {
+		const uint32_t target = threadIdx.x ? i1 : i0;
+		int lo = 0, hi = P - 1;
+		while (lo < hi) {   // smallest rank with offsets[rank] > target
+			const int mid = (lo + hi) >> 1;
+			if (offsets[mid] > target) hi = mid;
+			else lo = mid + 1;
+		}
+		if (threadIdx.x) s_r1 = lo;
+		else s_r0 = lo;
+	}
+	__syncthreads();
+	const int r0 = s_r0, nr = s_r1 - r0 + 1;   // nr <= IPB (every rank in the window has >= 1 tile)
+	for (int k = threadIdx.x; k <= nr; k += 256) {
+		const int r = r0 + k - 1;
+		s_off[k] = r < 0 ? 0u : offsets[r];
+	}
+	for (int k = threadIdx.x; k < nr; k += 256) {
+		const uint32_t g = perm[r0 + k];
+		const float2 p = means2D[g];
+		uint32_t x0, y0, x1, y1;
+		get_rect(p.x, p.y, radii[g], gx, gy, x0, y0, x1, y1);
+		s_g[k] = g;
+		s_rect[k] = x0 | (y0 << 16);
+		s_w[k] = x1 - x0;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int it = 0; it < IPB / 256; it++) {
+		const uint32_t i = i0 + it * 256 + threadIdx.x;
+		if (i > i1) break;
+		int lo = 0, hi = nr - 1;   // largest k with s_off[k] <= i
+		while (lo < hi) {
+			const int mid = (lo + hi + 1) >> 1;
+			if (s_off[mid] <= i) lo = mid;
+			else hi = mid - 1;
+		}
+		const uint32_t k = i - s_off[lo];
+		const uint32_t rc = s_rect[lo];
+		const uint32_t x0 = rc & 0xffffu, y0 = rc >> 16, w = s_w[lo];
+		keys32[i] = (y0 + k / w) * (uint32_t)gx + (x0 + k % w);
+		vals[i] = s_g[lo];
+	}
+}
+
+void launch_emit_tile_keys(hipStream_t st, int P, uint32_t L, const float2* means2D,
+			   const uint32_t* offsets, const int* radii, const uint32_t* perm, int gx,
+			   int gy, uint32_t* keys32, uint32_t* vals)
+{
+	if (L == 0) return;
+	hipLaunchKernelGGL(emit_tile_keys_kernel, dim3((L + IPB - 1) / IPB), dim3(256), 0, st, P, L,
+			   means2D, offsets, radii, perm, gx, gy, keys32, vals);
+}
+
+size_t sort32_temp_bytes(size_t L, int end_bit)
+{
+	size_t bytes = 0;
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+					(uint32_t*)nullptr, (uint32_t*)nullptr, L, 0u, (unsigned)end_bit,
+					(hipStream_t)0);
+	return bytes;
+}
+
+hipError_t launch_sort32_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint32_t* keys_in,
+			       uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,
+			       int end_bit)
+{
+	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, L, 0u,
+					 (unsigned)end_bit, st);
+}
+
+__global__ __launch_bounds__(256) void tile_ranges32_kernel(uint32_t L,
+							     const uint32_t* __restrict__ tiles,
+							     uint2* __restrict__ ranges)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= L) return;
+	const uint32_t cur = tiles[i];
+	if (i == 0) ranges[cur].x = 0;
+	else {
+		const uint32_t prev = tiles[i - 1];
+		if (cur != prev) {
+			ranges[prev].y = i;
+			ranges[cur].x = i;
+		}
+	}
+	if (i == L - 1) ranges[cur].y = L;
+}
+
+void launch_tile_ranges32(hipStream_t st, size_t L, const uint32_t* tiles, uint2* ranges, int ntiles)
+{
+	(void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st);
+	if (L == 0) return;
+	hipLaunchKernelGGL(tile_ranges32_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st,
+			   (uint32_t)L, tiles, ranges);
+}
+
+// keys_sorted[i] = tile << 32 | depth bits of point_list[i]: the reference's sorted 64-bit keys,
+// materialised on demand (parity tests); nothing on the render path reads them.
+__global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t L,
+								const uint32_t* __restrict__ tiles,
+								const uint32_t* __restrict__ point_list,
+								const float* __restrict__ depths,
+								uint64_t* __restrict__ keys_sorted)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= L) return;
+	keys_sorted[i] = ((uint64_t)tiles[i] << 32) | (uint64_t)__float_as_uint(depths[point_list[i]]);
+}
+
+void launch_reconstruct_keys(hipStream_t st, size_t L, const uint32_t* tiles,
+			     const uint32_t* point_list, const float* depths, uint64_t* keys_sorted)
+{
+	if (L == 0) return;
+	hipLaunchKernelGGL(reconstruct_keys_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st,
+			   (uint32_t)L, tiles, point_list, depths, keys_sorted);
+}
+
 } // namespace sgs

@@ -107,7 +107,11 @@ BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int n
 	b.pub.vals_unsorted = c.take(L * 4);
 	b.pub.keys_sorted = c.take(L * 8);
 	b.pub.point_list = c.take(L * 4);
-	b.sort_temp_bytes = L ? sgs::sort_temp_bytes(L, 0, sort_bits) : 0;   // upper bound for both modes
+	b.sort_temp_bytes = 0;
+	if (L) {   // room for either mode's radix sort
+		const size_t t64 = sgs::sort_temp_bytes(L, 0, sort_bits), t32 = sgs::sort32_temp_bytes(L, sort_bits - 32);
+		b.sort_temp_bytes = t64 > t32 ? t64 : t32;
+	}
 	b.sort_temp = c.take(b.sort_temp_bytes);
 	b.arena = 0;
 	if (arena_capacity) {
@@ -395,21 +399,42 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	uint64_t* keys_s = (uint64_t*)(bchunk + bl.pub.keys_sorted);
 	uint32_t* point_list = (uint32_t*)(bchunk + bl.pub.point_list);
 
-	sgs::launch_duplicate_with_keys(st, P, means2D, depths, point_offsets, radii, gx, gy, keys_u,
-					vals_u, L, perm);
-	SGS_CHECK_STAGE("duplicateWithKeys");
-	tm.mark();
-	if (L > 0) {
-		e = sgs::launch_sort_pairs(st, bchunk + bl.sort_temp, bl.sort_temp_bytes, keys_u, keys_s,
-					   vals_u, point_list, L, presort ? 32 : 0, sort_bits);
-		if (e != hipSuccess) return fail_hip(e, "radix sort");
-	}
-	SGS_CHECK_STAGE("radix sort");
-	tm.mark();
 	uint2* ranges = (uint2*)(ichunk + il.ranges);
-	sgs::launch_tile_ranges(st, L, keys_s, ranges, ntiles);
-	SGS_CHECK_STAGE("identifyTileRanges");
-	tm.mark();
+	if (presort) {
+		// mode 0: 32-bit tile keys (depth order is already in the emission order).  The
+		// 8-B-per-instance "keys_unsorted" area holds the unsorted and the sorted tile ids.
+		uint32_t* tiles_u = (uint32_t*)keys_u;
+		uint32_t* tiles_s = tiles_u + L;
+		sgs::launch_emit_tile_keys(st, P, L, means2D, point_offsets, radii, perm, gx, gy, tiles_u,
+					   vals_u);
+		SGS_CHECK_STAGE("emit tile keys");
+		tm.mark();
+		if (L > 0) {
+			e = sgs::launch_sort32_pairs(st, bchunk + bl.sort_temp, bl.sort_temp_bytes, tiles_u,
+						     tiles_s, vals_u, point_list, L, sort_bits - 32);
+			if (e != hipSuccess) return fail_hip(e, "radix sort");
+		}
+		SGS_CHECK_STAGE("radix sort");
+		tm.mark();
+		sgs::launch_tile_ranges32(st, L, tiles_s, ranges, ntiles);
+		SGS_CHECK_STAGE("identifyTileRanges");
+		tm.mark();
+	} else {
+		sgs::launch_duplicate_with_keys(st, P, means2D, depths, point_offsets, radii, gx, gy, keys_u,
+						vals_u, L, nullptr);
+		SGS_CHECK_STAGE("duplicateWithKeys");
+		tm.mark();
+		if (L > 0) {
+			e = sgs::launch_sort_pairs(st, bchunk + bl.sort_temp, bl.sort_temp_bytes, keys_u, keys_s,
+						   vals_u, point_list, L, 0, sort_bits);
+			if (e != hipSuccess) return fail_hip(e, "radix sort");
+		}
+		SGS_CHECK_STAGE("radix sort");
+		tm.mark();
+		sgs::launch_tile_ranges(st, L, keys_s, ranges, ntiles);
+		SGS_CHECK_STAGE("identifyTileRanges");
+		tm.mark();
+	}
 
 	sgs::BlendFwdArgs a;
 	a.ranges = ranges;
@@ -542,6 +567,26 @@ int sgs_knn_mean_dist2(int P, const float* points, float* meanDists, sgs_alloc_f
 	if (!s) return fail(SGS_EALLOC, "scratch allocation failed");
 	hipError_t e = sgs::launch_knn((hipStream_t)stream, P, points, meanDists, align_ptr(s), bytes);
 	if (e != hipSuccess) return fail_hip(e, "knn");
+	return 0;
+}
+
+int sgs_debug_sorted_keys(int P, int num_rendered, const char* geom_buffer, char* binning_buffer,
+			  void* stream)
+{
+	if (P < 0 || num_rendered < 0) return fail(SGS_EINVAL, "bad sizes");
+	if (num_rendered == 0) return 0;
+	if (!geom_buffer || !binning_buffer) return fail(SGS_EINVAL, "null state buffer");
+	const GeomLayout gl = geom_layout(P);
+	const BinLayout bl = bin_layout((size_t)num_rendered, 64);
+	const char* gchunk = align_ptr(const_cast<char*>(geom_buffer));
+	char* bchunk = align_ptr(binning_buffer);
+	const uint32_t* tiles_s = (const uint32_t*)(bchunk + bl.pub.keys_unsorted) + num_rendered;
+	sgs::launch_reconstruct_keys((hipStream_t)stream, (size_t)num_rendered, tiles_s,
+				     (const uint32_t*)(bchunk + bl.pub.point_list),
+				     (const float*)(gchunk + gl.pub.depths),
+				     (uint64_t*)(bchunk + bl.pub.keys_sorted));
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail_hip(e, "reconstruct keys");
 	return 0;
 }
 

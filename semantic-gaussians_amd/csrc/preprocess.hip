@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 	if (i >= P) return;
 	radii[i] = 0;
 	tiles_touched[i] = 0;
+	// depth doubles as the presort key (binning mode 0): culled Gaussians sort last
+	depths[i] = __uint_as_float(0xFFFFFFFFu);
 
 	const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1],
 		    pz = means3D[3 * (size_t)i + 2];

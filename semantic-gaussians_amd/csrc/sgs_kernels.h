@@ -31,6 +31,16 @@ hipError_t launch_gaussian_depth_sort(hipStream_t st, void* temp, size_t temp_by
 				      int P);
 void launch_gather_counts(hipStream_t st, int P, const uint32_t* perm, const uint32_t* tiles_touched,
 			  uint32_t* counts_sorted);
+void launch_emit_tile_keys(hipStream_t st, int P, uint32_t L, const float2* means2D,
+			   const uint32_t* offsets, const int* radii, const uint32_t* perm, int gx,
+			   int gy, uint32_t* keys32, uint32_t* vals);
+size_t sort32_temp_bytes(size_t L, int end_bit);
+hipError_t launch_sort32_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint32_t* keys_in,
+			       uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,
+			       int end_bit);
+void launch_tile_ranges32(hipStream_t st, size_t L, const uint32_t* tiles, uint2* ranges, int ntiles);
+void launch_reconstruct_keys(hipStream_t st, size_t L, const uint32_t* tiles,
+			     const uint32_t* point_list, const float* depths, uint64_t* keys_sorted);
 size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit);
 hipError_t launch_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint64_t* keys_in,
 			     uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,

@@ -36,7 +36,7 @@ class ImageLayout(C.Structure):
 EXPORTS = (
     "sgs_abi_version", "sgs_last_error", "sgs_rasterize_forward", "sgs_rasterize_backward",
     "sgs_mark_visible", "sgs_knn_mean_dist2", "sgs_geometry_layout_of", "sgs_binning_layout_of",
-    "sgs_image_layout_of", "sgs_sort_bits", "sgs_debug_expf", "sgs_set_blend_variant",
+    "sgs_image_layout_of", "sgs_sort_bits", "sgs_debug_expf", "sgs_debug_sorted_keys", "sgs_set_blend_variant",
     "sgs_set_stage_timing", "sgs_get_stage_ms", "sgs_set_binning_mode",
 )
 
@@ -90,6 +90,8 @@ def load():
     lib.sgs_image_layout_of.argtypes = [i, i, C.POINTER(ImageLayout)]
     lib.sgs_sort_bits.restype = i
     lib.sgs_sort_bits.argtypes = [i, i]
+    lib.sgs_debug_sorted_keys.restype = i
+    lib.sgs_debug_sorted_keys.argtypes = [i, i, p, p, p]
     lib.sgs_debug_expf.restype = i
     lib.sgs_debug_expf.argtypes = [i, p, p, p]
     lib.sgs_set_blend_variant.restype = i

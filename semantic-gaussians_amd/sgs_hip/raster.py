@@ -246,7 +246,14 @@ def geometry_views(geomBuffer, P):
         point_offsets=v(lay.point_offsets, 4 * P, torch.int32, (P,)))
 
 
-def binning_views(binningBuffer, L):
+def binning_views(binningBuffer, L, geomBuffer=None, P=None):
+    """Typed views into the opaque binning buffer.  In binning mode 0 the sorted 64-bit keys are
+    only materialised here (pass geomBuffer and P); unsorted 64-bit keys exist only in mode 1."""
+    if geomBuffer is not None and L > 0:
+        with torch.cuda.device(binningBuffer.device):
+            _lib.check(_lib.load().sgs_debug_sorted_keys(int(P), int(L), geomBuffer.data_ptr(),
+                                                         binningBuffer.data_ptr(),
+                                                         _stream_ptr(binningBuffer.device)), "keys")
     lay = _lib.BinningLayout()
     _lib.check(_lib.load().sgs_binning_layout_of(int(L), C.byref(lay)), "layout")
     base = _aligned(binningBuffer)

@@ -57,14 +57,12 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0,
     assert np.array_equal(g["depths"][vis].view(np.uint32), fw["depths"][vis].view(np.uint32))
     assert np.array_equal(g["means2D"][vis].view(np.uint32), fw["means2D"][vis].view(np.uint32))
     assert np.array_equal(g["conic_opacity"][vis].view(np.uint32), fw["conic_opacity"][vis].view(np.uint32))
-    b = {k: v.cpu().numpy() for k, v in raster.binning_views(binn, n).items()}
-    if binning_mode == 1:   # only the reference order of operations emits in index order
+    if binning_mode == 1:   # the reference order of operations: 64-bit keys emitted in index order
+        b = {k: v.cpu().numpy() for k, v in raster.binning_views(binn, n).items()}
         assert np.array_equal(b["keys_unsorted"].view(np.uint64), fw["keys_unsorted"])
         assert np.array_equal(b["vals_unsorted"].view(np.uint32), fw["vals_unsorted"])
-    else:                   # same multiset of (key, value) pairs, emitted in depth order
-        ku, vu = b["keys_unsorted"].view(np.uint64), b["vals_unsorted"].view(np.uint32)
-        o1, o2 = np.lexsort((vu, ku)), np.lexsort((fw["vals_unsorted"], fw["keys_unsorted"]))
-        assert np.array_equal(ku[o1], fw["keys_unsorted"][o2]) and np.array_equal(vu[o1], fw["vals_unsorted"][o2])
+    else:                   # mode 0 sorts 32-bit tile ids; the 64-bit sorted keys are rebuilt on demand
+        b = {k: v.cpu().numpy() for k, v in raster.binning_views(binn, n, geom, P).items()}
     assert np.array_equal(b["keys_sorted"].view(np.uint64), fw["keys_sorted"])
     assert np.array_equal(b["point_list"].view(np.uint32), fw["point_list"])
     im = {k: v.cpu().numpy() for k, v in raster.image_views(img, W, H).items()}
