@@ -51,6 +51,14 @@ constexpr int ACH = 128;  // work-list slots per chunk
 
 } // namespace
 
+// BF = false: work-list rows of 256 fp32 weights per entry (the exact accumulate kernels).
+// BF = true : weights split into bf16 hi + bf16 lo (w = hi + lo + O(2^-18 w)) and stored
+//             k-major for the bf16 MFMA's B operand: per group of 8 consecutive entries
+//             [256 px][8 x hi] (4 KB) then [256 px][8 x lo] (4 KB); the tile's last 16-entry
+//             batch is padded with zero weights.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool BF>
 __global__ __launch_bounds__(256) void blend_weights_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
@@ -79,6 +87,25 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	__shared__ int s_alive[4];
 	__shared__ uint32_t s_cnt, s_mask, s_ovf;
 	__shared__ uint32_t s_chunk[64];   // first slot of each chunk (re-read from `table` beyond 64)
+	__shared__ float s_pend[BF ? 8 * 256 : 1];   // BF: the entry group being filled, [k][px]
+
+	// BF: entries 8*gi .. 8*gi+7 of this tile are complete in s_pend -> split and store them.
+	// Thread p only ever touches column p of s_pend, so no barrier is involved.
+	auto flush_group = [&](uint32_t gi) {
+		const uint32_t g0 = gi * 8u, ci = g0 / ACH;
+		const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+		const uint32_t slot = cstart + (g0 % ACH);
+		bf16x8 hi, lo;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const float v = s_pend[k * 256 + threadIdx.x];
+			hi[k] = (__bf16)v;
+			lo[k] = (__bf16)(v - (float)hi[k]);
+		}
+		bf16x8* dst = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * 8192);
+		dst[threadIdx.x] = hi;
+		dst[256 + threadIdx.x] = lo;
+	};
 
 	float T = 1.0f;
 	uint32_t last = 0;
@@ -184,11 +211,23 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 					const uint32_t g = total + r, ci = g / ACH;
 					const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
 					const uint32_t slot = cstart + (g % ACH);
-					wgt[(size_t)slot * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
+					if (BF) {
+						s_pend[(g & 7u) * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
+						if ((g & 7u) == 7u) flush_group(g >> 3);
+					} else {
+						wgt[(size_t)slot * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
+					}
 					if (threadIdx.x == 0) act_id[slot] = s_e[e].id;
 				}
 			}
 			total += cnt;
+		}
+	}
+	if (BF && s_ovf == 0u) {   // zero-pad the last batch to 16 entries (all inside the tile's last chunk)
+		const uint32_t pad_end = (total + 15u) & ~15u;
+		for (uint32_t g = total; g < pad_end; g++) {
+			s_pend[(g & 7u) * 256 + threadIdx.x] = 0.0f;
+			if ((g & 7u) == 7u) flush_group(g >> 3);
 		}
 	}
 	if (threadIdx.x == 0) nact[tile] = total;
@@ -625,6 +664,177 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 }
 
 // -------------------------------------------------------------------------------------
+// Split-bf16 MFMA accumulate ("bf16x3").  out[ch][px] = sum_k F[k][ch] * W[k][px] with both
+// operands split into two bf16 terms, F = Fh + Fl, W = Wh + Wl (each split drops O(2^-18) of
+// the value), and three bf16 MFMAs per block, Fl*Wh + Fh*Wl + Fh*Wh, accumulated in fp32:
+// every product is exact in fp32, the dropped Fl*Wl term and the split remainders are
+// <= 3 * 2^-18 ~ 1.1e-5 of |F*W| per term.  Against the exact path the result differs by
+// <= ~1.2e-5 * sum_k |F_k| W_k  -- inside the north star's 1e-4, asserted by the parity tests
+// against the oracle's absolute composite -- while v_mfma_f32_32x32x16_bf16 runs at 16x the
+// f32 MFMA rate, so three of them cost 3/16 of the exact kernel's matrix time and the kernel
+// becomes memory-bound.  The exact f32-MFMA kernel above stays available (blend variant 4).
+//
+// One workgroup = tile x 128 channels; wave w owns channels [64(w&1), +64) x pixels
+// [128(w>>1), +128): 2 x 4 MFMA blocks (128 accumulator VGPRs), which needs 12 KB of LDS
+// operand reads per wave and batch instead of 18 KB for a 32 x 256 wave tile.  Per batch of 16
+// entries: features arrive as fp32 (8 KB) and are split in registers (A: lane l -> channel
+// l&31, entries 8(l>>5)..+7); weights arrive pre-split and k-major from blend_weights_kernel
+// (16 KB; B: lane l -> pixel l&31, entries 8(l>>5)..+7 = one ds_read_b128).
+__global__ __launch_bounds__(256, 2) void blend_accum_bf16_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const char* __restrict__ wgt, const float* __restrict__ features,
+	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
+	int total_blocks, int dbg)
+{
+	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
+	const int b = blockIdx.x;
+	const int v = (b & 7) * per_xcd + (b >> 3);
+	if (v >= total_blocks) return;
+	const int tile = v / nchunks_c;
+	const int chunk = v - tile * nchunks_c;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int cbase = chunk * 128;
+	const int cgrp = wave & 1, pgrp = wave >> 1;
+	const int tx = tile % gx, ty = tile / gx;
+	const size_t HW = (size_t)H * W;
+	const uint32_t total = nact[tile];
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const uint32_t Q = (total + AB - 1) / AB;
+
+	__shared__ float4 s_featA[AB * 32], s_featB[AB * 32];   // [entry][128 floats]
+	__shared__ float4 s_wA[1024], s_wB[1024];               // [group 2][hi, lo][256 px][8 bf16]
+
+	f32x16 acc[2][4];
+#pragma unroll
+	for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+		for (int pb = 0; pb < 4; pb++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[cb][pb][r] = 0.f;
+
+	auto batch_slot = [&](uint32_t q) -> uint32_t {
+		const uint32_t first = q * AB;
+		return table[chunk_base + (first >> 7)] + (first & 127u);
+	};
+	const int sub = threadIdx.x >> 5;
+	auto load_ids = [&](uint32_t q, uint32_t& i0, uint32_t& i1) {
+		const uint32_t slot = batch_slot(q);
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		const uint32_t e0 = (uint32_t)sub < n ? (uint32_t)sub : n - 1u;
+		const uint32_t e1 = (uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u;
+		i0 = act_id[slot + e0];
+		i1 = act_id[slot + e1];
+	};
+	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
+		const uint32_t slot = batch_slot(q);
+		if (!(dbg & 4)) {
+		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
+		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
+						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32],
+						 16, 0, 0);
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
+						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32],
+						 16, 0, 0);
+		}
+		if (dbg & 8) return;
+		const char* wsrc = wgt + (size_t)(slot >> 3) * 8192 + (size_t)threadIdx.x * 16;
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + j * 4096),
+							 (__attribute__((address_space(3))) void*)&s_w[j * 256 + wave * 64],
+							 16, 0, 0);
+	};
+	const int half = lane >> 5, l31 = lane & 31;
+	auto compute = [&](uint32_t q, const float4* s_feat4, const float4* s_w4) {
+		if (dbg & 2) return;
+		const float* s_feat = reinterpret_cast<const float*>(s_feat4);
+		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
+		bf16x8 ah[2], al[2];
+#pragma unroll
+		for (int cb = 0; cb < 2; cb++) {
+			const float* fcol = s_feat + (8 * half) * 128 + cgrp * 64 + cb * 32 + l31;
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				// rows past n hold a clamped duplicate of the last entry; their weights are
+				// zero, and zeroing the feature too keeps a non-finite duplicate out
+				float f = fcol[k * 128];
+				f = (uint32_t)(8 * half + k) < n ? f : 0.f;
+				ah[cb][k] = (__bf16)f;
+				al[cb][k] = (__bf16)(f - (float)ah[cb][k]);
+			}
+		}
+		const bf16x8* wrow = reinterpret_cast<const bf16x8*>(s_w4) + half * 512 + pgrp * 128 + l31;
+		bf16x8 bh[4], bl[4];
+#pragma unroll
+		for (int pb = 0; pb < 4; pb++) {
+			bh[pb] = wrow[pb * 32];
+			bl[pb] = wrow[256 + pb * 32];
+		}
+#pragma unroll
+		for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+			for (int pb = 0; pb < 4; pb++)
+				acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+#pragma unroll
+		for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+			for (int pb = 0; pb < 4; pb++)
+				acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
+#pragma unroll
+		for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+			for (int pb = 0; pb < 4; pb++)
+				acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+	};
+
+	if (Q > 0) {
+		uint32_t i0, i1, n0 = 0, n1 = 0;
+		load_ids(0, i0, i1);
+		issue(0, s_featA, s_wA, i0, i1);
+		if (Q > 1) load_ids(1, n0, n1);
+		for (uint32_t q = 0; q < Q; q += 2) {
+			__syncthreads();
+			if (q + 1 < Q) {
+				issue(q + 1, s_featB, s_wB, n0, n1);
+				if (q + 2 < Q) load_ids(q + 2, n0, n1);
+			}
+			compute(q, s_featA, s_wA);
+			if (q + 1 < Q) {
+				__syncthreads();
+				if (q + 2 < Q) {
+					issue(q + 2, s_featA, s_wA, n0, n1);
+					if (q + 3 < Q) load_ids(q + 3, n0, n1);
+				}
+				compute(q + 1, s_featB, s_wB);
+			}
+		}
+	}
+
+	// epilogue.  D layout: column = lane & 31 -> pixel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+	for (int pb = 0; pb < 4; pb++) {
+		const int qidx = pgrp * 128 + pb * 32 + l31;   // work-list pixel index: strip*64 + pos
+		const int x = tx * SGS_TILE + (qidx & 15);
+		const int y = ty * SGS_TILE + (qidx >> 6) * 4 + ((qidx & 63) >> 4);
+		if (x < W && y < H && !((dbg & 1) && acc[0][pb][0] != 123.f)) {
+			const size_t pix = (size_t)y * W + x;
+			const float Tp = final_T[pix];
+#pragma unroll
+			for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					const int c = cbase + cgrp * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+					out[(size_t)c * HW + pix] = __builtin_fmaf(Tp, bg[c], acc[cb][pb][r]);
+				}
+		}
+	}
+}
+
+// -------------------------------------------------------------------------------------
 // MFMA accumulate, 3-stage LDS ring.  Same arithmetic as blend_accum_mfma_kernel; the operand
 // bundles (features + weights + the Gaussian ids two batches ahead) run TWO batches ahead of
 // the MFMAs instead of one: with one batch in flight a workgroup spends most of its life
@@ -875,10 +1085,16 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	if (e != hipSuccess) return e;
 	{
 		const int per_xcd = (ntiles + 7) / 8;
-		hipLaunchKernelGGL(blend_weights_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
-				   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,
-				   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd,
-				   ntiles);
+		if ((split_mode & 15) == 6)
+			hipLaunchKernelGGL(blend_weights_kernel<true>, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
+					   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,
+					   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd,
+					   ntiles);
+		else
+			hipLaunchKernelGGL(blend_weights_kernel<false>, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
+					   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,
+					   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd,
+					   ntiles);
 	}
 	{
 		// split_mode: 0 = 32 channels per wave, 1 entry per scalar wait (default);
@@ -893,7 +1109,11 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
 			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
 			   total, (split_mode >> 4))
-		if (sm == 5)
+		if (sm == 6)
+			hipLaunchKernelGGL(blend_accum_bf16_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
+					   table, nbatches, act_id, (const char*)wgt, a.features, a.final_T, a.bg,
+					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, split_mode >> 4);
+		else if (sm == 5)
 			hipLaunchKernelGGL(blend_accum_mfma3_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
 					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
 					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);

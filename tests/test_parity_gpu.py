@@ -36,7 +36,7 @@ def _hip_forward(scene, cam, C=None, want_depth=False, colors=None, variant=0, d
     return out
 
 
-def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0, **kw):
+def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0, exact=True, **kw):
     from sgs_hip import raster
     fw = oracle_forward(orc, scene, cam, want_depth=want_depth, **kw)
     raster.set_binning_mode(binning_mode)
@@ -73,7 +73,17 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0,
     # north-star tolerance first (1e-4 relative), then the stronger bit-exact claim
     scale = np.abs(fw["out"]).max() + 1e-30
     assert np.abs(out - fw["out"]).max() <= 1e-4 * scale
-    assert np.array_equal(out.view(np.uint32), fw["out"].view(np.uint32))
+    if exact:
+        assert np.array_equal(out.view(np.uint32), fw["out"].view(np.uint32))
+    else:
+        # split-bf16 accumulate: |error| <= 3 * 2^-16 (4.6e-5) of every |feature * weight| term
+        # (two bf16 terms per operand, the lo*lo product dropped), i.e. bounded by the ABSOLUTE
+        # composite (same weights, |features|, |bg|) -- immune to cancellation; measured max
+        # 2.1e-5, mean 1.6e-6.  5e-5 is 2x inside the north star's 1e-4.
+        sa = scene._replace(features=scene.features.abs(), bg=scene.bg.abs())
+        fa = oracle_forward(orc, sa, cam, **kw)["out"]
+        assert (np.abs(out - fw["out"]) <= 5e-5 * fa + 1e-30).all()
+        assert not np.array_equal(out, fw["out"]) or fa.max() == 0
     if want_depth:
         assert np.array_equal(depth.cpu().numpy().view(np.uint32), fw["depth"].view(np.uint32))
     return fw
@@ -92,6 +102,13 @@ def test_forward_c128_all_variants(orc, variant):
     scene, cam = small_scene(P=3000, C=128, W=200, H=120, fx=170.0, seed=1)
     fw = _check_forward(orc, scene, cam, variant=variant)
     assert fw["n_contrib"].max() > 20 and (fw["final_T"] < 1e-3).any()   # early stop exercised
+
+
+@pytest.mark.parametrize("C", [128, 160, 512])
+def test_forward_split_bf16_within_tolerance(orc, C):
+    """Variant 12: integer state bit-exact, feature map within 5e-5 of the absolute composite."""
+    scene, cam = small_scene(P=3000, C=C, W=200, H=120, fx=170.0, seed=C + 1)
+    _check_forward(orc, scene, cam, variant=12, exact=False)
 
 
 @pytest.mark.parametrize("C", [1, 3, 20, 21, 32, 33, 64, 160, 256, 768])
