@@ -28,6 +28,7 @@
 // single-kernel path (launched right after it) take over, so no host round trip is needed;
 // the host grows the arena for the next frame.
 #include "sgs_kernels.h"
+#include <type_traits>
 
 #ifndef SGS_ACC_PREFETCH
 #define SGS_ACC_PREFETCH 1
@@ -48,17 +49,23 @@ struct StagedEntryW {   // 32 B per list entry in LDS
 
 constexpr int WB = 32;    // list entries per batch
 constexpr int ACH = 128;  // work-list slots per chunk
+constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the T * bg pseudo entry (weights MODE 2)
 
 } // namespace
 
-// BF = false: work-list rows of 256 fp32 weights per entry (the exact accumulate kernels).
-// BF = true : weights split into bf16 hi + bf16 lo (w = hi + lo + O(2^-18 w)) and stored
+// MODE 0: work-list rows of 256 fp32 weights per entry (the exact accumulate kernels).
+// MODE 2: as MODE 1, plus one closing pseudo entry per tile whose "weights" are the pixels'
+//         final transmittance and whose id is SGS_BG_ID: the accumulate kernel feeds the
+//         background vector as its feature row, so  + T * bg  falls out of the matrix product.
+// MODE 1: weights split into bf16 hi + bf16 lo (w = hi + lo + O(2^-18 w)) and stored
 //             k-major for the bf16 MFMA's B operand: per group of 8 consecutive entries
 //             [256 px][8 x hi] (4 KB) then [256 px][8 x lo] (4 KB); the tile's last 16-entry
-//             batch is padded with zero weights.
+//             batch is padded with zero weights.  Pixels are in row-parity-major order,
+//             px' = (y & 1) * 128 + (y >> 1) * 16 + x, so that the rows of one parity are a
+//             contiguous 2-KB half (blend_accum_pair_kernel reads only one of them).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <bool BF>
+template <int MODE>
 __global__ __launch_bounds__(256) void blend_weights_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
@@ -68,6 +75,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	int H, int gx, int per_xcd, int ntiles)
 {
 	const int b = blockIdx.x;
+	constexpr bool BF = MODE != 0;
 	const int tile = (b & 7) * per_xcd + (b >> 3);
 	if (tile >= ntiles) return;
 	const int tx = tile % gx, ty = tile / gx;
@@ -103,8 +111,10 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			lo[k] = (__bf16)(v - (float)hi[k]);
 		}
 		bf16x8* dst = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * 8192);
-		dst[threadIdx.x] = hi;
-		dst[256 + threadIdx.x] = lo;
+		const int yl = wave * 4 + (lane >> 4);
+		const int pxp = (yl & 1) * 128 + (yl >> 1) * 16 + (lane & 15);
+		dst[pxp] = hi;
+		dst[256 + pxp] = lo;
 	};
 
 	float T = 1.0f;
@@ -222,6 +232,29 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			}
 			total += cnt;
 		}
+	}
+	if (MODE == 2) {   // the closing T * bg pseudo entry (every tile gets one, also an empty tile)
+		__syncthreads();
+		if (threadIdx.x == 0 && nchunks * ACH < total + 1u && s_ovf == 0u) {
+			const uint32_t start = atomicAdd(&counter[0], (uint32_t)ACH);
+			if (start + ACH > capacity) {
+				atomicExch(&counter[1], 1u);
+				s_ovf = 1u;
+			} else {
+				table[chunk_base + nchunks] = start;
+				if (nchunks < 64) s_chunk[nchunks] = start;
+				nchunks++;
+			}
+		}
+		__syncthreads();
+		if (s_ovf == 0u) {
+			const uint32_t g = total, ci = g / ACH;
+			const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+			s_pend[(g & 7u) * 256 + threadIdx.x] = inside ? T : 0.0f;
+			if (threadIdx.x == 0) act_id[cstart + (g % ACH)] = SGS_BG_ID;
+			if ((g & 7u) == 7u) flush_group(g >> 3);
+		}
+		total += 1u;
 	}
 	if (BF && s_ovf == 0u) {   // zero-pad the last batch to 16 entries (all inside the tile's last chunk)
 		const uint32_t pad_end = (total + 15u) & ~15u;
@@ -817,9 +850,9 @@ __global__ __launch_bounds__(256, 2) void blend_accum_bf16_kernel(
 	// epilogue.  D layout: column = lane & 31 -> pixel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
 	for (int pb = 0; pb < 4; pb++) {
-		const int qidx = pgrp * 128 + pb * 32 + l31;   // work-list pixel index: strip*64 + pos
+		const int qidx = pgrp * 128 + pb * 32 + l31;   // parity-major pixel index
 		const int x = tx * SGS_TILE + (qidx & 15);
-		const int y = ty * SGS_TILE + (qidx >> 6) * 4 + ((qidx & 63) >> 4);
+		const int y = ty * SGS_TILE + 2 * ((qidx >> 4) & 7) + (qidx >> 7);
 		if (x < W && y < H && !((dbg & 1) && acc[0][pb][0] != 123.f)) {
 			const size_t pix = (size_t)y * W + x;
 			const float Tp = final_T[pix];
@@ -832,6 +865,561 @@ __global__ __launch_bounds__(256, 2) void blend_accum_bf16_kernel(
 				}
 		}
 	}
+}
+
+// -------------------------------------------------------------------------------------
+// Split-bf16 accumulate over TILE PAIRS with full-line stores (the default).
+//
+// tools/ubench_store.hip (profiles/r01_ubench_store.txt): writing the (C,H,W) image in the
+// 64-B pieces a single 16-px-wide tile owns runs at 3.5 TB/s, the same bytes as complete,
+// aligned 128-B lines at 4.8-5.2 TB/s -- and with the matrix work on the bf16 pipe the
+// epilogue store is the largest part of the kernel.  A 128-B line of channel c, row y covers
+// 32 pixels = two horizontally adjacent tiles; with a pitch of W*4 bytes (W % 16 == 0) the
+// lines start at x = 0 mod 32 on rows whose y*W is a multiple of 32 and at x = 16 mod 32 on
+// the others (W % 32 == 16: odd rows).  So a workgroup owns, for 128 channels and the rows of
+// one parity p, the pixels of one line column: tiles A = 2k - p*stagger and B = A + 1.  It runs
+// tile A's work list and then tile B's through the same pipeline into two accumulator sets,
+// and the epilogue exchanges 16-lane rows between them (v_permlane16_swap_b32) so that every
+// store instruction writes two complete lines.
+//
+// Wave tile: 64 channels x (64 px of A + 64 px of B): 2 x 2 x 2 MFMA blocks, 128 accumulator
+// VGPRs.  Batch = 32 entries (two k-steps of the 32x32x16 MFMA), two LDS stages of
+// 16 KB fp32 features + 16 KB pre-split weights (only the parity's half of each tile's
+// pixels is fetched).  The Gaussian ids and chunk starts of both tiles are loaded into LDS
+// once, so the per-batch critical path is a single DMA round trip.
+constexpr int PB = 32;      // entries per batch
+constexpr int IDW = 512;    // ids kept in LDS per tile (refilled for longer lists)
+constexpr int NTAB = 32;    // chunk starts kept in LDS per tile
+
+__global__ __launch_bounds__(256, 2) void blend_accum_pair_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const char* __restrict__ wgt, const float* __restrict__ features,
+	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int nk,
+	int stagger, int per_xcd, int total_items, int dbg)
+{
+	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
+	const int b = blockIdx.x;
+	const int v = (b & 7) * per_xcd + (b >> 3);
+	if (v >= total_items) return;
+	const int chunk = v % nchunks_c;
+	int rest = v / nchunks_c;
+	const int par = rest & 1;
+	rest >>= 1;
+	const int k = rest % nk, ty = rest / nk;
+	const int txA = 2 * k - par * stagger, txB = txA + 1;
+	const bool validA = txA >= 0 && txA < gx, validB = txB < gx;
+	if (!validA && !validB) return;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int cbase = chunk * 128;
+	const int cgrp = wave & 1, ph = wave >> 1;
+	const size_t HW = (size_t)H * W;
+	const int tileA = ty * gx + txA, tileB = tileA + 1;
+	const uint32_t totA = validA ? nact[tileA] : 0u, totB = validB ? nact[tileB] : 0u;
+	const uint32_t cbA = validA ? (ranges[tileA].x >> 7) + (uint32_t)tileA : 0u;
+	const uint32_t cbB = validB ? (ranges[tileB].x >> 7) + (uint32_t)tileB : 0u;
+	const uint32_t QA = (totA + PB - 1) / PB, QB = (totB + PB - 1) / PB, QT = QA + QB;
+
+	__shared__ float4 s_f0[PB * 32], s_f1[PB * 32];   // [entry][128 floats]
+	__shared__ float4 s_w0[1024], s_w1[1024];         // [k-group 4][hi, lo][128 px][8 bf16]
+	__shared__ uint32_t s_ids[2][IDW];
+	__shared__ uint32_t s_tab[2][NTAB];
+
+	f32x16 acc[2][2][2];   // [tile][channel block][pixel block]
+#pragma unroll
+	for (int t = 0; t < 2; t++)
+#pragma unroll
+		for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+			for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) acc[t][cb][pb][r] = 0.f;
+
+	// ---- chunk starts, then ids, of both tiles into LDS
+	if (threadIdx.x < 2 * NTAB) {
+		const int t = threadIdx.x / NTAB, i = threadIdx.x % NTAB;
+		const uint32_t tot = t ? totB : totA;
+		if ((uint32_t)i * ACH < tot) s_tab[t][i] = table[(t ? cbB : cbA) + i];
+	}
+	__syncthreads();
+	auto chunk_start = [&](int t, uint32_t ci) __attribute__((always_inline)) -> uint32_t {
+		return ci < (uint32_t)NTAB ? s_tab[t][ci] : table[(t ? cbB : cbA) + ci];
+	};
+	auto fill_ids = [&](int t, uint32_t first) __attribute__((always_inline)) {   // entries [first, first + IDW) of tile t
+		const uint32_t tot = t ? totB : totA;
+		for (uint32_t e = first + threadIdx.x; e < first + IDW && e < tot; e += 256)
+			s_ids[t][e - first] = act_id[chunk_start(t, e >> 7) + (e & 127u)];
+	};
+	fill_ids(0, 0);
+	fill_ids(1, 0);
+	__syncthreads();
+
+	// flattened batch j: tile A's batches, then tile B's
+	auto issue = [&](uint32_t j, float4* s_feat, float4* s_w) __attribute__((always_inline)) {
+		const int t = j >= QA ? 1 : 0;
+		const uint32_t q = t ? j - QA : j;
+		const uint32_t tot = t ? totB : totA;
+		const uint32_t first = q * PB;
+		if (first > 0 && (first % IDW) == 0) {   // (uniform) slide the id window
+			__syncthreads();
+			fill_ids(t, first);
+			__syncthreads();
+		}
+		const uint32_t n = (tot - first) < (uint32_t)PB ? (tot - first) : (uint32_t)PB;
+		const uint32_t slot = chunk_start(t, first >> 7) + (first & 127u);
+		const int ninstr = n > 16 ? 4 : 2;
+		if (!(dbg & 4)) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			if (i < ninstr) {
+				uint32_t e = (uint32_t)(8 * i + 2 * wave + (lane >> 5));
+				e = e < n ? e : n - 1u;
+				const uint32_t id = s_ids[t][(first % IDW) + e];
+				const float* src = features + (size_t)id * C + cbase + (lane & 31) * 4;
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+								 (__attribute__((address_space(3))) void*)&s_feat[(8 * i + 2 * wave) * 32],
+								 16, 0, 0);
+			}
+		}
+		}
+		if (dbg & 8) return;
+		// weights: k-group `wave` (8 entries), hi and lo halves of this parity: 2 x 2 KB
+		if (wave * 8 < (int)((n + 15u) & ~15u)) {
+			const char* wsrc = wgt + (size_t)((slot >> 3) + wave) * 8192 + par * 2048 + lane * 16;
+#pragma unroll
+			for (int hl = 0; hl < 2; hl++)
+#pragma unroll
+				for (int hh = 0; hh < 2; hh++)
+					__builtin_amdgcn_global_load_lds(
+						(const __attribute__((address_space(1))) void*)(wsrc + hl * 4096 + hh * 1024),
+						(__attribute__((address_space(3))) void*)&s_w[(wave * 2 + hl) * 128 + hh * 64],
+						16, 0, 0);
+		}
+	};
+	const int half = lane >> 5, l31 = lane & 31;
+	auto compute = [&](uint32_t j, const float4* s_feat4, const float4* s_w4, auto tsel) __attribute__((always_inline)) {
+		constexpr int T = decltype(tsel)::value;
+		if (dbg & 2) return;
+		const uint32_t q = T ? j - QA : j;
+		const uint32_t tot = T ? totB : totA;
+		const uint32_t n = (tot - q * PB) < (uint32_t)PB ? (tot - q * PB) : (uint32_t)PB;
+		const float* s_feat = reinterpret_cast<const float*>(s_feat4);
+#pragma unroll
+		for (int ks = 0; ks < 2; ks++) {
+			if (ks == 1 && n <= 16) break;
+			bf16x8 ah[2], al[2];
+#pragma unroll
+			for (int cb = 0; cb < 2; cb++) {
+				const float* fcol = s_feat + (ks * 16 + 8 * half) * 128 + cgrp * 64 + cb * 32 + l31;
+				const int nrel = (int)n - (ks * 16 + 8 * half);   // live entries of this lane's k-group
+#pragma unroll
+				for (int kk = 0; kk < 8; kk++) {
+					float f = fcol[kk * 128];
+					f = kk < nrel ? f : 0.f;   // padding rows: see bf16 kernel
+					ah[cb][kk] = (__bf16)f;
+					al[cb][kk] = (__bf16)(f - (float)ah[cb][kk]);
+				}
+			}
+			const bf16x8* wrow = reinterpret_cast<const bf16x8*>(s_w4) + (ks * 2 + half) * 256 + ph * 64 + l31;
+			bf16x8 bh[2], bl[2];
+#pragma unroll
+			for (int pb = 0; pb < 2; pb++) {
+				bh[pb] = wrow[pb * 32];
+				bl[pb] = wrow[128 + pb * 32];
+			}
+#pragma unroll
+			for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+				for (int pb = 0; pb < 2; pb++)
+					acc[T][cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[T][cb][pb], 0, 0, 0);
+#pragma unroll
+			for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+				for (int pb = 0; pb < 2; pb++)
+					acc[T][cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[T][cb][pb], 0, 0, 0);
+#pragma unroll
+			for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+				for (int pb = 0; pb < 2; pb++)
+					acc[T][cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[T][cb][pb], 0, 0, 0);
+		}
+	};
+	auto compute_any = [&](uint32_t j, const float4* s_feat4, const float4* s_w4) __attribute__((always_inline)) {
+		if (j >= QA) compute(j, s_feat4, s_w4, std::integral_constant<int, 1>{});
+		else compute(j, s_feat4, s_w4, std::integral_constant<int, 0>{});
+	};
+
+	if (QT > 0) {
+		issue(0, s_f0, s_w0);
+		for (uint32_t j = 0; j < QT; j += 2) {
+			__syncthreads();
+			if (j + 1 < QT) issue(j + 1, s_f1, s_w1);
+			compute_any(j, s_f0, s_w0);
+			if (j + 1 < QT) {
+				__syncthreads();
+				if (j + 2 < QT) issue(j + 2, s_f0, s_w0);
+				compute_any(j + 1, s_f1, s_w1);
+			}
+		}
+	}
+
+	// ---- epilogue.  Block pb of this wave holds, per tile, rows rp0 = 2*(2*ph + pb) and rp0 + 1
+	// of this parity (lanes 0-15 / 16-31; lanes 32-63 the same for channel + 4).  After the
+	// row swap, register `lo` is row rp0 of A|B and `hi` is row rp0 + 1 of A|B: 32 consecutive x.
+	const int xA0 = txA * SGS_TILE;
+#pragma unroll
+	for (int pb = 0; pb < 2; pb++) {
+		const int rp = 2 * (2 * ph + pb) + ((l31 >> 4) & 1);        // row pair of this lane before the swap
+		const int yown = ty * SGS_TILE + 2 * rp + par;
+		const int xa = xA0 + (l31 & 15), xb = xa + SGS_TILE;
+		const float TA = (validA && yown < H && xa < W) ? final_T[(size_t)yown * W + xa] : 0.f;
+		const float TB = (validB && yown < H && xb < W) ? final_T[(size_t)yown * W + xb] : 0.f;
+		// after the swap lanes 0-31 / 32-63 hold row y0 (register lo) or y0 + 2 (register hi)
+		const int y0 = ty * SGS_TILE + 2 * (2 * (2 * ph + pb)) + par;
+		const int x = xA0 + l31;
+		const bool xok = x >= 0 && x < W && (l31 < 16 ? validA : validB);
+#pragma unroll
+		for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const int c = cbase + cgrp * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+				const float bgc = bg[c];
+				const float va = __builtin_fmaf(TA, bgc, acc[0][cb][pb][r]);
+				const float vb = __builtin_fmaf(TB, bgc, acc[1][cb][pb][r]);
+				const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+				float* dst = out + (size_t)c * HW + (size_t)y0 * W + x;
+				if (xok && !((dbg & 1) && va != 123.f)) {
+					if (y0 < H) *dst = __uint_as_float(sw[0]);
+					if (y0 + 2 < H) dst[2 * (size_t)W] = __uint_as_float(sw[1]);
+				}
+			}
+	}
+}
+
+// -------------------------------------------------------------------------------------
+// Row-sweep split-bf16 accumulate (the default when W % 32 == 16).
+//
+// Measured on the per-tile kernel above: the epilogue's 64-B pieces (a tile is 16 px wide)
+// cost 0.77 ms of its 1.3 ms, because the memory system writes partial 128-B lines at
+// 3.5 TB/s but complete aligned lines at 4.8-5.2 TB/s (tools/ubench_store.hip,
+// profiles/r01_ubench_store.txt); splitting the work by row parity to own whole lines
+// (blend_accum_pair_kernel) fetches and converts every feature twice and loses more than
+// it gains.  This kernel instead SWEEPS: one workgroup walks `seg` consecutive tiles of a
+// tile row for 128 channels, one pipeline across all of them, and keeps the half lines that
+// still wait for their right-hand neighbour in registers:
+//     even rows: line = tiles (2k, 2k+1)      odd rows: line = tiles (2k-1, 2k)
+// (pitch W*4 with W % 32 == 16: odd rows start 64 B into a line).  After an even tile its odd
+// rows complete the lines begun by the previous (odd) tile, after an odd tile its even rows
+// complete the previous tile's; v_permlane16_swap_b32 merges the two 16-lane half rows so
+// each store instruction writes two complete 128-B lines.  Only the first/last tile of a
+// segment writes half lines.  Three accumulator sets of 4 blocks rotate through the roles
+// (even rows, odd rows, pending) with period two tiles, so nothing is ever copied.
+//
+// The sweep also amortises the per-workgroup prologue (work-list metadata, ids, final_T and
+// background staged in LDS once per segment) and never drains the DMA pipeline between
+// tiles: the next tile's first batch is in flight while the finished tile is stored.
+//
+// Wave tile 32 channels x 256 px (8 MFMA blocks, parity-major pixel order: blocks 0-3 even
+// rows, 4-7 odd rows); batch = 16 entries; two LDS stages of 8 KB features + 16 KB weights.
+constexpr int SEGMAX = 12;   // tiles per sweep (upper bound, the launcher picks the length)
+constexpr int STAB = 8;      // chunk starts per tile kept in LDS
+constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
+constexpr int LA = NST - 1;
+constexpr int STAGE_BYTES = 8192 + 16384 + 2048;   // features | weights | ids of the batch LA bundles on
+constexpr int SW_NDMA = 4;   // LDS-DMA instructions per wave per bundle: 1 feature + 2 weight + 1 id
+
+// The accumulator sets are touched only through these free functions with compile-time set
+// indices (closures nested more than one level deep keep the array in scratch memory).
+typedef f32x16 SweepSets[2][4];   // [left, right][block]
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Block pb of a wave's row-parity group g holds rows rp = 2 pb (lanes 0-15 / 32-47) and rp + 1
+// (lanes 16-31 / 48-63), y = 2 rp + g; lanes >= 32 are channel + 4.
+// left (S[0]) | right (S[1]) half rows -> complete lines.
+// base = &out[c0 + 4*half][ty*16 + g][xl0 + (lane & 31)];  GUARD = some lane or row is outside
+// the image (edge tiles only): per-store predication instead of straight-line stores.
+template <bool GUARD>
+__device__ __forceinline__ void sweep_store_paired(const SweepSets& S, float* base, size_t HW, int W,
+						   bool xok, int y0, int H)
+{
+#pragma unroll
+	for (int pb = 0; pb < 4; pb++) {
+		const int y = y0 + 4 * pb;
+		const bool ok0 = xok && y < H, ok1 = xok && y + 2 < H;
+		float* bp = base + (size_t)(4 * pb) * W;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(S[0][pb][r]),
+									 __float_as_uint(S[1][pb][r]), false, false);
+			float* dst = bp + (size_t)((r & 3) + 8 * (r >> 2)) * HW;
+			if (!GUARD || ok0) *dst = __uint_as_float(sw[0]);
+			if (!GUARD || ok1) dst[2 * (size_t)W] = __uint_as_float(sw[1]);
+		}
+	}
+}
+
+// the half rows in S[1] on their own (segment ends): 64-B pieces;
+// base = &out[c0 + 4*half][ty*16 + g + 2*((lane>>4)&1)][x0 + (lane & 15)]
+template <bool GUARD>
+__device__ __forceinline__ void sweep_store_single(const SweepSets& S, float* base, size_t HW, int W,
+						   bool xok, int y0, int H)
+{
+#pragma unroll
+	for (int pb = 0; pb < 4; pb++) {
+		const bool ok = xok && y0 + 4 * pb < H;
+		float* bp = base + (size_t)(4 * pb) * W;
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			if (!GUARD || ok) bp[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = S[1][pb][r];
+	}
+}
+
+template <int X>
+__device__ __forceinline__ void sweep_zero(SweepSets& S)
+{
+#pragma unroll
+	for (int pb = 0; pb < 4; pb++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) S[X][pb][r] = 0.f;
+}
+
+// One batch of 16 entries out of ring stage `st` (LDS byte address) into S[1], for the wave's
+// 32 channels (cg) and its row parity g (4 pixel blocks).  All LDS reads of the ring are inline
+// asm: the compiler's waitcnt pass would put s_waitcnt vmcnt(0) in front of every ds_read that
+// may alias an LDS-DMA destination and drain the bundles in flight (cdna_hip_programming.md
+// 5.7: early-clobber outputs, nothing consumes an output before the explicit lgkmcnt(0), that
+// wait takes the values as "+v").
+__device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_t n, int cg, int g, int half, int l31)
+{
+	const uint32_t fa = st + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;                     // + kk * 512
+	const uint32_t wa = st + 8192u + (uint32_t)half * 8192u + (uint32_t)(g * 128 + l31) * 16u;      // + pb * 512 (+ 4096 lo)
+	float f[8];
+	v4i bh, bl;
+	asm volatile(
+		"ds_read_b32 %0, %10\n\t"
+		"ds_read_b32 %1, %10 offset:512\n\t"
+		"ds_read_b32 %2, %10 offset:1024\n\t"
+		"ds_read_b32 %3, %10 offset:1536\n\t"
+		"ds_read_b32 %4, %10 offset:2048\n\t"
+		"ds_read_b32 %5, %10 offset:2560\n\t"
+		"ds_read_b32 %6, %10 offset:3072\n\t"
+		"ds_read_b32 %7, %10 offset:3584\n\t"
+		"ds_read_b128 %8, %11\n\t"
+		"ds_read_b128 %9, %11 offset:4096\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]),
+		  "=&v"(f[7]), "=&v"(bh), "=&v"(bl)
+		: "v"(fa), "v"(wa)
+		: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+	const int nrel = (int)n - 8 * half;   // live entries of this lane's k-group
+	bf16x8 ah, al;
+#pragma unroll
+	for (int kk = 0; kk < 8; kk++) {
+		const float fv = kk < nrel ? f[kk] : 0.f;   // padding rows hold a clamped duplicate (weights are 0)
+		ah[kk] = (__bf16)fv;
+		al[kk] = (__bf16)(fv - (float)ah[kk]);
+	}
+#pragma unroll
+	for (int pb = 0; pb < 4; pb++) {   // the next block's operands fly while this block multiplies
+		v4i nh, nl;
+		if (pb < 3) {
+			const uint32_t wn = wa + (uint32_t)(pb + 1) * 512u;
+			asm volatile(
+				"ds_read_b128 %0, %2\n\t"
+				"ds_read_b128 %1, %2 offset:4096"
+				: "=&v"(nh), "=&v"(nl)
+				: "v"(wn)
+				: "memory");
+		}
+		const bf16x8 h = __builtin_bit_cast(bf16x8, bh), l = __builtin_bit_cast(bf16x8, bl);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h, S[1][pb], 0, 0, 0);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l, S[1][pb], 0, 0, 0);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h, S[1][pb], 0, 0, 0);
+		if (pb < 3) {
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nh), "+v"(nl) : : "memory");
+			__builtin_amdgcn_sched_barrier(0);
+			bh = nh;
+			bl = nl;
+		}
+	}
+}
+
+// 512 lanes: wave w = channel group (w & 3) x row parity (w >> 2).
+__global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const char* __restrict__ wgt, const float* __restrict__ features,
+	const float* __restrict__ bg, float* __restrict__ out, const uint32_t* __restrict__ counter,
+	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items)
+{
+	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
+	const int b = blockIdx.x;
+	const int v = (b & 7) * per_xcd + (b >> 3);
+	if (v >= total_items) return;
+	const int chunk = v % nchunks_c;
+	const int rest = v / nchunks_c;
+	const int sg = rest % nseg, ty = rest / nseg;
+	const int tx0 = sg * seg;   // even (seg is even)
+	const int nt = (gx - tx0) < seg ? (gx - tx0) : seg;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int cg = wave & 3, g = wave >> 2;
+	const int half = lane >> 5, l31 = lane & 31;
+	const int cbase = chunk * 128;
+	const int c0 = cbase + cg * 32;
+	const size_t HW = (size_t)H * W;
+
+	__shared__ float4 s_ring[NST * STAGE_BYTES / 16];
+	__shared__ uint32_t s_tab[SEGMAX][STAB];
+	__shared__ uint32_t s_tot[SEGMAX], s_cb[SEGMAX];
+
+	// ---- prologue: per-tile work-list metadata (ordinary LDS accesses before the first DMA,
+	// asm loads afterwards)
+	if ((int)threadIdx.x < nt) {
+		const int tile = ty * gx + tx0 + threadIdx.x;
+		s_tot[threadIdx.x] = nact[tile];   // >= 1: every tile ends with the T * bg pseudo entry
+		s_cb[threadIdx.x] = (ranges[tile].x >> 7) + (uint32_t)tile;
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < nt * STAB) {
+		const int t = threadIdx.x / STAB, i = threadIdx.x % STAB;
+		if ((uint32_t)i * ACH < s_tot[t]) s_tab[t][i] = table[s_cb[t] + i];
+	}
+	__syncthreads();
+
+	const uint32_t ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_ring;
+	const uint32_t tot_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_tot;
+	const uint32_t cb_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_cb;
+	const uint32_t tab_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_tab;
+	auto lds_u32 = [](uint32_t addr) __attribute__((always_inline)) -> uint32_t {   // uniform LDS word -> SGPR
+		uint32_t r;
+		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+		return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+	};
+	auto tile_tot = [&](int t) __attribute__((always_inline)) -> uint32_t { return lds_u32(tot_a + 4u * (uint32_t)t); };
+	// first slot of batch q of tile t
+	auto batch_slot = [&](int t, uint32_t q) __attribute__((always_inline)) -> uint32_t {
+		const uint32_t first = q * AB, ci = first >> 7;
+		const uint32_t cs = ci < (uint32_t)STAB ? lds_u32(tab_a + 4u * ((uint32_t)t * STAB + ci))
+							: table[lds_u32(cb_a + 4u * (uint32_t)t) + ci];
+		return cs + (first & 127u);
+	};
+
+	struct It { int t; uint32_t q; uint32_t tot; };   // a batch of the segment's stream; t == nt: past the end
+	auto advance = [&](It& it) __attribute__((always_inline)) {
+		if (it.t >= nt) return;
+		if ((it.q + 1) * AB < it.tot) { it.q++; return; }
+		it.t++;
+		it.q = 0;
+		it.tot = it.t < nt ? tile_tot(it.t) : 0u;
+	};
+	const uint32_t sub = (uint32_t)(2 * wave + half);   // the entry (of 16) whose feature row this lane fetches
+	// bundle = features + weights of batch `bt` into stage st, and the ids of batch `bi` into its id
+	// area.  Every wave issues exactly SW_NDMA DMA instructions per bundle (clamped dummies past the end).
+	auto issue = [&](const It& bt, uint32_t id, const It& bi, uint32_t st) __attribute__((always_inline)) {
+		const It b = bt.t < nt ? bt : It{nt - 1, 0u, 1u};   // past the end: a harmless re-read
+		const uint32_t slot = batch_slot(b.t, b.q);
+		const float* row = id == SGS_BG_ID ? bg : features + (size_t)id * C;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + cbase + l31 * 4),
+						 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(2 * wave) * 512u),
+						 16, 0, 0);
+		const char* wsrc = wgt + (size_t)(slot >> 3) * 8192 + (size_t)(wave * 2) * 1024 + (size_t)lane * 16;
+#pragma unroll
+		for (int j = 0; j < 2; j++)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + j * 1024),
+							 (__attribute__((address_space(3))) void*)(size_t)(st + 8192u + (uint32_t)(wave * 2 + j) * 1024u),
+							 16, 0, 0);
+		const It c = bi.t < nt ? bi : It{nt - 1, 0u, 1u};
+		const uint32_t slot2 = batch_slot(c.t, c.q);
+		const uint32_t n2 = (c.tot - c.q * AB) < (uint32_t)AB ? (c.tot - c.q * AB) : (uint32_t)AB;
+		const uint32_t li = (uint32_t)(lane & 15) < n2 ? (uint32_t)(lane & 15) : n2 - 1u;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(act_id + slot2 + li),
+						 (__attribute__((address_space(3))) void*)(size_t)(st + 24576u + (uint32_t)wave * 256u),
+						 4, 0, 0);
+	};
+	// this lane's feature-row id, from the id area of a landed bundle
+	auto id_from = [&](uint32_t st) __attribute__((always_inline)) -> uint32_t {
+		const uint32_t ia = st + 24576u + (uint32_t)wave * 256u + sub * 4u;
+		uint32_t id;
+		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(id) : "v"(ia) : "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		return id;
+	};
+	auto id_direct = [&](const It& bt) __attribute__((always_inline)) -> uint32_t {
+		const It b = bt.t < nt ? bt : It{nt - 1, 0u, 1u};
+		const uint32_t slot = batch_slot(b.t, b.q);
+		const uint32_t n = (b.tot - b.q * AB) < (uint32_t)AB ? (b.tot - b.q * AB) : (uint32_t)AB;
+		return act_id[slot + (sub < n ? sub : n - 1u)];
+	};
+
+	SweepSets S;   // this wave's left / right half rows
+	sweep_zero<0>(S);
+	sweep_zero<1>(S);
+
+	// ---- the sweep.  it0 = batch computed in this step; itI = it0 + LA, the bundle issued in this
+	// step; itD = it0 + 2 LA, the batch whose ids travel with that bundle.
+	It it0{0, 0u, tile_tot(0)};
+	It itI = it0;
+	{
+		It itd = it0;   // = bundle b + LA while issuing prologue bundle b
+#pragma unroll
+		for (int k = 0; k < LA; k++) advance(itd);
+#pragma unroll
+		for (int k = 0; k < LA; k++) {
+			issue(itI, id_direct(itI), itd, ring + (uint32_t)k * STAGE_BYTES);
+			advance(itI);
+			advance(itd);
+		}
+	}
+	It itD = itI;
+#pragma unroll
+	for (int k = 0; k < LA; k++) advance(itD);
+	uint32_t st0 = ring, stI = ring + LA * STAGE_BYTES;   // stages of it0 and itI
+	bool has_pending = false;   // S[0] holds left half rows waiting for their right-hand tile
+	bool after_stores = false;
+	while (it0.t < nt) {
+		// bundle it0 landed; the LA - 1 younger bundles -- and after an epilogue part of its stores --
+		// may still be in flight (vmcnt is 6 bits: <= 63)
+		if (after_stores) __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (15 << 8));
+		else __builtin_amdgcn_s_waitcnt(((LA - 1) * SW_NDMA) | (7 << 4) | (15 << 8));
+		after_stores = false;
+		__builtin_amdgcn_s_barrier();
+		issue(itI, id_from(st0), itD, stI);   // into the stage batch it0 - 1 was computed from
+		const uint32_t n = (it0.tot - it0.q * AB) < (uint32_t)AB ? (it0.tot - it0.q * AB) : (uint32_t)AB;
+		const int tx = tx0 + it0.t;
+		const bool is_left = ((tx + g) & 1) == 0;   // even rows: even tiles are left halves; odd rows: odd tiles
+		sweep_compute(S, st0, n, cg, g, half, l31);   // always into S[1]
+		if ((it0.q + 1) * AB >= it0.tot) {   // tile complete
+			const int hi = (l31 >> 4) & 1;
+			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * W;
+			const int xs = tx * SGS_TILE + (l31 & 15), xp = (tx - 1) * SGS_TILE + l31;
+			const int y0 = ty * SGS_TILE + g;
+			if (!is_left && has_pending) {   // S[0] | S[1] are whole lines
+				const bool inside = xp + 31 - l31 < W && y0 + 14 < H;   // uniform: the whole 32 x 8 block
+				if (inside) sweep_store_paired<false>(S, cbp + xp, HW, W, true, y0, H);
+				else sweep_store_paired<true>(S, cbp + xp, HW, W, xp < W, y0, H);
+				after_stores = true;
+			} else if (!is_left || it0.t == nt - 1) {   // a half with no partner in this segment
+				sweep_store_single<true>(S, cbp + (size_t)(2 * hi) * W + xs, HW, W, xs < W, y0 + 2 * hi, H);
+				after_stores = true;
+			}
+			if (is_left) {   // becomes the pending left half
+#pragma unroll
+				for (int pb = 0; pb < 4; pb++) S[0][pb] = S[1][pb];
+			}
+			has_pending = is_left;
+			sweep_zero<1>(S);
+		}
+		advance(it0);
+		advance(itI);
+		advance(itD);
+		st0 = st0 + STAGE_BYTES == ring + NST * STAGE_BYTES ? ring : st0 + STAGE_BYTES;
+		stI = stI + STAGE_BYTES == ring + NST * STAGE_BYTES ? ring : stI + STAGE_BYTES;
+	}
+	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the dummy tail bundles before LDS is released
 }
 
 // -------------------------------------------------------------------------------------
@@ -1085,16 +1673,15 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	if (e != hipSuccess) return e;
 	{
 		const int per_xcd = (ntiles + 7) / 8;
-		if ((split_mode & 15) == 6)
-			hipLaunchKernelGGL(blend_weights_kernel<true>, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
-					   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,
-					   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd,
-					   ntiles);
-		else
-			hipLaunchKernelGGL(blend_weights_kernel<false>, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
-					   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,
-					   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd,
-					   ntiles);
+		const int sm_ = split_mode & 15;
+#define SGS_LAUNCH_W(M_)                                                                            \
+	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,     \
+			   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,   \
+			   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd, ntiles)
+		if (sm_ == 8) SGS_LAUNCH_W(2);
+		else if (sm_ == 6 || sm_ == 7) SGS_LAUNCH_W(1);
+		else SGS_LAUNCH_W(0);
+#undef SGS_LAUNCH_W
 	}
 	{
 		// split_mode: 0 = 32 channels per wave, 1 entry per scalar wait (default);
@@ -1109,7 +1696,27 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
 			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
 			   total, (split_mode >> 4))
-		if (sm == 6)
+		if (sm == 8) {
+			int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) : 10;
+			if (seg > SEGMAX) seg = SEGMAX;
+			const int nseg = (a.gx + seg - 1) / seg;
+			seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
+			const int nc = a.C / 128;
+			const int items = a.gy * nseg * nc;
+			const int pxcd = (items + 7) / 8;
+			hipLaunchKernelGGL(blend_accum_sweep_kernel, dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table,
+					   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,
+					   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items);
+		} else if (sm == 7) {
+			const int stagger = (a.W % 32) == 16 ? 1 : 0;
+			const int nk = (a.gx + stagger) / 2 + 1;
+			const int nc = a.C / 128;
+			const int items = a.gy * nk * 2 * nc;
+			const int pxcd = (items + 7) / 8;
+			hipLaunchKernelGGL(blend_accum_pair_kernel, dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table,
+					   nbatches, act_id, (const char*)wgt, a.features, a.final_T, a.bg, a.out,
+					   counter, a.W, a.H, a.C, a.gx, nc, nk, stagger, pxcd, items, split_mode >> 4);
+		} else if (sm == 6)
 			hipLaunchKernelGGL(blend_accum_bf16_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
 					   table, nbatches, act_id, (const char*)wgt, a.features, a.final_T, a.bg,
 					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, split_mode >> 4);

@@ -104,11 +104,14 @@ def test_forward_c128_all_variants(orc, variant):
     assert fw["n_contrib"].max() > 20 and (fw["final_T"] < 1e-3).any()   # early stop exercised
 
 
-@pytest.mark.parametrize("C", [128, 160, 512])
-def test_forward_split_bf16_within_tolerance(orc, C):
-    """Variant 12: integer state bit-exact, feature map within 5e-5 of the absolute composite."""
-    scene, cam = small_scene(P=3000, C=C, W=200, H=120, fx=170.0, seed=C + 1)
-    _check_forward(orc, scene, cam, variant=12, exact=False)
+@pytest.mark.parametrize("variant", [12, 13, 14])
+@pytest.mark.parametrize("C,W,H", [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64)])
+def test_forward_split_bf16_within_tolerance(orc, variant, C, W, H):
+    """Split-bf16 accumulate (12: per tile, 13: tile pairs with full-line stores): integer state
+    bit-exact, feature map within 5e-5 of the absolute composite.  Widths cover W % 32 == 16
+    (staggered pairs), W % 32 == 0, ragged W and a single tile."""
+    scene, cam = small_scene(P=3000, C=C, W=W, H=H, fx=170.0, seed=C + W)
+    _check_forward(orc, scene, cam, variant=variant, exact=False)
 
 
 @pytest.mark.parametrize("C", [1, 3, 20, 21, 32, 33, 64, 160, 256, 768])
