@@ -44,7 +44,7 @@ struct StagedEntryW {   // 32 B per list entry in LDS
 	float a2, b2, c2, o;
 	float x, y;
 	uint32_t id;
-	float pad;
+	float thr;   // prefilter: no pixel with power < thr can pass the alpha test
 };
 
 constexpr int WB = 32;    // list entries per batch
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	const uint32_t chunk_base = (range.x >> 7) + (uint32_t)tile;
 
 	__shared__ StagedEntryW s_e[WB];
-	__shared__ float s_wt[WB * 256];       // [entry][strip*64 + lane]
-	__shared__ unsigned s_active[WB];
+	__shared__ float s_wt[(WB + 3) * 256]; // [entry][strip*64 + lane] (+ padding entries)
+	__shared__ uint32_t s_amask;           // entries of the batch taken by at least one pixel
 	__shared__ int s_alive[4];
 	__shared__ uint32_t s_cnt, s_mask, s_ovf;
 	__shared__ uint32_t s_chunk[64];   // first slot of each chunk (re-read from `table` beyond 64)
@@ -131,67 +131,81 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		const int alive = s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3];
 		if (!alive) break;
 		const int n = (n_total - base) < WB ? (n_total - base) : WB;
-		if ((int)threadIdx.x < n) {
-			const uint32_t id = point_list[range.x + base + threadIdx.x];
-			const float2 xy = means2D[id];
-			const float4 co = conic_opacity[id];
+		if ((int)threadIdx.x < WB) {
 			StagedEntryW e;
-			e.a2 = -0.5f * co.x;
-			e.b2 = -co.y;
-			e.c2 = -0.5f * co.z;
-			e.o = co.w;
-			e.x = xy.x;
-			e.y = xy.y;
-			e.id = id;
-			e.pad = 0.f;
+			if ((int)threadIdx.x < n) {
+				const uint32_t id = point_list[range.x + base + threadIdx.x];
+				const float2 xy = means2D[id];
+				const float4 co = conic_opacity[id];
+				e.a2 = -0.5f * co.x;
+				e.b2 = -co.y;
+				e.c2 = -0.5f * co.z;
+				e.o = co.w;
+				e.x = xy.x;
+				e.y = xy.y;
+				e.id = id;
+				// prefilter threshold: alpha = o * exp(power) >= 1/255 needs power >= ln(1 / (255 o)).
+				// 1 % below it (the contract exp is good to 5 ulp, __logf to ~1e-6) a pixel
+				// provably fails the alpha test; anything else goes through the exact path.
+				e.thr = __logf(1.0f / (255.0f * co.w)) - 0.01f;
+			} else {   // padding up to a multiple of 4: an entry nothing can take
+				e.a2 = e.b2 = e.c2 = e.o = e.x = e.y = 0.f;
+				e.id = 0u;
+				e.thr = __builtin_inff();
+			}
 			s_e[threadIdx.x] = e;
 		}
-		if (threadIdx.x < WB) s_active[threadIdx.x] = 0u;
+		if (threadIdx.x == 0) s_amask = 0u;
 		__syncthreads();
-		// ---- weight phase: wave w evaluates strip w for the whole batch.  Four entries per
-		// step: their LDS reads, exponents and alphas are independent (ILP); only the
-		// transmittance chain (3 ops per entry) is sequential.
+		// ---- weight phase: wave w evaluates strip w for the whole batch.  The quadratic form of
+		// four entries is evaluated together (independent, ILP); an entry then runs the exp /
+		// alpha / transmittance chain only if some pixel of the strip can pass the alpha test
+		// (wave-uniform branch) -- for ~60 % of the (strip, entry) pairs none can.
 		if (wave_alive) {
-			for (int j0 = 0; j0 < n; j0 += 4) {
-				float alpha[4], power[4];
+			uint32_t act = 0u;   // entries of this batch taken by some pixel of this strip
+			const int n4 = (n + 3) & ~3;
+			for (int j0 = 0; j0 < n4; j0 += 4) {
+				float power[4], opac[4];
+				bool pre[4];
 #pragma unroll
 				for (int u = 0; u < 4; u++) {
-					const int j = (j0 + u < n) ? j0 + u : n - 1;   // clamp: results of padding are dropped
-					const StagedEntryW e = s_e[j];
+					const StagedEntryW e = s_e[j0 + u];
 					const float dx = e.x - pxf, dy = e.y - pyf;
 					power[u] = __builtin_fmaf(e.b2 * dx, dy,
 								  __builtin_fmaf(e.c2 * dy, dy, (e.a2 * dx) * dx));
-					alpha[u] = fmin_(0.99f, e.o * expf_contract(power[u]));
+					opac[u] = e.o;
+					pre[u] = !(power[u] > 0.0f) && !(power[u] < e.thr);
 				}
 #pragma unroll
 				for (int u = 0; u < 4; u++) {
 					const int j = j0 + u;
-					if (j < n) {
-						const float test_T = T * (1.0f - alpha[u]);
-						const bool cand = !done && !(power[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
+					const bool cand0 = !done && pre[u];
+					float w = 0.0f;
+					if (__ballot(cand0) != 0ull) {
+						const float alpha = fmin_(0.99f, opac[u] * expf_contract(power[u]));
+						const float test_T = T * (1.0f - alpha);
+						const bool cand = cand0 && !(alpha < 1.0f / 255.0f);
 						const bool stop = cand && (test_T < 0.0001f);
 						const bool take = cand && !stop;
 						done = done || stop;
-						float w = 0.0f;
 						if (take) {
-							w = alpha[u] * T;
+							w = alpha * T;
 							T = test_T;
 							last = (uint32_t)(base + j + 1);
 						}
-						const bool any_take = __ballot(take) != 0ull;
-						if (lane == 0 && any_take) s_active[j] = 1u;   // benign same-value race
-						s_wt[j * 256 + wave * 64 + lane] = w;
+						if (__ballot(take) != 0ull) act |= 1u << j;
 					}
+					s_wt[j * 256 + wave * 64 + lane] = w;
 				}
 			}
+			if (lane == 0 && act != 0u) atomicOr(&s_amask, act);
 		} else {
 			for (int j = 0; j < n; j++) s_wt[j * 256 + wave * 64 + lane] = 0.0f;
 		}
 		__syncthreads();
 		// ---- compaction into the tile's contiguous chunks
 		if (wave == 0) {
-			const bool a = (lane < n) && (s_active[lane & (WB - 1)] != 0u);
-			const unsigned long long m = __ballot(a);
+			const unsigned long long m = (unsigned long long)s_amask;
 			if (lane == 0) {
 				const uint32_t cnt = (uint32_t)__popcll(m);
 				// reserve chunks until [total, total+cnt) is covered
@@ -1123,9 +1137,9 @@ __global__ __launch_bounds__(256, 2) void blend_accum_pair_kernel(
 //
 // Wave tile 32 channels x 256 px (8 MFMA blocks, parity-major pixel order: blocks 0-3 even
 // rows, 4-7 odd rows); batch = 16 entries; two LDS stages of 8 KB features + 16 KB weights.
-constexpr int SEGMAX = 12;   // tiles per sweep (upper bound, the launcher picks the length)
+constexpr int SEGMAX = 16;   // tiles per sweep (upper bound, the launcher picks the length)
 constexpr int STAB = 8;      // chunk starts per tile kept in LDS
-constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
+constexpr int NST = 5;       // ring stages (bundles of NST - 1 batches in flight)
 constexpr int LA = NST - 1;
 constexpr int STAGE_BYTES = 8192 + 16384 + 2048;   // features | weights | ids of the batch LA bundles on
 constexpr int SW_NDMA = 4;   // LDS-DMA instructions per wave per bundle: 1 feature + 2 weight + 1 id
@@ -1248,6 +1262,8 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 }
 
 // 512 lanes: wave w = channel group (w & 3) x row parity (w >> 2).
+// DBG (development ablations, 0 in production): 1 = no stores, 2 = no matrix work.
+template <int DBG>
 __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -1383,7 +1399,7 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	while (it0.t < nt) {
 		// bundle it0 landed; the LA - 1 younger bundles -- and after an epilogue part of its stores --
 		// may still be in flight (vmcnt is 6 bits: <= 63)
-		if (after_stores) __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (15 << 8));
+		if (after_stores) __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (15 << 8));   // vmcnt(63)
 		else __builtin_amdgcn_s_waitcnt(((LA - 1) * SW_NDMA) | (7 << 4) | (15 << 8));
 		after_stores = false;
 		__builtin_amdgcn_s_barrier();
@@ -1391,8 +1407,8 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 		const uint32_t n = (it0.tot - it0.q * AB) < (uint32_t)AB ? (it0.tot - it0.q * AB) : (uint32_t)AB;
 		const int tx = tx0 + it0.t;
 		const bool is_left = ((tx + g) & 1) == 0;   // even rows: even tiles are left halves; odd rows: odd tiles
-		sweep_compute(S, st0, n, cg, g, half, l31);   // always into S[1]
-		if ((it0.q + 1) * AB >= it0.tot) {   // tile complete
+		if (!(DBG & 2)) sweep_compute(S, st0, n, cg, g, half, l31);   // always into S[1]
+		if ((it0.q + 1) * AB >= it0.tot && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
 			const int hi = (l31 >> 4) & 1;
 			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * W;
 			const int xs = tx * SGS_TILE + (l31 & 15), xp = (tx - 1) * SGS_TILE + l31;
@@ -1697,16 +1713,24 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
 			   total, (split_mode >> 4))
 		if (sm == 8) {
-			int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) : 10;
+			int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) + 1 : 12;
 			if (seg > SEGMAX) seg = SEGMAX;
 			const int nseg = (a.gx + seg - 1) / seg;
 			seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
 			const int nc = a.C / 128;
 			const int items = a.gy * nseg * nc;
 			const int pxcd = (items + 7) / 8;
-			hipLaunchKernelGGL(blend_accum_sweep_kernel, dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table,
-					   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,
-					   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items);
+#define SGS_LAUNCH_SWEEP(D_)                                                                         \
+	hipLaunchKernelGGL(blend_accum_sweep_kernel<D_>, dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
+			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items)
+			switch (split_mode >> 8) {
+			case 1: SGS_LAUNCH_SWEEP(1); break;
+			case 2: SGS_LAUNCH_SWEEP(2); break;
+			case 3: SGS_LAUNCH_SWEEP(3); break;
+			default: SGS_LAUNCH_SWEEP(0); break;
+			}
+#undef SGS_LAUNCH_SWEEP
 		} else if (sm == 7) {
 			const int stagger = (a.W % 32) == 16 ? 1 : 0;
 			const int nk = (a.gx + stagger) / 2 + 1;
