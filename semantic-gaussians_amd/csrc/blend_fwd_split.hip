@@ -1138,8 +1138,8 @@ __global__ __launch_bounds__(256, 2) void blend_accum_pair_kernel(
 // Wave tile 32 channels x 256 px (8 MFMA blocks, parity-major pixel order: blocks 0-3 even
 // rows, 4-7 odd rows); batch = 16 entries; two LDS stages of 8 KB features + 16 KB weights.
 constexpr int SEGMAX = 16;   // tiles per sweep (upper bound, the launcher picks the length)
-constexpr int STAB = 8;      // chunk starts per tile kept in LDS
-constexpr int NST = 5;       // ring stages (bundles of NST - 1 batches in flight)
+constexpr int SW_JMAX = 1024; // batch-table window (batches of a segment kept in LDS)
+constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
 constexpr int LA = NST - 1;
 constexpr int STAGE_BYTES = 8192 + 16384 + 2048;   // features | weights | ids of the batch LA bundles on
 constexpr int SW_NDMA = 4;   // LDS-DMA instructions per wave per bundle: 1 feature + 2 weight + 1 id
@@ -1289,55 +1289,58 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	const size_t HW = (size_t)H * W;
 
 	__shared__ float4 s_ring[NST * STAGE_BYTES / 16];
-	__shared__ uint32_t s_tab[SEGMAX][STAB];
-	__shared__ uint32_t s_tot[SEGMAX], s_cb[SEGMAX];
+	// the segment's batches as one flat stream: .x = first arena slot of the batch,
+	// .y = entries (1..16) | tile index in the segment << 8 | last batch of its tile << 16
+	__shared__ uint2 s_bt[SW_JMAX];
+	__shared__ uint32_t s_tot[SEGMAX], s_cb[SEGMAX], s_pref[SEGMAX + 1];
 
-	// ---- prologue: per-tile work-list metadata (ordinary LDS accesses before the first DMA,
-	// asm loads afterwards)
+	// ---- prologue: the batch table (ordinary LDS / global accesses: nothing is in flight yet)
 	if ((int)threadIdx.x < nt) {
 		const int tile = ty * gx + tx0 + threadIdx.x;
 		s_tot[threadIdx.x] = nact[tile];   // >= 1: every tile ends with the T * bg pseudo entry
 		s_cb[threadIdx.x] = (ranges[tile].x >> 7) + (uint32_t)tile;
 	}
 	__syncthreads();
-	if ((int)threadIdx.x < nt * STAB) {
-		const int t = threadIdx.x / STAB, i = threadIdx.x % STAB;
-		if ((uint32_t)i * ACH < s_tot[t]) s_tab[t][i] = table[s_cb[t] + i];
+	if (threadIdx.x == 0) {
+		uint32_t acc = 0;
+		for (int t = 0; t < nt; t++) {
+			s_pref[t] = acc;
+			acc += (s_tot[t] + AB - 1) / AB;
+		}
+		s_pref[nt] = acc;
 	}
+	__syncthreads();
+	const uint32_t J = s_pref[nt];   // batches in this segment
+	// (re)build the table window [wbase, wbase + SW_JMAX); entries past J repeat the last batch
+	auto fill_table = [&](uint32_t wbase) __attribute__((always_inline)) {
+		uint32_t maxnb = 0;
+		for (int t = 0; t < nt; t++) maxnb = max(maxnb, s_pref[t + 1] - s_pref[t]);
+		for (uint32_t qb = 0; qb < maxnb; qb += 32) {   // 32 batches of each of 16 tiles per pass
+			const int t = threadIdx.x >> 5;
+			const uint32_t q = qb + (threadIdx.x & 31);
+			if (t < nt) {
+				const uint32_t p0 = s_pref[t], nb = s_pref[t + 1] - p0;
+				if (q < nb && p0 + q >= wbase && p0 + q < wbase + SW_JMAX) {
+					const uint32_t tot = s_tot[t], first = q * AB;
+					const uint32_t slot = table[s_cb[t] + (first >> 7)] + (first & 127u);
+					const uint32_t n = (tot - first) < (uint32_t)AB ? (tot - first) : (uint32_t)AB;
+					s_bt[p0 + q - wbase] = make_uint2(slot, n | ((uint32_t)t << 8) | (q + 1 == nb ? 1u << 16 : 0u));
+				}
+			}
+		}
+		// past the end: 2 LA dummy batches (re-reads of a valid batch, never consumed)
+		if (threadIdx.x < 2 * LA && J + threadIdx.x >= wbase && J + threadIdx.x - wbase < SW_JMAX)
+			s_bt[J + threadIdx.x - wbase] = make_uint2(table[s_cb[nt - 1]], 1u | ((uint32_t)(nt - 1) << 8));
+	};
+	fill_table(0);
 	__syncthreads();
 
 	const uint32_t ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_ring;
-	const uint32_t tot_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_tot;
-	const uint32_t cb_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_cb;
-	const uint32_t tab_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_tab;
-	auto lds_u32 = [](uint32_t addr) __attribute__((always_inline)) -> uint32_t {   // uniform LDS word -> SGPR
-		uint32_t r;
-		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
-		return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-	};
-	auto tile_tot = [&](int t) __attribute__((always_inline)) -> uint32_t { return lds_u32(tot_a + 4u * (uint32_t)t); };
-	// first slot of batch q of tile t
-	auto batch_slot = [&](int t, uint32_t q) __attribute__((always_inline)) -> uint32_t {
-		const uint32_t first = q * AB, ci = first >> 7;
-		const uint32_t cs = ci < (uint32_t)STAB ? lds_u32(tab_a + 4u * ((uint32_t)t * STAB + ci))
-							: table[lds_u32(cb_a + 4u * (uint32_t)t) + ci];
-		return cs + (first & 127u);
-	};
-
-	struct It { int t; uint32_t q; uint32_t tot; };   // a batch of the segment's stream; t == nt: past the end
-	auto advance = [&](It& it) __attribute__((always_inline)) {
-		if (it.t >= nt) return;
-		if ((it.q + 1) * AB < it.tot) { it.q++; return; }
-		it.t++;
-		it.q = 0;
-		it.tot = it.t < nt ? tile_tot(it.t) : 0u;
-	};
+	const uint32_t bt_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_bt;
 	const uint32_t sub = (uint32_t)(2 * wave + half);   // the entry (of 16) whose feature row this lane fetches
-	// bundle = features + weights of batch `bt` into stage st, and the ids of batch `bi` into its id
-	// area.  Every wave issues exactly SW_NDMA DMA instructions per bundle (clamped dummies past the end).
-	auto issue = [&](const It& bt, uint32_t id, const It& bi, uint32_t st) __attribute__((always_inline)) {
-		const It b = bt.t < nt ? bt : It{nt - 1, 0u, 1u};   // past the end: a harmless re-read
-		const uint32_t slot = batch_slot(b.t, b.q);
+	// bundle = features + weights of the batch at `slot` into stage st, and the ids of the batch
+	// (slot2, n2) into its id area.  Every wave issues exactly SW_NDMA DMA instructions.
+	auto issue = [&](uint32_t slot, uint32_t id, uint32_t slot2, uint32_t n2, uint32_t st) __attribute__((always_inline)) {
 		const float* row = id == SGS_BG_ID ? bg : features + (size_t)id * C;
 		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + cbase + l31 * 4),
 						 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(2 * wave) * 512u),
@@ -1348,77 +1351,84 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + j * 1024),
 							 (__attribute__((address_space(3))) void*)(size_t)(st + 8192u + (uint32_t)(wave * 2 + j) * 1024u),
 							 16, 0, 0);
-		const It c = bi.t < nt ? bi : It{nt - 1, 0u, 1u};
-		const uint32_t slot2 = batch_slot(c.t, c.q);
-		const uint32_t n2 = (c.tot - c.q * AB) < (uint32_t)AB ? (c.tot - c.q * AB) : (uint32_t)AB;
 		const uint32_t li = (uint32_t)(lane & 15) < n2 ? (uint32_t)(lane & 15) : n2 - 1u;
 		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(act_id + slot2 + li),
 						 (__attribute__((address_space(3))) void*)(size_t)(st + 24576u + (uint32_t)wave * 256u),
 						 4, 0, 0);
-	};
-	// this lane's feature-row id, from the id area of a landed bundle
-	auto id_from = [&](uint32_t st) __attribute__((always_inline)) -> uint32_t {
-		const uint32_t ia = st + 24576u + (uint32_t)wave * 256u + sub * 4u;
-		uint32_t id;
-		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(id) : "v"(ia) : "memory");
-		__builtin_amdgcn_sched_barrier(0);
-		return id;
-	};
-	auto id_direct = [&](const It& bt) __attribute__((always_inline)) -> uint32_t {
-		const It b = bt.t < nt ? bt : It{nt - 1, 0u, 1u};
-		const uint32_t slot = batch_slot(b.t, b.q);
-		const uint32_t n = (b.tot - b.q * AB) < (uint32_t)AB ? (b.tot - b.q * AB) : (uint32_t)AB;
-		return act_id[slot + (sub < n ? sub : n - 1u)];
 	};
 
 	SweepSets S;   // this wave's left / right half rows
 	sweep_zero<0>(S);
 	sweep_zero<1>(S);
 
-	// ---- the sweep.  it0 = batch computed in this step; itI = it0 + LA, the bundle issued in this
-	// step; itD = it0 + 2 LA, the batch whose ids travel with that bundle.
-	It it0{0, 0u, tile_tot(0)};
-	It itI = it0;
-	{
-		It itd = it0;   // = bundle b + LA while issuing prologue bundle b
+	// ---- the sweep.  Step j computes batch j, issues bundle j + LA, whose id area carries the ids
+	// of batch j + 2 LA.
+	uint32_t wbase = 0;
 #pragma unroll
-		for (int k = 0; k < LA; k++) advance(itd);
-#pragma unroll
-		for (int k = 0; k < LA; k++) {
-			issue(itI, id_direct(itI), itd, ring + (uint32_t)k * STAGE_BYTES);
-			advance(itI);
-			advance(itd);
-		}
+	for (int k = 0; k < LA; k++) {   // prologue bundles 0 .. LA-1 (ids by ordinary loads)
+		const uint2 e = s_bt[k], e2 = s_bt[k + LA];
+		const uint32_t n = e.y & 255u;
+		const uint32_t id = act_id[e.x + (sub < n ? sub : n - 1u)];
+		issue(e.x, id, e2.x, e2.y & 255u, ring + (uint32_t)k * STAGE_BYTES);
 	}
-	It itD = itI;
-#pragma unroll
-	for (int k = 0; k < LA; k++) advance(itD);
-	uint32_t st0 = ring, stI = ring + LA * STAGE_BYTES;   // stages of it0 and itI
+	uint32_t st0 = ring, stI = ring + LA * STAGE_BYTES;   // stages of batch j and of bundle j + LA
 	bool has_pending = false;   // S[0] holds left half rows waiting for their right-hand tile
 	bool after_stores = false;
-	while (it0.t < nt) {
-		// bundle it0 landed; the LA - 1 younger bundles -- and after an epilogue part of its stores --
+	for (uint32_t j = 0; j < J; j++) {
+		if (j + 2 * LA >= wbase + SW_JMAX) {   // (uniform, long segments only) slide the table window
+			__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+			__syncthreads();
+			wbase = j;
+			fill_table(wbase);
+			__syncthreads();
+		}
+		// this step's three table entries: batch j, j + LA, j + 2 LA
+		uint32_t e0y, eIx, eDx, eDy;
+		{
+			const uint32_t a = bt_a + (j - wbase) * 8u;
+			uint32_t r0, r1;
+			uint64_t rd;
+			asm volatile(
+				"ds_read_b32 %0, %3 offset:4\n\t"
+				"ds_read_b32 %1, %3 offset:%4\n\t"
+				"ds_read_b64 %2, %3 offset:%5\n\t"
+				"s_waitcnt lgkmcnt(0)"
+				: "=&v"(r0), "=&v"(r1), "=&v"(rd)
+				: "v"(a), "n"(LA * 8), "n"(2 * LA * 8)
+				: "memory");
+			e0y = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
+			eIx = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1);
+			eDx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rd);
+			eDy = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rd >> 32));
+		}
+		// bundle j landed; the LA - 1 younger bundles -- and after an epilogue part of its stores --
 		// may still be in flight (vmcnt is 6 bits: <= 63)
 		if (after_stores) __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (15 << 8));   // vmcnt(63)
 		else __builtin_amdgcn_s_waitcnt(((LA - 1) * SW_NDMA) | (7 << 4) | (15 << 8));
 		after_stores = false;
 		__builtin_amdgcn_s_barrier();
-		issue(itI, id_from(st0), itD, stI);   // into the stage batch it0 - 1 was computed from
-		const uint32_t n = (it0.tot - it0.q * AB) < (uint32_t)AB ? (it0.tot - it0.q * AB) : (uint32_t)AB;
-		const int tx = tx0 + it0.t;
+		{
+			uint32_t id;   // this lane's feature-row id for bundle j + LA, from the id area of bundle j
+			const uint32_t ia = st0 + 24576u + (uint32_t)wave * 256u + sub * 4u;
+			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(id) : "v"(ia) : "memory");
+			__builtin_amdgcn_sched_barrier(0);
+			issue(eIx, id, eDx, eDy & 255u, stI);   // into the stage batch j - 1 was computed from
+		}
+		const uint32_t n = e0y & 255u;
+		const int tx = tx0 + (int)((e0y >> 8) & 255u);
 		const bool is_left = ((tx + g) & 1) == 0;   // even rows: even tiles are left halves; odd rows: odd tiles
 		if (!(DBG & 2)) sweep_compute(S, st0, n, cg, g, half, l31);   // always into S[1]
-		if ((it0.q + 1) * AB >= it0.tot && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
+		if ((e0y >> 16) != 0u && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
 			const int hi = (l31 >> 4) & 1;
 			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * W;
 			const int xs = tx * SGS_TILE + (l31 & 15), xp = (tx - 1) * SGS_TILE + l31;
 			const int y0 = ty * SGS_TILE + g;
 			if (!is_left && has_pending) {   // S[0] | S[1] are whole lines
-				const bool inside = xp + 31 - l31 < W && y0 + 14 < H;   // uniform: the whole 32 x 8 block
+				const bool inside = (tx + 1) * SGS_TILE <= W && y0 + 14 < H;   // uniform: the whole 32 x 8 block
 				if (inside) sweep_store_paired<false>(S, cbp + xp, HW, W, true, y0, H);
 				else sweep_store_paired<true>(S, cbp + xp, HW, W, xp < W, y0, H);
 				after_stores = true;
-			} else if (!is_left || it0.t == nt - 1) {   // a half with no partner in this segment
+			} else if (!is_left || tx == tx0 + nt - 1) {   // a half with no partner in this segment
 				sweep_store_single<true>(S, cbp + (size_t)(2 * hi) * W + xs, HW, W, xs < W, y0 + 2 * hi, H);
 				after_stores = true;
 			}
@@ -1429,9 +1439,6 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 			has_pending = is_left;
 			sweep_zero<1>(S);
 		}
-		advance(it0);
-		advance(itI);
-		advance(itD);
 		st0 = st0 + STAGE_BYTES == ring + NST * STAGE_BYTES ? ring : st0 + STAGE_BYTES;
 		stI = stI + STAGE_BYTES == ring + NST * STAGE_BYTES ? ring : stI + STAGE_BYTES;
 	}
