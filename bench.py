@@ -226,7 +226,10 @@ def main():
             "config": {"workload": f"{args.config}: P={P} Gaussians, C={C}, {H}x{W} forward render "
                                    f"(BASELINE.md config 3 generator, seed 0)",
                        "views_per_step_per_gpu": 1, "parallelism": f"views x{world} (scene replicated)",
-                       "blend_variant": args.variant},
+                       "blend_variant": args.variant,
+                       "blend_arithmetic": ("fp32 MFMA, bit-exact" if args.variant == 15 else
+                                            "split-bf16 x3 MFMA products, fp32 accumulate (<= 5e-5 of the absolute "
+                                            "composite; SGS_BLEND_EXACT=1 selects the bit-exact fp32 MFMA path)")},
             "roofline": {"bound": "hbm", "kernel": "blend_fwd", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": traffic, "algorithmic_bytes": bytes_blend,

@@ -72,12 +72,13 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
 	uint32_t* __restrict__ act_id, float* __restrict__ wgt, uint32_t* __restrict__ table,
 	uint32_t* __restrict__ nact, uint32_t* __restrict__ counter, uint32_t capacity, int W,
-	int H, int gx, int per_xcd, int ntiles)
+	int H, int gx, int per_xcd, int ntiles, int tile_begin)
 {
 	const int b = blockIdx.x;
 	constexpr bool BF = MODE != 0;
-	const int tile = (b & 7) * per_xcd + (b >> 3);
-	if (tile >= ntiles) return;
+	const int tl = (b & 7) * per_xcd + (b >> 3);   // tiles [tile_begin, tile_begin + ntiles)
+	if (tl >= ntiles) return;
+	const int tile = tile_begin + tl;
 	const int tx = tile % gx, ty = tile / gx;
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1269,7 +1270,7 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const char* __restrict__ wgt, const float* __restrict__ features,
 	const float* __restrict__ bg, float* __restrict__ out, const uint32_t* __restrict__ counter,
-	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items)
+	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int ty0)
 {
 	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
 	const int b = blockIdx.x;
@@ -1277,7 +1278,8 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	if (v >= total_items) return;
 	const int chunk = v % nchunks_c;
 	const int rest = v / nchunks_c;
-	const int sg = rest % nseg, ty = rest / nseg;
+	const int stagger = (W & 31) == 16 ? 1 : 0;   // odd rows start 64 B into a line (else every row is aligned alike)
+	const int sg = rest % nseg, ty = ty0 + rest / nseg;   // tile rows [ty0, ...) of this band
 	const int tx0 = sg * seg;   // even (seg is even)
 	const int nt = (gx - tx0) < seg ? (gx - tx0) : seg;
 	const int lane = threadIdx.x & 63;
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 		}
 		const uint32_t n = e0y & 255u;
 		const int tx = tx0 + (int)((e0y >> 8) & 255u);
-		const bool is_left = ((tx + g) & 1) == 0;   // even rows: even tiles are left halves; odd rows: odd tiles
+		const bool is_left = ((tx + g * stagger) & 1) == 0;   // even rows: even tiles are left halves; odd rows (staggered): odd tiles
 		if (!(DBG & 2)) sweep_compute(S, st0, n, cg, g, half, l31);   // always into S[1]
 		if ((e0y >> 16) != 0u && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
 			const int hi = (l31 >> 4) & 1;
@@ -1683,6 +1685,31 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	return a.total;
 }
 
+namespace {
+// Helper stream + events for the banded overlap of the two blend kernels (one set per device).
+struct BandCtx {
+	hipStream_t wstream = nullptr;
+	hipEvent_t start = nullptr;
+	hipEvent_t wdone[8] = {};
+};
+BandCtx* band_ctx()
+{
+	static BandCtx ctx[16];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+	BandCtx& c = ctx[dev];
+	if (!c.wstream) {
+		int least = 0, greatest = 0;   // weights fill in around the sweep, not the other way round
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&c.wstream, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+		if (hipEventCreateWithFlags(&c.start, hipEventDisableTiming) != hipSuccess) return nullptr;
+		for (int i = 0; i < 8; i++)
+			if (hipEventCreateWithFlags(&c.wdone[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+	}
+	return &c;
+}
+} // namespace
+
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, int split_mode)
 {
@@ -1694,18 +1721,62 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	float* wgt = (float*)(arena + lay.wgt);
 	hipError_t e = hipMemsetAsync(counter, 0, 8, st);
 	if (e != hipSuccess) return e;
-	{
-		const int per_xcd = (ntiles + 7) / 8;
-		const int sm_ = split_mode & 15;
-#define SGS_LAUNCH_W(M_)                                                                            \
-	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,     \
-			   a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, act_id,   \
-			   wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, per_xcd, ntiles)
-		if (sm_ == 8) SGS_LAUNCH_W(2);
-		else if (sm_ == 6 || sm_ == 7) SGS_LAUNCH_W(1);
-		else SGS_LAUNCH_W(0);
-#undef SGS_LAUNCH_W
+#define SGS_LAUNCH_W(M_, ST_, T0_, NT_)                                                             \
+	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3((((NT_) + 7) / 8) * 8), dim3(256), 0, ST_,    \
+			   a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, \
+			   act_id, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx,        \
+			   ((NT_) + 7) / 8, NT_, T0_)
+	if ((split_mode & 15) == 8) {
+		// ---- row-sweep path.  The weights kernel is instruction-bound, the sweep memory-bound, and
+		// one sweep workgroup leaves room for a weights workgroup on the same CU: the image is cut
+		// into bands of tile rows, weights of band i+1 run on a helper stream while band i is swept.
+		int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) + 1 : 16;
+		if (seg > SEGMAX) seg = SEGMAX;
+		const int nseg = (a.gx + seg - 1) / seg;
+		seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
+		const int nc = a.C / 128;
+		int nbands = (split_mode >> 12) & 15;
+		if (nbands == 0) nbands = 4;
+		if (nbands > 8) nbands = 8;
+		if (nbands > a.gy) nbands = a.gy;
+		BandCtx* ctx = nbands > 1 ? band_ctx() : nullptr;
+		if (!ctx) nbands = 1;
+		if (ctx) {
+			if ((e = hipEventRecord(ctx->start, st)) != hipSuccess) return e;
+			if ((e = hipStreamWaitEvent(ctx->wstream, ctx->start, 0)) != hipSuccess) return e;
+		}
+		hipStream_t ws = ctx ? ctx->wstream : st;
+		for (int bnd = 0; bnd < nbands; bnd++) {   // all weights launches first: they only queue
+			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
+			const int t0 = r0 * a.gx, nt = (r1 - r0) * a.gx;
+			SGS_LAUNCH_W(2, ws, t0, nt);
+			if (ctx && (e = hipEventRecord(ctx->wdone[bnd], ws)) != hipSuccess) return e;
+		}
+		for (int bnd = 0; bnd < nbands; bnd++) {
+			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
+			if (ctx && (e = hipStreamWaitEvent(st, ctx->wdone[bnd], 0)) != hipSuccess) return e;
+			const int items = (r1 - r0) * nseg * nc;
+			const int pxcd = (items + 7) / 8;
+#define SGS_LAUNCH_SWEEP(D_)                                                                         \
+	hipLaunchKernelGGL(blend_accum_sweep_kernel<D_>, dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
+			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, r0)
+			switch ((split_mode >> 8) & 15) {
+			case 1: SGS_LAUNCH_SWEEP(1); break;
+			case 2: SGS_LAUNCH_SWEEP(2); break;
+			case 3: SGS_LAUNCH_SWEEP(3); break;
+			default: SGS_LAUNCH_SWEEP(0); break;
+			}
+#undef SGS_LAUNCH_SWEEP
+		}
+		return hipGetLastError();
 	}
+	{
+		const int sm_ = split_mode & 15;
+		if (sm_ == 6 || sm_ == 7) SGS_LAUNCH_W(1, st, 0, ntiles);
+		else SGS_LAUNCH_W(0, st, 0, ntiles);
+	}
+#undef SGS_LAUNCH_W
 	{
 		// split_mode: 0 = 32 channels per wave, 1 entry per scalar wait (default);
 		//             1 = (32, 2);  2 = (16, 4)
@@ -1719,26 +1790,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
 			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
 			   total, (split_mode >> 4))
-		if (sm == 8) {
-			int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) + 1 : 12;
-			if (seg > SEGMAX) seg = SEGMAX;
-			const int nseg = (a.gx + seg - 1) / seg;
-			seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
-			const int nc = a.C / 128;
-			const int items = a.gy * nseg * nc;
-			const int pxcd = (items + 7) / 8;
-#define SGS_LAUNCH_SWEEP(D_)                                                                         \
-	hipLaunchKernelGGL(blend_accum_sweep_kernel<D_>, dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
-			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
-			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items)
-			switch (split_mode >> 8) {
-			case 1: SGS_LAUNCH_SWEEP(1); break;
-			case 2: SGS_LAUNCH_SWEEP(2); break;
-			case 3: SGS_LAUNCH_SWEEP(3); break;
-			default: SGS_LAUNCH_SWEEP(0); break;
-			}
-#undef SGS_LAUNCH_SWEEP
-		} else if (sm == 7) {
+		if (sm == 7) {
 			const int stagger = (a.W % 32) == 16 ? 1 : 0;
 			const int nk = (a.gx + stagger) / 2 + 1;
 			const int nc = a.C / 128;
