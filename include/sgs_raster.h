@@ -209,7 +209,8 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.
- * stages: 0 preprocess 1 scan+readback 2 duplicate 3 sort 4 ranges 5 blend
+ * stages: 0 preprocess 1 scan+readback 2 duplicate 3 sort 4 ranges 5 blend weights pre-pass
+ *         6 blend accumulate (the whole blend on the single-kernel paths)
  * mode 0 off; 1 = resolve at the end of each call (adds a host sync per forward);
  * 2 = deferred: events are parked and sgs_get_stage_ms() returns the MEAN over all
  * forwards since the last query (no extra synchronisation inside the timed region).
@@ -221,7 +222,7 @@ int sgs_set_stage_timing(int mode);
  * bit-identical in both modes; point_offsets and the UNSORTED key/value arrays follow the
  * reference's emission order only in mode 1.  Returns the previous mode. */
 int sgs_set_binning_mode(int mode);
-int sgs_get_stage_ms(float *ms6);
+int sgs_get_stage_ms(float *ms7);
 
 #ifdef __cplusplus
 }

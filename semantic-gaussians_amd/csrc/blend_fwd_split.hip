@@ -1711,7 +1711,8 @@ BandCtx* band_ctx()
 } // namespace
 
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
-				      const SplitArena& lay, int split_mode)
+				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
+				      int split_mode)
 {
 	const int ntiles = a.gx * a.gy;
 	uint32_t* counter = (uint32_t*)(arena + lay.counter);
@@ -1755,6 +1756,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		for (int bnd = 0; bnd < nbands; bnd++) {
 			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
 			if (ctx && (e = hipStreamWaitEvent(st, ctx->wdone[bnd], 0)) != hipSuccess) return e;
+			if (bnd == 0 && mark) mark(mark_user);
 			const int items = (r1 - r0) * nseg * nc;
 			const int pxcd = (items + 7) / 8;
 #define SGS_LAUNCH_SWEEP(D_)                                                                         \
@@ -1775,6 +1777,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		const int sm_ = split_mode & 15;
 		if (sm_ == 6 || sm_ == 7) SGS_LAUNCH_W(1, st, 0, ntiles);
 		else SGS_LAUNCH_W(0, st, 0, ntiles);
+		if (mark) mark(mark_user);
 	}
 #undef SGS_LAUNCH_W
 	{

@@ -26,7 +26,7 @@ thread_local std::string g_err;
 std::atomic<int> g_blend_variant{0};
 std::atomic<int> g_stage_timing{0};
 std::atomic<int> g_binning_mode{0};   // 0 = depth-presorted emission (default), 1 = reference order
-float g_stage_ms[6] = {0, 0, 0, 0, 0, 0};
+float g_stage_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 
 int fail(int code, const std::string& msg)
 {
@@ -158,7 +158,7 @@ inline char* align_ptr(char* p) { return (char*)align_up((size_t)p, 128); }
 //   mode 2: deferred -- events are parked and resolved by sgs_get_stage_ms(), so the timed
 //           region of bench.py carries no extra synchronisation
 struct EventSet {
-	hipEvent_t ev[7];
+	hipEvent_t ev[8];
 	int n;
 };
 std::mutex g_ev_mu;
@@ -176,12 +176,12 @@ struct StageTimer {
 	}
 	void mark()
 	{
-		if (mode && es.n < 7) (void)hipEventRecord(es.ev[es.n++], st);
+		if (mode && es.n < 8) (void)hipEventRecord(es.ev[es.n++], st);
 	}
 	static void resolve(EventSet& s, float* ms)
 	{
 		(void)hipEventSynchronize(s.ev[s.n - 1]);
-		for (int i = 0; i < 6; i++) {
+		for (int i = 0; i < 7; i++) {
 			ms[i] = 0.f;
 			if (i + 1 < s.n) (void)hipEventElapsedTime(&ms[i], s.ev[i], s.ev[i + 1]);
 		}
@@ -222,7 +222,7 @@ const char* sgs_last_error(void) { return g_err.c_str(); }
 int sgs_set_blend_variant(int variant) { return g_blend_variant.exchange(variant); }
 int sgs_set_stage_timing(int enable) { return g_stage_timing.exchange(enable); }
 int sgs_set_binning_mode(int mode) { return g_binning_mode.exchange(mode); }
-int sgs_get_stage_ms(float* ms6)
+int sgs_get_stage_ms(float* ms7)
 {
 	std::vector<EventSet> parked;
 	{
@@ -230,15 +230,15 @@ int sgs_get_stage_ms(float* ms6)
 		parked.swap(g_parked);
 	}
 	if (!parked.empty()) {   // deferred mode: mean over the parked forward calls
-		double acc[6] = {0, 0, 0, 0, 0, 0};
+		double acc[7] = {0, 0, 0, 0, 0, 0, 0};
 		for (auto& s : parked) {
-			float ms[6];
+			float ms[7];
 			StageTimer::resolve(s, ms);
-			for (int i = 0; i < 6; i++) acc[i] += ms[i];
+			for (int i = 0; i < 7; i++) acc[i] += ms[i];
 		}
-		for (int i = 0; i < 6; i++) g_stage_ms[i] = (float)(acc[i] / (double)parked.size());
+		for (int i = 0; i < 7; i++) g_stage_ms[i] = (float)(acc[i] / (double)parked.size());
 	}
-	for (int i = 0; i < 6; i++) ms6[i] = g_stage_ms[i];
+	for (int i = 0; i < 7; i++) ms7[i] = g_stage_ms[i];
 	return (int)parked.size();
 }
 
@@ -455,7 +455,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.out_depth = out_depth;
 	if (use_split) {
 		char* arena = bchunk + bl.arena;
-		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, variant >= 16 ? variant : (variant == 0 ? (8 | (1 << 12)) : variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 9 ? 0 : (variant == 10 ? 3 : (variant == 11 ? 5 : (variant == 12 ? 6 : (variant == 13 ? 7 : (variant == 14 ? 8 : 4)))))))));
+		struct MarkCtx { StageTimer* t; } mctx{&tm};
+		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 0 ? (8 | (1 << 12)) : variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 9 ? 0 : (variant == 10 ? 3 : (variant == 11 ? 5 : (variant == 12 ? 6 : (variant == 13 ? 7 : (variant == 14 ? 8 : 4)))))))));
 		if (e != hipSuccess) return fail_hip(e, "blend forward (split)");
 		const uint32_t* counter = (const uint32_t*)(arena + bl.arena_lay.counter);
 		const int c_split = (num_channels / 128) * 128;
@@ -466,6 +467,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		if (e == hipSuccess && g_usage_host)
 			e = hipMemcpyAsync(g_usage_host, counter, 8, hipMemcpyDeviceToHost, st);
 	} else {
+		tm.mark();   // (no weights pre-pass on this path)
 		e = sgs::launch_blend_forward(st, a, variant == 6 ? 0 : variant);   // 6 = px4 without the split
 	}
 	if (e != hipSuccess) return fail_hip(e, "blend forward");

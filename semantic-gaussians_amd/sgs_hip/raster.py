@@ -320,7 +320,7 @@ def set_stage_timing(on):
 
 
 def get_stage_ms():
-    arr = (C.c_float * 6)()
+    arr = (C.c_float * 7)()
     _lib.load().sgs_get_stage_ms(arr)
     return [float(a) for a in arr]
 
