@@ -1142,8 +1142,8 @@ constexpr int SEGMAX = 16;   // tiles per sweep (upper bound, the launcher picks
 constexpr int SW_JMAX = 1024; // batch-table window (batches of a segment kept in LDS)
 constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
 constexpr int LA = NST - 1;
-constexpr int STAGE_BYTES = 8192 + 16384 + 2048;   // features | weights | ids of the batch LA bundles on
-constexpr int SW_NDMA = 4;   // LDS-DMA instructions per wave per bundle: 1 feature + 2 weight + 1 id
+constexpr int STAGE_BYTES = 8192 + 8192 + 1024;   // features | this parity's weights | ids of the batch LA bundles on
+constexpr int SW_NDMA = 5;   // LDS-DMA instructions per wave per bundle: 2 feature + 2 weight + 1 id
 
 // The accumulator sets are touched only through these free functions with compile-time set
 // indices (closures nested more than one level deep keep the array in scratch memory).
@@ -1171,6 +1171,31 @@ __device__ __forceinline__ void sweep_store_paired(const SweepSets& S, float* ba
 			float* dst = bp + (size_t)((r & 3) + 8 * (r >> 2)) * HW;
 			if (!GUARD || ok0) *dst = __uint_as_float(sw[0]);
 			if (!GUARD || ok1) dst[2 * (size_t)W] = __uint_as_float(sw[1]);
+		}
+	}
+}
+
+// The interior case (every lane and row inside the image) without per-store address arithmetic:
+// `global_store_dword voffset, data, s[base]` with the channel plane as a wave-uniform SGPR base
+// walked by scalar adds (planes (r & 3) + 8 (r >> 2): +1, +1, +1, +5) and one 32-bit byte offset
+// per lane and pixel block.  Inline asm keeps the compiler from tabulating the 16 bases (it runs
+// out of SGPRs and falls back to 64-bit VGPR addresses: ~2 VALU per store, 256 per tile and wave).
+// ubase = &out[c0][0][0] (uniform); loff = byte offset of [4*half][ty*16 + g][xl0 + (lane & 31)]
+__device__ __forceinline__ void sweep_store_paired_fast(const SweepSets& S, const float* ubase, uint32_t loff,
+							size_t HW, int W)
+{
+	const uint64_t plane = (uint64_t)HW * 4u;
+#pragma unroll
+	for (int pb = 0; pb < 4; pb++) {
+		const uint32_t o0 = loff + (uint32_t)(4 * pb * W) * 4u, o1 = o0 + (uint32_t)(2 * W) * 4u;
+		uint64_t sb = (uint64_t)ubase;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(S[0][pb][r]),
+									 __float_as_uint(S[1][pb][r]), false, false);
+			asm volatile("global_store_dword %0, %1, %2" : : "v"(o0), "v"(sw[0]), "s"(sb) : "memory");
+			asm volatile("global_store_dword %0, %1, %2" : : "v"(o1), "v"(sw[1]), "s"(sb) : "memory");
+			sb += ((r & 3) == 3 ? 5u : 1u) * plane;
 		}
 	}
 }
@@ -1206,10 +1231,10 @@ __device__ __forceinline__ void sweep_zero(SweepSets& S)
 // may alias an LDS-DMA destination and drain the bundles in flight (cdna_hip_programming.md
 // 5.7: early-clobber outputs, nothing consumes an output before the explicit lgkmcnt(0), that
 // wait takes the values as "+v").
-__device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_t n, int cg, int g, int half, int l31)
+__device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_t n, int cg, int half, int l31)
 {
-	const uint32_t fa = st + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;                     // + kk * 512
-	const uint32_t wa = st + 8192u + (uint32_t)half * 8192u + (uint32_t)(g * 128 + l31) * 16u;      // + pb * 512 (+ 4096 lo)
+	const uint32_t fa = st + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;   // + kk * 512
+	const uint32_t wa = st + 8192u + (uint32_t)half * 4096u + (uint32_t)l31 * 16u;  // + pb * 512 (+ 2048 lo)
 	float f[8];
 	v4i bh, bl;
 	asm volatile(
@@ -1222,20 +1247,20 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 		"ds_read_b32 %6, %10 offset:3072\n\t"
 		"ds_read_b32 %7, %10 offset:3584\n\t"
 		"ds_read_b128 %8, %11\n\t"
-		"ds_read_b128 %9, %11 offset:4096\n\t"
+		"ds_read_b128 %9, %11 offset:2048\n\t"
 		"s_waitcnt lgkmcnt(0)"
 		: "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]),
 		  "=&v"(f[7]), "=&v"(bh), "=&v"(bl)
 		: "v"(fa), "v"(wa)
 		: "memory");
 	__builtin_amdgcn_sched_barrier(0);
-	const int nrel = (int)n - 8 * half;   // live entries of this lane's k-group
+	// (rows past n hold a clamped duplicate of the last entry; their weights are zero)
+	(void)n;
 	bf16x8 ah, al;
 #pragma unroll
 	for (int kk = 0; kk < 8; kk++) {
-		const float fv = kk < nrel ? f[kk] : 0.f;   // padding rows hold a clamped duplicate (weights are 0)
-		ah[kk] = (__bf16)fv;
-		al[kk] = (__bf16)(fv - (float)ah[kk]);
+		ah[kk] = (__bf16)f[kk];
+		al[kk] = (__bf16)(f[kk] - (float)ah[kk]);
 	}
 #pragma unroll
 	for (int pb = 0; pb < 4; pb++) {   // the next block's operands fly while this block multiplies
@@ -1244,7 +1269,7 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 			const uint32_t wn = wa + (uint32_t)(pb + 1) * 512u;
 			asm volatile(
 				"ds_read_b128 %0, %2\n\t"
-				"ds_read_b128 %1, %2 offset:4096"
+				"ds_read_b128 %1, %2 offset:2048"
 				: "=&v"(nh), "=&v"(nl)
 				: "v"(wn)
 				: "memory");
@@ -1262,10 +1287,13 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 	}
 }
 
-// 512 lanes: wave w = channel group (w & 3) x row parity (w >> 2).
+// One workgroup = (tile-row segment, 128 channels, row parity g): 4 waves = 4 channel groups of 32.
+// The two parities are separate workgroups (two per CU) so that one's store phase overlaps the
+// other's multiply phase; each fetches the features (the second copy comes from L2) and its own
+// half of the weights.
 // DBG (development ablations, 0 in production): 1 = no stores, 2 = no matrix work.
 template <int DBG>
-__global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
+__global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const char* __restrict__ wgt, const float* __restrict__ features,
@@ -1277,14 +1305,15 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	const int v = (b & 7) * per_xcd + (b >> 3);
 	if (v >= total_items) return;
 	const int chunk = v % nchunks_c;
-	const int rest = v / nchunks_c;
+	const int g = (v / nchunks_c) & 1;   // row parity of this workgroup
+	const int rest = v / (2 * nchunks_c);
 	const int stagger = (W & 31) == 16 ? 1 : 0;   // odd rows start 64 B into a line (else every row is aligned alike)
 	const int sg = rest % nseg, ty = ty0 + rest / nseg;   // tile rows [ty0, ...) of this band
 	const int tx0 = sg * seg;   // even (seg is even)
 	const int nt = (gx - tx0) < seg ? (gx - tx0) : seg;
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int cg = wave & 3, g = wave >> 2;
+	const int cg = wave;
 	const int half = lane >> 5, l31 = lane & 31;
 	const int cbase = chunk * 128;
 	const int c0 = cbase + cg * 32;
@@ -1317,19 +1346,20 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	auto fill_table = [&](uint32_t wbase) __attribute__((always_inline)) {
 		uint32_t maxnb = 0;
 		for (int t = 0; t < nt; t++) maxnb = max(maxnb, s_pref[t + 1] - s_pref[t]);
-		for (uint32_t qb = 0; qb < maxnb; qb += 32) {   // 32 batches of each of 16 tiles per pass
-			const int t = threadIdx.x >> 5;
-			const uint32_t q = qb + (threadIdx.x & 31);
-			if (t < nt) {
-				const uint32_t p0 = s_pref[t], nb = s_pref[t + 1] - p0;
-				if (q < nb && p0 + q >= wbase && p0 + q < wbase + SW_JMAX) {
-					const uint32_t tot = s_tot[t], first = q * AB;
-					const uint32_t slot = table[s_cb[t] + (first >> 7)] + (first & 127u);
-					const uint32_t n = (tot - first) < (uint32_t)AB ? (tot - first) : (uint32_t)AB;
-					s_bt[p0 + q - wbase] = make_uint2(slot, n | ((uint32_t)t << 8) | (q + 1 == nb ? 1u << 16 : 0u));
+		for (int tb = 0; tb < nt; tb += 8)   // 8 tiles x 32 batches per pass
+			for (uint32_t qb = 0; qb < maxnb; qb += 32) {
+				const int t = tb + (int)(threadIdx.x >> 5);
+				const uint32_t q = qb + (threadIdx.x & 31);
+				if (t < nt) {
+					const uint32_t p0 = s_pref[t], nb = s_pref[t + 1] - p0;
+					if (q < nb && p0 + q >= wbase && p0 + q < wbase + SW_JMAX) {
+						const uint32_t tot = s_tot[t], first = q * AB;
+						const uint32_t slot = table[s_cb[t] + (first >> 7)] + (first & 127u);
+						const uint32_t n = (tot - first) < (uint32_t)AB ? (tot - first) : (uint32_t)AB;
+						s_bt[p0 + q - wbase] = make_uint2(slot, n | ((uint32_t)t << 8) | (q + 1 == nb ? 1u << 16 : 0u));
+					}
 				}
 			}
-		}
 		// past the end: 2 LA dummy batches (re-reads of a valid batch, never consumed)
 		if (threadIdx.x < 2 * LA && J + threadIdx.x >= wbase && J + threadIdx.x - wbase < SW_JMAX)
 			s_bt[J + threadIdx.x - wbase] = make_uint2(table[s_cb[nt - 1]], 1u | ((uint32_t)(nt - 1) << 8));
@@ -1339,15 +1369,21 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 
 	const uint32_t ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_ring;
 	const uint32_t bt_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_bt;
-	const uint32_t sub = (uint32_t)(2 * wave + half);   // the entry (of 16) whose feature row this lane fetches
-	// bundle = features + weights of the batch at `slot` into stage st, and the ids of the batch
-	// (slot2, n2) into its id area.  Every wave issues exactly SW_NDMA DMA instructions.
-	auto issue = [&](uint32_t slot, uint32_t id, uint32_t slot2, uint32_t n2, uint32_t st) __attribute__((always_inline)) {
-		const float* row = id == SGS_BG_ID ? bg : features + (size_t)id * C;
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + cbase + l31 * 4),
-						 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(2 * wave) * 512u),
+	const uint32_t sub = (uint32_t)(4 * wave + half);   // this lane fetches the feature rows of entries sub and sub + 2
+	// bundle = features + this parity's weights of the batch at `slot` into stage st, and the ids of
+	// the batch (slot2, n2) into its id area.  Every wave issues exactly SW_NDMA DMA instructions.
+	auto issue = [&](uint32_t slot, uint32_t id0, uint32_t id1, uint32_t slot2, uint32_t n2, uint32_t st) __attribute__((always_inline)) {
+		const float* row0 = id0 == SGS_BG_ID ? bg : features + (size_t)id0 * C;
+		const float* row1 = id1 == SGS_BG_ID ? bg : features + (size_t)id1 * C;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row0 + cbase + l31 * 4),
+						 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(4 * wave) * 512u),
 						 16, 0, 0);
-		const char* wsrc = wgt + (size_t)(slot >> 3) * 8192 + (size_t)(wave * 2) * 1024 + (size_t)lane * 16;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row1 + cbase + l31 * 4),
+						 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(4 * wave + 2) * 512u),
+						 16, 0, 0);
+		// weights piece `wave` = (k-group wave >> 1, hi/lo wave & 1): this parity's 2 KB half
+		const char* wsrc = wgt + (size_t)((slot >> 3) + (wave >> 1)) * 8192 + (size_t)(wave & 1) * 4096 +
+				   (size_t)g * 2048 + (size_t)lane * 16;
 #pragma unroll
 		for (int j = 0; j < 2; j++)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + j * 1024),
@@ -1355,7 +1391,7 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 							 16, 0, 0);
 		const uint32_t li = (uint32_t)(lane & 15) < n2 ? (uint32_t)(lane & 15) : n2 - 1u;
 		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(act_id + slot2 + li),
-						 (__attribute__((address_space(3))) void*)(size_t)(st + 24576u + (uint32_t)wave * 256u),
+						 (__attribute__((address_space(3))) void*)(size_t)(st + 16384u + (uint32_t)wave * 256u),
 						 4, 0, 0);
 	};
 
@@ -1370,8 +1406,9 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 	for (int k = 0; k < LA; k++) {   // prologue bundles 0 .. LA-1 (ids by ordinary loads)
 		const uint2 e = s_bt[k], e2 = s_bt[k + LA];
 		const uint32_t n = e.y & 255u;
-		const uint32_t id = act_id[e.x + (sub < n ? sub : n - 1u)];
-		issue(e.x, id, e2.x, e2.y & 255u, ring + (uint32_t)k * STAGE_BYTES);
+		const uint32_t id0 = act_id[e.x + (sub < n ? sub : n - 1u)];
+		const uint32_t id1 = act_id[e.x + (sub + 2u < n ? sub + 2u : n - 1u)];
+		issue(e.x, id0, id1, e2.x, e2.y & 255u, ring + (uint32_t)k * STAGE_BYTES);
 	}
 	uint32_t st0 = ring, stI = ring + LA * STAGE_BYTES;   // stages of batch j and of bundle j + LA
 	bool has_pending = false;   // S[0] holds left half rows waiting for their right-hand tile
@@ -1410,16 +1447,17 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 		after_stores = false;
 		__builtin_amdgcn_s_barrier();
 		{
-			uint32_t id;   // this lane's feature-row id for bundle j + LA, from the id area of bundle j
-			const uint32_t ia = st0 + 24576u + (uint32_t)wave * 256u + sub * 4u;
-			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(id) : "v"(ia) : "memory");
+			uint32_t id0, id1;   // this lane's feature-row ids for bundle j + LA, from the id area of bundle j
+			const uint32_t ia = st0 + 16384u + (uint32_t)wave * 256u + sub * 4u;
+			asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+				     : "=&v"(id0), "=&v"(id1) : "v"(ia) : "memory");
 			__builtin_amdgcn_sched_barrier(0);
-			issue(eIx, id, eDx, eDy & 255u, stI);   // into the stage batch j - 1 was computed from
+			issue(eIx, id0, id1, eDx, eDy & 255u, stI);   // into the stage batch j - 1 was computed from
 		}
 		const uint32_t n = e0y & 255u;
 		const int tx = tx0 + (int)((e0y >> 8) & 255u);
 		const bool is_left = ((tx + g * stagger) & 1) == 0;   // even rows: even tiles are left halves; odd rows (staggered): odd tiles
-		if (!(DBG & 2)) sweep_compute(S, st0, n, cg, g, half, l31);   // always into S[1]
+		if (!(DBG & 2)) sweep_compute(S, st0, n, cg, half, l31);   // always into S[1]
 		if ((e0y >> 16) != 0u && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
 			const int hi = (l31 >> 4) & 1;
 			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * W;
@@ -1427,7 +1465,10 @@ __global__ __launch_bounds__(512, 1) void blend_accum_sweep_kernel(
 			const int y0 = ty * SGS_TILE + g;
 			if (!is_left && has_pending) {   // S[0] | S[1] are whole lines
 				const bool inside = (tx + 1) * SGS_TILE <= W && y0 + 14 < H;   // uniform: the whole 32 x 8 block
-				if (inside) sweep_store_paired<false>(S, cbp + xp, HW, W, true, y0, H);
+				if (inside && (DBG & 4)) sweep_store_paired<false>(S, cbp + xp, HW, W, true, y0, H);
+				else if (inside)
+					sweep_store_paired_fast(S, out + (size_t)c0 * HW,
+								((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)(y0 * W + xp)) * 4u, HW, W);
 				else sweep_store_paired<true>(S, cbp + xp, HW, W, xp < W, y0, H);
 				after_stores = true;
 			} else if (!is_left || tx == tx0 + nt - 1) {   // a half with no partner in this segment
@@ -1757,16 +1798,17 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
 			if (ctx && (e = hipStreamWaitEvent(st, ctx->wdone[bnd], 0)) != hipSuccess) return e;
 			if (bnd == 0 && mark) mark(mark_user);
-			const int items = (r1 - r0) * nseg * nc;
+			const int items = (r1 - r0) * nseg * nc * 2;   // x 2 row parities
 			const int pxcd = (items + 7) / 8;
 #define SGS_LAUNCH_SWEEP(D_)                                                                         \
-	hipLaunchKernelGGL(blend_accum_sweep_kernel<D_>, dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+	hipLaunchKernelGGL(blend_accum_sweep_kernel<D_>, dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, r0)
 			switch ((split_mode >> 8) & 15) {
 			case 1: SGS_LAUNCH_SWEEP(1); break;
 			case 2: SGS_LAUNCH_SWEEP(2); break;
 			case 3: SGS_LAUNCH_SWEEP(3); break;
+			case 4: SGS_LAUNCH_SWEEP(4); break;
 			default: SGS_LAUNCH_SWEEP(0); break;
 			}
 #undef SGS_LAUNCH_SWEEP

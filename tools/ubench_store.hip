@@ -9,7 +9,8 @@
 constexpr int W = 1296, H = 968, C = 512, GX = 81, GY = 61, NT = GX * GY;
 
 template <int MODE>
-__global__ __launch_bounds__(256) void store_kernel(float* __restrict__ out, int per_xcd, int total)
+__global__ __launch_bounds__(256) void store_kernel(float* __restrict__ out, int per_xcd, int total,
+							  const float4* __restrict__ src = nullptr, float* __restrict__ sink = nullptr)
 {
 	const int b = blockIdx.x;
 	const int v = (b & 7) * per_xcd + (b >> 3);
@@ -24,7 +25,19 @@ __global__ __launch_bounds__(256) void store_kernel(float* __restrict__ out, int
 	const int cgrp = wave & 1, pgrp = wave >> 1, half = lane >> 5, l31 = lane & 31;
 	const size_t HW = (size_t)H * W;
 	const int tx = tile % GX, ty = tile / GX;
-	const float val = (float)v;
+	float val = (float)v;
+	if (src) {   // mixed traffic: 64 KB of reads per workgroup (1.3 GB in all), hashed 4-KB runs, before the stores
+		float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+		const size_t nruns = (size_t)1 << 18;   // 1 GiB source / 4 KB
+#pragma unroll 4
+		for (int i = 0; i < 16; i++) {
+			const size_t run = ((size_t)v * 16 + i) * 2654435761ull % nruns;
+			const float4 x = src[run * 256 + threadIdx.x];
+			acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+		}
+		val += (acc.x + acc.y + acc.z + acc.w) * 1e-30f;
+		if (val == 12345.678f) sink[0] = val;
+	}
 	if (MODE == 0) {   // contiguous 128 KB per workgroup, 256 B per wave store
 		float* base = out + (size_t)v * 32768 + wave * 8192 + lane;
 #pragma unroll 8
@@ -62,13 +75,18 @@ __global__ __launch_bounds__(256) void store_kernel(float* __restrict__ out, int
 				}
 			}
 		}
-	} else if (MODE == 15 || MODE == 16) {
+	} else if (MODE == 15 || MODE == 16 || MODE == 17) {
 		// staggered tile pairs x 64 channels: even rows x in [32k, 32k+32), odd rows x in [32k+16, 32k+48):
 		// every 128-B line of the (pitch 5184) image is owned by ONE workgroup.
 		// 15: wave 0/1 write the left/right 64-B halves of even rows, wave 2/3 of odd rows (same time)
 		// 16: one wave store = 2 complete lines (waves 0,1: even rows, 4 rows each; 2,3: odd rows)
-		const int pair = v >> 3, sub = v & 7;
 		const int npx = (GX + 1) / 2 + 1;
+		int pair = v >> 3, sub = v & 7;
+		if (MODE == 17) {   // x-major: the 8 channel groups of a tile row are 8 consecutive sweeps over its pairs
+			const int row = v / (npx * 8), i = v - row * npx * 8;
+			sub = i / npx;
+			pair = row * npx + (i - sub * npx);
+		}
 		const int pk = pair % npx, pty = pair / npx;
 		if (pty >= GY) return;
 		if (MODE == 15) {
@@ -154,32 +172,40 @@ int main()
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
 	hipEventCreate(&e1);
-	const char* names[17] = {"contiguous 128 KB per WG", "blend epilogue pattern (4 x 64 B per store)",
-				"tile pairs (2 x 128 B per store)", "epilogue pattern, nontemporal", "tile quads (256 B per store)", "epilogue pattern, chunk-major block order", "hashed 512-B runs", "hashed 1-KB runs", "hashed 2-KB runs", "hashed 4-KB runs", "hashed 16-KB runs", "tile pairs, pitch 1312 (aligned 128-B runs)", "hashed 64-B runs", "hashed 128-B runs", "hashed 256-B runs", "staggered pairs, half lines from 2 waves", "staggered pairs, full lines per store"};
-	for (int mode = 0; mode < 17; mode++) {
+	const char* names[18] = {"contiguous 128 KB per WG", "blend epilogue pattern (4 x 64 B per store)",
+				"tile pairs (2 x 128 B per store)", "epilogue pattern, nontemporal", "tile quads (256 B per store)", "epilogue pattern, chunk-major block order", "hashed 512-B runs", "hashed 1-KB runs", "hashed 2-KB runs", "hashed 4-KB runs", "hashed 16-KB runs", "tile pairs, pitch 1312 (aligned 128-B runs)", "hashed 64-B runs", "hashed 128-B runs", "hashed 256-B runs", "staggered pairs, half lines from 2 waves", "staggered pairs, full lines per store", "as 16, consecutive workgroups along x"};
+	float4* src;
+	float* sink;
+	hipMalloc(&src, (size_t)1 << 30);
+	hipMalloc(&sink, 64);
+	hipMemset(src, 0, (size_t)1 << 30);
+	for (int pass = 0; pass < 2; pass++)
+	for (int mode = 0; mode < 18; mode++) {
+		if (pass == 1 && mode != 0 && mode != 1 && mode != 16 && mode != 17) continue;
 		const int total = (mode >= 15) ? ((GX + 1) / 2 + 1) * GY * 8 : (mode == 2 || mode == 11) ? ((GX + 1) / 2) * GY * 8 : (mode == 4 ? ((GX + 3) / 4) * GY * 16 : NT * 4);
 		const int per_xcd = (total + 7) / 8;
 		float best = 1e9f;
 		for (int rep = 0; rep < 6; rep++) {
 			hipEventRecord(e0);
 			switch (mode) {
-			case 0: hipLaunchKernelGGL(store_kernel<0>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 1: hipLaunchKernelGGL(store_kernel<1>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 2: hipLaunchKernelGGL(store_kernel<2>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 3: hipLaunchKernelGGL(store_kernel<3>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 4: hipLaunchKernelGGL(store_kernel<4>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 5: hipLaunchKernelGGL(store_kernel<5>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 6: hipLaunchKernelGGL(store_kernel<6>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 7: hipLaunchKernelGGL(store_kernel<7>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 8: hipLaunchKernelGGL(store_kernel<8>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 9: hipLaunchKernelGGL(store_kernel<9>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 10: hipLaunchKernelGGL(store_kernel<10>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 11: hipLaunchKernelGGL(store_kernel<11>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 12: hipLaunchKernelGGL(store_kernel<12>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 13: hipLaunchKernelGGL(store_kernel<13>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 14: hipLaunchKernelGGL(store_kernel<14>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 15: hipLaunchKernelGGL(store_kernel<15>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
-			case 16: hipLaunchKernelGGL(store_kernel<16>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total); break;
+			case 0: hipLaunchKernelGGL(store_kernel<0>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 1: hipLaunchKernelGGL(store_kernel<1>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 2: hipLaunchKernelGGL(store_kernel<2>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 3: hipLaunchKernelGGL(store_kernel<3>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 4: hipLaunchKernelGGL(store_kernel<4>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 5: hipLaunchKernelGGL(store_kernel<5>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 6: hipLaunchKernelGGL(store_kernel<6>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 7: hipLaunchKernelGGL(store_kernel<7>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 8: hipLaunchKernelGGL(store_kernel<8>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 9: hipLaunchKernelGGL(store_kernel<9>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 10: hipLaunchKernelGGL(store_kernel<10>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 11: hipLaunchKernelGGL(store_kernel<11>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 12: hipLaunchKernelGGL(store_kernel<12>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 13: hipLaunchKernelGGL(store_kernel<13>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 14: hipLaunchKernelGGL(store_kernel<14>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 15: hipLaunchKernelGGL(store_kernel<15>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 16: hipLaunchKernelGGL(store_kernel<16>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 17: hipLaunchKernelGGL(store_kernel<17>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
 			}
 			hipEventRecord(e1);
 			hipEventSynchronize(e1);
@@ -187,7 +213,7 @@ int main()
 			hipEventElapsedTime(&ms, e0, e1);
 			if (rep > 0 && ms < best) best = ms;
 		}
-		printf("mode %d  %-46s %.3f ms  %.2f TB/s\n", mode, names[mode], best, bytes / best * 1e-9);
+		printf("%s mode %d  %-46s %.3f ms  %.2f TB/s written%s\n", pass ? "R+W" : "W  ", mode, names[mode], best, bytes / best * 1e-9, pass ? " (+1.3 GB read)" : "");
 	}
 	return 0;
 }
