@@ -40,11 +40,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-struct StagedEntryW {   // 32 B per list entry in LDS
+struct StagedEntryW {   // 40 B per list entry in LDS
 	float a2, b2, c2, o;
 	float x, y;
 	uint32_t id;
-	float thr;   // prefilter: no pixel with power < thr can pass the alpha test
+	float thr;      // prefilter: no pixel with power < thr can pass the alpha test
+	uint32_t idx1;  // 1-based position in the tile's list (n_contrib bookkeeping)
+	uint32_t pad;
 };
 
 constexpr int WB = 32;    // list entries per batch
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	__shared__ StagedEntryW s_e[WB];
 	__shared__ float s_wt[(WB + 3) * 256]; // [entry][strip*64 + lane] (+ padding entries)
 	__shared__ uint32_t s_amask;           // entries of the batch taken by at least one pixel
+	__shared__ int s_nkeep;                // entries of the batch that survive the tile-level rejection
 	__shared__ int s_alive[4];
 	__shared__ uint32_t s_cnt, s_mask, s_ovf;
 	__shared__ uint32_t s_chunk[64];   // first slot of each chunk (re-read from `table` beyond 64)
@@ -132,8 +135,9 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		const int alive = s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3];
 		if (!alive) break;
 		const int n = (n_total - base) < WB ? (n_total - base) : WB;
-		if ((int)threadIdx.x < WB) {
+		if ((int)threadIdx.x < WB) {   // (the first 32 lanes of wave 0)
 			StagedEntryW e;
+			bool keep = false;
 			if ((int)threadIdx.x < n) {
 				const uint32_t id = point_list[range.x + base + threadIdx.x];
 				const float2 xy = means2D[id];
@@ -145,28 +149,61 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 				e.x = xy.x;
 				e.y = xy.y;
 				e.id = id;
+				e.idx1 = (uint32_t)(base + (int)threadIdx.x + 1);
 				// prefilter threshold: alpha = o * exp(power) >= 1/255 needs power >= ln(1 / (255 o)).
 				// 1 % below it (the contract exp is good to 5 ulp, __logf to ~1e-6) a pixel
 				// provably fails the alpha test; anything else goes through the exact path.
 				e.thr = __logf(1.0f / (255.0f * co.w)) - 0.01f;
-			} else {   // padding up to a multiple of 4: an entry nothing can take
-				e.a2 = e.b2 = e.c2 = e.o = e.x = e.y = 0.f;
-				e.id = 0u;
-				e.thr = __builtin_inff();
+				// tile-level rejection: the exact maximum of the (concave) quadratic form over the
+				// tile's pixel box; below the threshold no pixel of the tile can take the entry.
+				keep = true;
+				if (e.a2 < 0.f && e.c2 < 0.f && 4.f * e.a2 * e.c2 - e.b2 * e.b2 > 0.f) {
+					const float dxl = xy.x - (float)(tx * SGS_TILE + SGS_TILE - 1) - 0.01f;
+					const float dxh = xy.x - (float)(tx * SGS_TILE) + 0.01f;
+					const float dyl = xy.y - (float)(ty * SGS_TILE + SGS_TILE - 1) - 0.01f;
+					const float dyh = xy.y - (float)(ty * SGS_TILE) + 0.01f;
+					if (!(dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f)) {
+						float qmax = -__builtin_inff();
+#pragma unroll
+						for (int k = 0; k < 2; k++) {
+							const float ex = k ? dxh : dxl;   // edge dx = ex
+							const float sy = fmin_(fmax_(-e.b2 * ex / (2.f * e.c2), dyl), dyh);
+							qmax = fmax_(qmax, e.a2 * ex * ex + e.b2 * ex * sy + e.c2 * sy * sy);
+							const float ey = k ? dyh : dyl;   // edge dy = ey
+							const float sx = fmin_(fmax_(-e.b2 * ey / (2.f * e.a2), dxl), dxh);
+							qmax = fmax_(qmax, e.a2 * sx * sx + e.b2 * sx * ey + e.c2 * ey * ey);
+						}
+						keep = !(qmax < e.thr - 0.01f);
+					}
+				}
 			}
-			s_e[threadIdx.x] = e;
+			// compact the kept entries (order preserved), pad to a multiple of 4 with null entries
+			const uint32_t km = (uint32_t)__ballot(keep);
+			const int nk = __popc(km);
+			if (keep) s_e[__popc(km & ((1u << threadIdx.x) - 1u))] = e;
+			if ((int)threadIdx.x < ((nk + 3) & ~3) - nk) {
+				StagedEntryW z;
+				z.a2 = z.b2 = z.c2 = z.o = z.x = z.y = 0.f;
+				z.id = 0u;
+				z.idx1 = 0u;
+				z.thr = __builtin_inff();
+				s_e[nk + threadIdx.x] = z;
+			}
+			if (threadIdx.x == 0) s_nkeep = nk;
 		}
 		if (threadIdx.x == 0) s_amask = 0u;
 		__syncthreads();
+		const int nkeep = s_nkeep;   // entries of this batch some pixel of the tile might take
 		// ---- weight phase: wave w evaluates strip w for the whole batch.  The quadratic form of
 		// four entries is evaluated together (independent, ILP); an entry then runs the exp /
 		// alpha / transmittance chain only if some pixel of the strip can pass the alpha test
 		// (wave-uniform branch) -- for ~60 % of the (strip, entry) pairs none can.
 		if (wave_alive) {
 			uint32_t act = 0u;   // entries of this batch taken by some pixel of this strip
-			const int n4 = (n + 3) & ~3;
+			const int n4 = (nkeep + 3) & ~3;
 			for (int j0 = 0; j0 < n4; j0 += 4) {
 				float power[4], opac[4];
+				uint32_t idx1[4];
 				bool pre[4];
 #pragma unroll
 				for (int u = 0; u < 4; u++) {
@@ -175,6 +212,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 					power[u] = __builtin_fmaf(e.b2 * dx, dy,
 								  __builtin_fmaf(e.c2 * dy, dy, (e.a2 * dx) * dx));
 					opac[u] = e.o;
+					idx1[u] = e.idx1;
 					pre[u] = !(power[u] > 0.0f) && !(power[u] < e.thr);
 				}
 #pragma unroll
@@ -192,7 +230,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 						if (take) {
 							w = alpha * T;
 							T = test_T;
-							last = (uint32_t)(base + j + 1);
+							last = idx1[u];
 						}
 						if (__ballot(take) != 0ull) act |= 1u << j;
 					}
@@ -201,7 +239,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			}
 			if (lane == 0 && act != 0u) atomicOr(&s_amask, act);
 		} else {
-			for (int j = 0; j < n; j++) s_wt[j * 256 + wave * 64 + lane] = 0.0f;
+			for (int j = 0; j < nkeep; j++) s_wt[j * 256 + wave * 64 + lane] = 0.0f;
 		}
 		__syncthreads();
 		// ---- compaction into the tile's contiguous chunks
