@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_pair_kernel(
 //
 // Wave tile 32 channels x 256 px (8 MFMA blocks, parity-major pixel order: blocks 0-3 even
 // rows, 4-7 odd rows); batch = 16 entries; two LDS stages of 8 KB features + 16 KB weights.
-constexpr int SEGMAX = 16;   // tiles per sweep (upper bound, the launcher picks the length)
+constexpr int SEGMAX = 96;   // tiles per sweep (upper bound, the launcher picks the length)
 constexpr int SW_JMAX = 1024; // batch-table window (batches of a segment kept in LDS)
 constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
 constexpr int LA = NST - 1;
@@ -1810,23 +1810,29 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// ---- row-sweep path.  The weights kernel is instruction-bound, the sweep memory-bound, and
 		// one sweep workgroup leaves room for a weights workgroup on the same CU: the image is cut
 		// into bands of tile rows, weights of band i+1 run on a helper stream while band i is swept.
-		int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) + 1 : 16;
+		// segment length: long sweeps amortise the prologue and leave few half-line stores at segment
+		// ends (cfg3: 48 -> 2 segments per tile row is 3 % faster than 16), but there must be enough
+		// workgroups to fill 256 CUs x 2 a few times over.
+		const int nc = a.C / 128;
+		int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) * 8 : 48;
 		if (seg > SEGMAX) seg = SEGMAX;
+		if (((split_mode >> 4) & 15) == 0)
+			while (seg > 8 && (long long)a.gy * ((a.gx + seg - 1) / seg) * nc * 2 < 1536) seg /= 2;
 		const int nseg = (a.gx + seg - 1) / seg;
 		seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
-		const int nc = a.C / 128;
 		int nbands = (split_mode >> 12) & 15;
 		if (nbands == 0) nbands = 4;
 		if (nbands > 8) nbands = 8;
 		if (nbands > a.gy) nbands = a.gy;
-		BandCtx* ctx = nbands > 1 ? band_ctx() : nullptr;
-		if (!ctx) nbands = 1;
+		const bool serial = ((split_mode >> 16) & 1) != 0;   // bands back to back on `st`: a band's weights stay in the 256-MB Infinity Cache
+		BandCtx* ctx = (nbands > 1 && !serial) ? band_ctx() : nullptr;
+		if (!ctx && !serial) nbands = 1;
 		if (ctx) {
 			if ((e = hipEventRecord(ctx->start, st)) != hipSuccess) return e;
 			if ((e = hipStreamWaitEvent(ctx->wstream, ctx->start, 0)) != hipSuccess) return e;
 		}
 		hipStream_t ws = ctx ? ctx->wstream : st;
-		for (int bnd = 0; bnd < nbands; bnd++) {   // all weights launches first: they only queue
+		for (int bnd = 0; bnd < nbands && !serial; bnd++) {   // all weights launches first: they only queue
 			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
 			const int t0 = r0 * a.gx, nt = (r1 - r0) * a.gx;
 			SGS_LAUNCH_W(2, ws, t0, nt);
@@ -1834,6 +1840,10 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		}
 		for (int bnd = 0; bnd < nbands; bnd++) {
 			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
+			if (serial) {
+				const int t0 = r0 * a.gx, nt = (r1 - r0) * a.gx;
+				SGS_LAUNCH_W(2, st, t0, nt);
+			}
 			if (ctx && (e = hipStreamWaitEvent(st, ctx->wdone[bnd], 0)) != hipSuccess) return e;
 			if (bnd == 0 && mark) mark(mark_user);
 			const int items = (r1 - r0) * nseg * nc * 2;   // x 2 row parities
