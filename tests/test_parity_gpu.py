@@ -40,7 +40,8 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0,
     from sgs_hip import raster
     if exact is None:   # the C >= 128 default (0) and variants 12-14 accumulate in split bf16; all else is bit-exact
         Cn = 3 if kw.get("shs") is not None else (scene.features.shape[1] if kw.get("colors") is None else kw["colors"].shape[1])
-        exact = not (variant in (0, 12, 13, 14) and Cn >= 128 and not want_depth)
+        bf16 = variant in (0, 12, 13, 14) or (variant >= 16 and (variant & 15) in (6, 7, 8))
+        exact = not (bf16 and Cn >= 128 and not want_depth)
     fw = oracle_forward(orc, scene, cam, want_depth=want_depth, **kw)
     raster.set_binning_mode(binning_mode)
     try:
@@ -116,6 +117,19 @@ def test_forward_split_bf16_within_tolerance(orc, variant, C, W, H):
     (staggered pairs), W % 32 == 0, ragged W and a single tile."""
     scene, cam = small_scene(P=3000, C=C, W=W, H=H, fx=170.0, seed=C + W)
     _check_forward(orc, scene, cam, variant=variant)
+
+
+def test_forward_sweep_long_lists(orc):
+    """Dense scene, wide image: ~50 tiles per sweep segment with several hundred active entries each,
+    so the sweep kernel's batch-table window (1024 batches) has to slide, chunk tables run past
+    one chunk per tile and the id ring crosses many tile boundaries."""
+    scene, cam = small_scene(P=40000, C=128, W=784, H=32, fx=600.0, seed=77)
+    scene = scene._replace(scales=scene.scales * 3.0, opacities=scene.opacities * 0.05)
+    fw = _check_forward(orc, scene, cam)
+    ranges = fw["ranges"].reshape(-1, 2)
+    assert (ranges[:, 1] - ranges[:, 0]).max() > 2000 and fw["n_contrib"].max() > 900
+    _check_forward(orc, scene, cam, variant=8 + 4096 + 16 * 6)   # one 49-tile segment: ~2900 batches, the window slides
+    _check_forward(orc, scene, cam, variant=15)                  # and the exact path on the same lists
 
 
 @pytest.mark.parametrize("C", [1, 3, 20, 21, 32, 33, 64, 160, 256, 768])
