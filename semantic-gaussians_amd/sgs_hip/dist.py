@@ -46,6 +46,31 @@ def render_views_sharded(render_fn, views, gather_to=0):
     return [merged[i] for i in range(len(views))]
 
 
+def render_views_pipelined(render_fn, views, in_flight=2, device=None):
+    """Render `views` on one GPU keeping `in_flight` of them in flight, one per HIP stream, from the
+    calling thread: while one view waits for its num_rendered read-back and runs its small binning
+    kernels, another view's blend keeps the memory system busy (cfg3 on MI355X: 2.1 -> 1.8 ms per view).
+
+    `render_fn(view, slot)` must enqueue on the CURRENT stream (the rasteriser does) and use
+    per-slot resources for anything it keeps across calls (e.g. `ScratchPool` number `slot`).
+    Results are returned in view order after a device synchronize."""
+    if not torch.cuda.is_available():
+        return [render_fn(v, 0) for v in views]
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    n = max(1, min(in_flight, len(views)))
+    streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(n - 1)]
+    for st in streams[1:]:
+        st.wait_stream(streams[0])   # inputs produced on the caller's stream are visible to the others
+    out = []
+    for i, v in enumerate(views):
+        with torch.cuda.stream(streams[i % n]):
+            out.append(render_fn(v, i % n))
+    for st in streams[1:]:
+        streams[0].wait_stream(st)
+    torch.cuda.synchronize(device)
+    return out
+
+
 def channel_slice(C, rank=None, world_size=None):
     r, w = world()
     rank = r if rank is None else rank
