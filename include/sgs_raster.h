@@ -39,7 +39,7 @@ extern "C" {
                              CR/cuda_rasterizer/auxiliary.h:156-160) */
 
 /* Resizable scratch buffer callback.  Replaces std::function<char*(size_t)>
- * (CR/cuda_rasterizer/rasterizer.h:24-26, built by resizeFunctional,
+ * (CR/cuda_rasterizer/rasterizer.h:31-33, built by resizeFunctional,
  * CR/rasterize_points.cu:28-36): must return a device pointer to at least `bytes`
  * bytes (128-B aligned) that stays valid until the caller releases it.  */
 typedef void *(*sgs_alloc_fn)(void *user, size_t bytes);
@@ -49,8 +49,8 @@ const char *sgs_last_error(void);
 
 /* ---- forward ---------------------------------------------------------------
  * Replaces CudaRasterizer::Rasterizer::forward
- *   (CR/cuda_rasterizer/rasterizer_impl.cu:198-341, declared rasterizer.h:34-58;
- *    RR/cuda_rasterizer/rasterizer_impl.cu:198-338 when out_depth != NULL).
+ *   (CR/cuda_rasterizer/rasterizer_impl.cu:198-341, declared rasterizer.h:30-53;
+ *    RR/cuda_rasterizer/rasterizer_impl.cu:198-339 when out_depth != NULL).
  * Pipeline: preprocess -> inclusive scan -> (4-byte D2H) -> duplicateWithKeys ->
  * stable 64-bit radix sort on bits [0, 32+msb(tiles)) -> tile ranges -> blend.
  *   P,D,M          #Gaussians, active SH degree, SH coeffs per Gaussian (0 if no shs)
@@ -93,7 +93,7 @@ int sgs_rasterize_forward(
 
 /* ---- backward --------------------------------------------------------------
  * Replaces CudaRasterizer::Rasterizer::backward
- *   (CR/cuda_rasterizer/rasterizer_impl.cu:345-441, rasterizer.h:60-86), with the
+ *   (CR/cuda_rasterizer/rasterizer_impl.cu:345-441, rasterizer.h:55-84), with the
  * colour-channel count a RUNTIME argument: the reference instantiates its backward on
  * the compile-time NUM_CHANNELS=3 (CR/cuda_rasterizer/config.h:15, backward.cu:599,636);
  * num_channels==3 reproduces it, other values are its runtime-C generalisation.
@@ -142,7 +142,7 @@ int sgs_rasterize_backward(
 int sgs_mark_visible(int P, const float *means3D, const float *viewmatrix,
 		     const float *projmatrix, uint8_t *present, void *stream);
 
-/* Replaces SimpleKNN::knn (SK/simple_knn.cu:186-220, simple_knn.h:17): mean squared
+/* Replaces SimpleKNN::knn (SK/simple_knn.cu:185-221, simple_knn.h:18): mean squared
  * distance to the three nearest other points.  points (P,3), meanDists (P).
  * Scratch comes from `scratch(scratch_user, bytes)` (one call). */
 int sgs_knn_mean_dist2(int P, const float *points, float *meanDists,

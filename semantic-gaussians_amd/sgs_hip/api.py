@@ -62,7 +62,7 @@ def _snapshot(args, path):
 
 
 def _make_function(with_depth):
-    """Builds the autograd bridge (CR/__init__.py:47-213; RR/__init__.py:40-156)."""
+    """Builds the autograd bridge (CR/channel_rasterization/__init__.py:47-213; RR/rgbd_rasterization/__init__.py:40-156)."""
 
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
@@ -144,14 +144,14 @@ class _RasterizerBase(nn.Module):
         self.raster_settings = raster_settings
 
     def markVisible(self, positions):
-        """Boolean mask of points with view-space z > 0.2 (CR/__init__.py:237-243)."""
+        """Boolean mask of points with view-space z > 0.2 (CR/channel_rasterization/__init__.py:237-243)."""
         with torch.no_grad():
             s = self.raster_settings
             return raster.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
                 rotations=None, cov3D_precomp=None):
-        # argument contract of the reference (CR/__init__.py:258-264), same messages
+        # argument contract of the reference (CR/channel_rasterization/__init__.py:258-264), same messages
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         has_sr = scales is not None or rotations is not None
