@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	const uint32_t chunk_base = (range.x >> 7) + (uint32_t)tile;
 
 	__shared__ StagedEntryW s_e[WB];
-	__shared__ float s_wt[(WB + 3) * 256]; // [entry][strip*64 + lane] (+ padding entries)
+	__shared__ float s_wt[WB * 256];       // [entry][strip*64 + lane]
 	__shared__ uint32_t s_amask;           // entries of the batch taken by at least one pixel
 	__shared__ int s_nkeep;                // entries of the batch that survive the tile-level rejection
 	__shared__ int s_alive[4];
