@@ -49,7 +49,7 @@ struct StagedEntryW {   // 40 B per list entry in LDS
 	uint32_t pad;
 };
 
-constexpr int WB = 32;    // list entries per batch
+constexpr int WB = 16;    // list entries per batch
 constexpr int ACH = 128;  // work-list slots per chunk
 constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the T * bg pseudo entry (weights MODE 2)
 
@@ -128,6 +128,22 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	uint32_t nchunks = 0;   // chunks reserved so far (only thread 0's copy is authoritative)
 	if (threadIdx.x == 0) s_ovf = 0u;
 
+	// Staging runs one batch ahead in registers (lanes < WB): at the top of batch b the Gaussian
+	// data of batch b is complete, the gathers for batch b + 1 are issued with the ids fetched during
+	// batch b - 1, and the ids of batch b + 2 are requested -- the dependent point_list -> means2D /
+	// conic_opacity round trips overlap the weight phase instead of preceding it.
+	uint32_t pf_id = 0u, pf_id_next = 0u;
+	float2 pf_xy = make_float2(0.f, 0.f);
+	float4 pf_co = make_float4(0.f, 0.f, 0.f, 0.f);
+	if ((int)threadIdx.x < WB) {
+		if ((int)threadIdx.x < n_total) {
+			pf_id = point_list[range.x + threadIdx.x];
+			pf_xy = means2D[pf_id];
+			pf_co = conic_opacity[pf_id];
+		}
+		if (WB + (int)threadIdx.x < n_total) pf_id_next = point_list[range.x + WB + threadIdx.x];
+	}
+
 	for (int base = 0; base < n_total; base += WB) {
 		const bool wave_alive = __ballot(!done) != 0ull;
 		if (lane == 0) s_alive[wave] = wave_alive ? 1 : 0;
@@ -138,10 +154,18 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		if ((int)threadIdx.x < WB) {   // (the first 32 lanes of wave 0)
 			StagedEntryW e;
 			bool keep = false;
+			// this batch's data (prefetched), then the next batch's gathers and the ids after that
+			const uint32_t id = pf_id;
+			const float2 xy = pf_xy;
+			const float4 co = pf_co;
+			if (base + WB + (int)threadIdx.x < n_total) {
+				pf_id = pf_id_next;
+				pf_xy = means2D[pf_id];
+				pf_co = conic_opacity[pf_id];
+			}
+			if (base + 2 * WB + (int)threadIdx.x < n_total)
+				pf_id_next = point_list[range.x + base + 2 * WB + threadIdx.x];
 			if ((int)threadIdx.x < n) {
-				const uint32_t id = point_list[range.x + base + threadIdx.x];
-				const float2 xy = means2D[id];
-				const float4 co = conic_opacity[id];
 				e.a2 = -0.5f * co.x;
 				e.b2 = -co.y;
 				e.c2 = -0.5f * co.z;
