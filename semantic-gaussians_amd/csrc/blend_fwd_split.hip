@@ -1242,6 +1242,8 @@ __device__ __forceinline__ void sweep_store_paired(const SweepSets& S, float* ba
 // walked by scalar adds (planes (r & 3) + 8 (r >> 2): +1, +1, +1, +5) and one 32-bit byte offset
 // per lane and pixel block.  Inline asm keeps the compiler from tabulating the 16 bases (it runs
 // out of SGPRs and falls back to 64-bit VGPR addresses: ~2 VALU per store, 256 per tile and wave).
+// `nt`: the image is written once and not read back by this pipeline; streaming stores were 6-10 %
+// faster in tools/ubench_store.hip (modes 16 vs 18).
 // ubase = &out[c0][0][0] (uniform); loff = byte offset of [4*half][ty*16 + g][xl0 + (lane & 31)]
 __device__ __forceinline__ void sweep_store_paired_fast(const SweepSets& S, const float* ubase, uint32_t loff,
 							size_t HW, int W)
@@ -1255,8 +1257,8 @@ __device__ __forceinline__ void sweep_store_paired_fast(const SweepSets& S, cons
 		for (int r = 0; r < 16; r++) {
 			const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(S[0][pb][r]),
 									 __float_as_uint(S[1][pb][r]), false, false);
-			asm volatile("global_store_dword %0, %1, %2" : : "v"(o0), "v"(sw[0]), "s"(sb) : "memory");
-			asm volatile("global_store_dword %0, %1, %2" : : "v"(o1), "v"(sw[1]), "s"(sb) : "memory");
+			asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(o0), "v"(sw[0]), "s"(sb) : "memory");
+			asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(o1), "v"(sw[1]), "s"(sb) : "memory");
 			sb += ((r & 3) == 3 ? 5u : 1u) * plane;
 		}
 	}

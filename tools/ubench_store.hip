@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void store_kernel(float* __restrict__ out, int
 				}
 			}
 		}
-	} else if (MODE == 15 || MODE == 16 || MODE == 17) {
+	} else if (MODE >= 15 && MODE <= 20) {
 		// staggered tile pairs x 64 channels: even rows x in [32k, 32k+32), odd rows x in [32k+16, 32k+48):
 		// every 128-B line of the (pitch 5184) image is owned by ONE workgroup.
 		// 15: wave 0/1 write the left/right 64-B halves of even rows, wave 2/3 of odd rows (same time)
@@ -108,7 +108,13 @@ __global__ __launch_bounds__(256) void store_kernel(float* __restrict__ out, int
 #pragma unroll
 				for (int k = 0; k < 32; k++) {
 					const int c = sub * 64 + k * 2 + half;
-					if (x >= 0 && x < W && y < H) out[(size_t)c * HW + (size_t)y * W + x] = val;
+					if (x >= 0 && x < W && y < H) {
+						float* p = &out[(size_t)c * HW + (size_t)y * W + x];
+						if (MODE == 18) asm volatile("global_store_dword %0, %1, off nt" : : "v"(p), "v"(val) : "memory");
+						else if (MODE == 19) asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(val) : "memory");
+						else if (MODE == 20) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(val) : "memory");
+						else *p = val;
+					}
 				}
 			}
 		}
@@ -172,16 +178,16 @@ int main()
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
 	hipEventCreate(&e1);
-	const char* names[18] = {"contiguous 128 KB per WG", "blend epilogue pattern (4 x 64 B per store)",
-				"tile pairs (2 x 128 B per store)", "epilogue pattern, nontemporal", "tile quads (256 B per store)", "epilogue pattern, chunk-major block order", "hashed 512-B runs", "hashed 1-KB runs", "hashed 2-KB runs", "hashed 4-KB runs", "hashed 16-KB runs", "tile pairs, pitch 1312 (aligned 128-B runs)", "hashed 64-B runs", "hashed 128-B runs", "hashed 256-B runs", "staggered pairs, half lines from 2 waves", "staggered pairs, full lines per store", "as 16, consecutive workgroups along x"};
+	const char* names[21] = {"contiguous 128 KB per WG", "blend epilogue pattern (4 x 64 B per store)",
+				"tile pairs (2 x 128 B per store)", "epilogue pattern, nontemporal", "tile quads (256 B per store)", "epilogue pattern, chunk-major block order", "hashed 512-B runs", "hashed 1-KB runs", "hashed 2-KB runs", "hashed 4-KB runs", "hashed 16-KB runs", "tile pairs, pitch 1312 (aligned 128-B runs)", "hashed 64-B runs", "hashed 128-B runs", "hashed 256-B runs", "staggered pairs, half lines from 2 waves", "staggered pairs, full lines per store", "as 16, consecutive workgroups along x", "as 16, nt", "as 16, sc0 sc1", "as 16, sc1"};
 	float4* src;
 	float* sink;
 	hipMalloc(&src, (size_t)1 << 30);
 	hipMalloc(&sink, 64);
 	hipMemset(src, 0, (size_t)1 << 30);
 	for (int pass = 0; pass < 2; pass++)
-	for (int mode = 0; mode < 18; mode++) {
-		if (pass == 1 && mode != 0 && mode != 1 && mode != 16 && mode != 17) continue;
+	for (int mode = 0; mode < 21; mode++) {
+		if (pass == 1 && mode != 0 && mode != 1 && mode < 16) continue;
 		const int total = (mode >= 15) ? ((GX + 1) / 2 + 1) * GY * 8 : (mode == 2 || mode == 11) ? ((GX + 1) / 2) * GY * 8 : (mode == 4 ? ((GX + 3) / 4) * GY * 16 : NT * 4);
 		const int per_xcd = (total + 7) / 8;
 		float best = 1e9f;
@@ -206,6 +212,9 @@ int main()
 			case 15: hipLaunchKernelGGL(store_kernel<15>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
 			case 16: hipLaunchKernelGGL(store_kernel<16>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
 			case 17: hipLaunchKernelGGL(store_kernel<17>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 18: hipLaunchKernelGGL(store_kernel<18>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 19: hipLaunchKernelGGL(store_kernel<19>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
+			case 20: hipLaunchKernelGGL(store_kernel<20>, dim3(per_xcd * 8), dim3(256), 0, 0, out, per_xcd, total, pass ? src : nullptr, sink); break;
 			}
 			hipEventRecord(e1);
 			hipEventSynchronize(e1);
