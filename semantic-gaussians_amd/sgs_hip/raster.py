@@ -34,13 +34,16 @@ class ScratchPool:
     survive the call, so re-allocating ~2 GB of scratch per frame through the caching
     allocator is pure overhead (and makes it thrash: blocks of 2.6 GB / 1.6 GB / 0.1 GB are
     split and re-split for many frames before it settles).  A pool keeps them resident.
-    Buffers handed out from a pool are only valid until the next forward on that pool."""
+    Buffers handed out from a pool are only valid until the next forward on that pool AND stream:
+    entries are keyed by (device, current stream, buffer), so forwards running concurrently on
+    different streams (sgs_hip.dist.render_views_pipelined) never share scratch."""
 
     def __init__(self):
         self._t = {}
 
     def get(self, device, key, nbytes):
-        k = (str(device), key)
+        stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+        k = (str(device), stream, key)
         t = self._t.get(k)
         if t is None or t.numel() < nbytes:
             nb = int(nbytes * 1.25) if t is not None else int(nbytes)   # amortise growth

@@ -351,12 +351,12 @@ def test_views_pipelined_on_two_streams_match_serial():
     s = scene.to(DEV)
     cams = [pinhole(208, 128, fx).to(DEV) for fx in (150.0, 160.0, 170.0, 180.0, 190.0, 200.0)]
     e = torch.Tensor([])
-    pools = [raster.ScratchPool(), raster.ScratchPool()]
+    pool = raster.ScratchPool()   # one pool: scratch is keyed by stream
 
     def render(c, slot):
         out = raster.rasterize_forward(s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e,
                                        c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy,
-                                       128, 208, e, 0, c.camera_center, False, False, 128, False, pool=pools[slot])
+                                       128, 208, e, 0, c.camera_center, False, False, 128, False, pool=pool)
         return out[0], out[1].clone(), out[2].clone()
 
     serial = [render(c, 0) for c in cams]
