@@ -271,6 +271,10 @@ def main():
                          "measured": f"hipEvents on the launch stream, {n_single} warm-up frames with one view in flight; "
                                      f"the timed region keeps {V} in flight (stage_ms_timed_region)"},
             "ms_per_view": ms_per_step / V,
+            # bytes_alg of the WHOLE forward (blend + binning front end) over the frame time
+            "whole_forward": {"algorithmic_bytes": bytes_blend + bytes_front,
+                              "achieved_GBps": V * (bytes_blend + bytes_front) / (ms_per_step * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": V * (bytes_blend + bytes_front) / (ms_per_step * 1e-3) / HBM_PEAK},
             "stage_ms": dict(zip(["preprocess", "scan_readback", "duplicate", "sort", "ranges", "blend_weights",
                                   "blend_accum"],
                                  [round(v, 4) for v in stage_ms])),
