@@ -125,7 +125,8 @@ def test_forward_sweep_long_lists(orc):
     one chunk per tile and the id ring crosses many tile boundaries."""
     scene, cam = small_scene(P=40000, C=128, W=784, H=32, fx=600.0, seed=77)
     scene = scene._replace(scales=scene.scales * 3.0, opacities=scene.opacities * 0.05)
-    fw = _check_forward(orc, scene, cam)
+    _check_forward(orc, scene, cam)        # first frame: the work-list arena overflows, the gated fallback renders
+    fw = _check_forward(orc, scene, cam)   # arena grown from the first frame's usage: the sweep renders
     ranges = fw["ranges"].reshape(-1, 2)
     assert (ranges[:, 1] - ranges[:, 0]).max() > 2000 and fw["n_contrib"].max() > 900
     _check_forward(orc, scene, cam, variant=8 + 4096 + 16 * 6)   # one 49-tile segment: ~2900 batches, the window slides
