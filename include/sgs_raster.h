@@ -189,12 +189,13 @@ int sgs_image_layout_of(int width, int height, sgs_image_layout *out);
  * (CR/cuda_rasterizer/rasterizer_impl.cu:35-50,302). */
 int sgs_sort_bits(int width, int height);
 
-/* Binning mode 0 sorts 32-bit tile ids; the reference's sorted 64-bit keys
- * (tile << 32 | depth bits) are not needed by any kernel and are materialised into the
- * binning buffer's keys_sorted area only by this call (parity tests).  Call it only on buffers
- * a mode-0 forward produced: a mode-1 forward has written the real sorted keys already. */
-int sgs_debug_sorted_keys(int P, int num_rendered, const char *geom_buffer,
-			  char *binning_buffer, void *stream);
+/* The default binning never builds the reference's 64-bit sort keys (tile << 32 | depth bits);
+ * this call materialises them, in sorted order, into the binning buffer's keys_sorted area from
+ * `ranges`, `point_list` and the depths (parity tests).  Call it only on buffers of a forward
+ * in binning mode 0 or 2: a mode-1 forward has written the real sorted keys already. */
+int sgs_debug_sorted_keys(int P, int num_rendered, int width, int height,
+			  const char *geom_buffer, char *binning_buffer,
+			  const char *image_buffer, void *stream);
 
 /* Device exp() used by the blend kernels, exposed for the numerics contract test
  * (DESIGN.md "exp contract"): out[i] = sgs_expf(in[i]). */
@@ -216,11 +217,12 @@ int sgs_set_blend_variant(int variant);
  * forwards since the last query (no extra synchronisation inside the timed region).
  * sgs_get_stage_ms returns the number of forwards averaged (0 in mode 1). */
 int sgs_set_stage_timing(int mode);
-/* Binning algorithm: 0 (default) = Gaussians presorted by depth, instances emitted in that
- * order, stable instance sort on the tile bits only; 1 = the reference's order of operations
- * (emit in index order, sort on all 32+msb(tiles) key bits).  Sorted keys, lists and ranges are
- * bit-identical in both modes; point_offsets and the UNSORTED key/value arrays follow the
- * reference's emission order only in mode 1.  Returns the previous mode. */
+/* Binning algorithm: 0 (default) = Gaussians presorted by depth, per-tile lists built from row
+ * instances without sorting the tile instances (binning_rows.hip); 1 = the reference's order of
+ * operations (emit in index order, sort on all 32+msb(tiles) key bits); 2 = depth presort,
+ * instances emitted in that order, stable radix sort on the 32-bit tile id.  Lists (point_list),
+ * ranges and the (reconstructed) sorted keys are bit-identical in all modes; point_offsets and
+ * the UNSORTED key/value arrays exist only in mode 1.  Returns the previous mode. */
 int sgs_set_binning_mode(int mode);
 int sgs_get_stage_ms(float *ms7);
 

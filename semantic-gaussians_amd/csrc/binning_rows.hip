@@ -1,0 +1,428 @@
+// binning_rows.hip -- binning mode 0: per-tile lists without sorting the tile instances.
+//
+// The reference turns (Gaussian, tile) instances into per-tile depth-ordered lists with a
+// 45-bit radix sort of L = 16.5 M pairs (cfg3).  With the Gaussians already in depth order
+// (binning.hip: depth presort) a tile's list is just "the Gaussians whose rect covers the tile,
+// in rank order", and a rect is a span of columns times a span of rows.  A stable partition of
+// items that each cover a SPAN of bins needs no sort at all: for 64 consecutive items (one wave)
+// and one bin, the ballot of "covers the bin" is both the chunk's count for that bin and, through
+// popcount(ballot & lanes_below), every covering item's rank inside the chunk.  Two such
+// partitions give the lists:
+//
+//   stage A  items = the P ranked Gaussians, bins = the longer tile-grid axis ("major", columns for
+//            cfg3: 81): output = per column the Gaussians covering it, in depth order, each carrying
+//            its row span ("major instances", R = 3.9 M for cfg3, 4.3x fewer than L);
+//   stage B  items = the major instances of one column (64 per wave, never straddling columns),
+//            bins = the other axis (rows, 61): output = point_list, every Gaussian id written once
+//            to its final position; the per-tile counts give `ranges`.
+//
+// Each stage is: chunk histogram (a +1/-1 difference array per span and a wave prefix), two-level
+// prefix of the chunk counts along the item order (groups of 32 chunks), an exclusive scan over the
+// bins / tiles, and the ballot sweep.  No keys exist, nothing L-sized is read, and the only
+// L-sized write is point_list itself.  Results are bit-identical to the reference's sorted order
+// (tests: point_list, ranges, reconstructed 64-bit keys).
+#include "sgs_kernels.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace sgs {
+
+namespace {
+constexpr int RCH = 64;    // items per chunk (one wave)
+constexpr int RGRP = 32;   // chunks per scan group
+
+// wave-uniform: the segment whose chunk range contains `id`: largest s with first[s] <= id.  The
+// table (nseg + 1 entries, first[nseg] = total > id) is read 64 entries per load and resolved with a
+// ballot: one memory round trip per 64 segments instead of a dependent binary search.
+__device__ __forceinline__ int seg_of(const uint32_t* __restrict__ first, int nseg, uint32_t id)
+{
+	const int lane = threadIdx.x & 63;
+	int s = 0;
+	for (int b = 0; b <= nseg; b += 64) {
+		const int i = b + lane;
+		const bool le = i <= nseg && first[i] <= id;
+		const unsigned long long m = __ballot(le);   // a prefix of the lanes (the table is non-decreasing)
+		if (m == 0ull) break;
+		s = b + __popcll(m) - 1;
+		if (m != ~0ull) break;
+	}
+	return s;
+}
+
+// an item of a stage: the Gaussian, the span it covers on this stage's axis, and (stage A) the
+// other axis' span as payload for stage B
+struct Item {
+	uint32_t g, lo, hi, payload;
+	bool valid;
+};
+
+// stage A item: rank r -> Gaussian perm[r], rect from means2D / radii
+__device__ __forceinline__ Item item_from_rank(uint32_t r, uint32_t n, const uint32_t* __restrict__ perm,
+					       const int* __restrict__ radii, const float2* __restrict__ means2D,
+					       int gx, int gy, bool major_x)
+{
+	Item it{0u, 0u, 0u, 0u, false};
+	if (r < n) {
+		const uint32_t g = perm[r];
+		const int rad = radii[g];
+		if (rad > 0) {
+			const float2 p = means2D[g];
+			uint32_t x0, y0, x1, y1;
+			get_rect(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
+			it.g = g;
+			it.lo = major_x ? x0 : y0;
+			it.hi = major_x ? x1 : y1;
+			it.payload = major_x ? (y0 | (y1 << 16)) : (x0 | (x1 << 16));
+			it.valid = it.hi > it.lo;
+		}
+	}
+	return it;
+}
+} // namespace
+
+// counts64[r] = major-axis bins covered << 32 | tiles covered, for the Gaussian of depth rank r; the
+// rank's record rrec[r] = (Gaussian, major span lo | hi << 16, minor span lo | hi << 16, 0) is kept so
+// that stage A reads its items coalesced instead of gathering perm -> radii / means2D twice more
+__global__ __launch_bounds__(256) void span_counts_kernel(int P, const uint32_t* __restrict__ perm,
+							   const int* __restrict__ radii,
+							   const float2* __restrict__ means2D, int gx, int gy, int major_x,
+							   uint64_t* __restrict__ counts64, uint4* __restrict__ rrec)
+{
+	const int r = blockIdx.x * 256 + threadIdx.x;
+	if (r >= P) return;
+	const Item it = item_from_rank((uint32_t)r, (uint32_t)P, perm, radii, means2D, gx, gy, major_x != 0);
+	rrec[r] = it.valid ? make_uint4(it.g, it.lo | (it.hi << 16), it.payload, 0u) : make_uint4(0u, 0u, 0u, 0u);
+	uint64_t c = 0;
+	if (it.valid) {
+		const uint32_t nmaj = it.hi - it.lo, nmin = (it.payload >> 16) - (it.payload & 0xffffu);
+		c = ((uint64_t)nmaj << 32) | (uint64_t)(nmaj * nmin);
+	}
+	counts64[r] = c;
+}
+
+size_t scan64_temp_bytes(int P)
+{
+	size_t bytes = 0;
+	(void)rocprim::inclusive_scan(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)P,
+				      rocprim::plus<uint64_t>(), (hipStream_t)0);
+	return bytes;
+}
+
+hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes, int P, const uint32_t* perm,
+				  const int* radii, const float2* means2D, int gx, int gy, uint64_t* counts64,
+				  uint64_t* offs64, uint4* rrec)
+{
+	const int major_x = gx >= gy;
+	hipLaunchKernelGGL(span_counts_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, perm, radii, means2D,
+			   gx, gy, major_x, counts64, rrec);
+	return rocprim::inclusive_scan(temp, temp_bytes, (const uint64_t*)counts64, offs64, (size_t)P,
+				       rocprim::plus<uint64_t>(), st);
+}
+
+// chunk0 / grp0 = first chunk / scan group of each segment (segment s = items [segstart[s], segstart[s+1])).
+// Stage A passes segstart == nullptr: one segment of `total` items.  One workgroup.
+__global__ __launch_bounds__(64) void seg_tables_kernel(int nseg, uint32_t total, uint32_t* __restrict__ segstart,
+							 bool single, uint32_t* __restrict__ chunk0,
+							 uint32_t* __restrict__ grp0)
+{
+	if (threadIdx.x != 0) return;
+	if (single) {
+		segstart[0] = 0u;
+		segstart[1] = total;
+	}
+	uint32_t c = 0, g = 0;
+	for (int s = 0; s < nseg; s++) {
+		chunk0[s] = c;
+		grp0[s] = g;
+		const uint32_t n = segstart[s + 1] - segstart[s];
+		const uint32_t nc = (n + RCH - 1) / RCH;
+		c += nc;
+		g += (nc + RGRP - 1) / RGRP;
+	}
+	chunk0[nseg] = c;
+	grp0[nseg] = g;
+}
+
+// per chunk and bin: how many of the chunk's items cover the bin
+template <bool FROM_RANKS>
+__global__ __launch_bounds__(256) void span_hist_kernel(
+	int nb, int nseg, const uint32_t* __restrict__ segstart, const uint32_t* __restrict__ chunk0,
+	const uint2* __restrict__ items, const uint4* __restrict__ rrec, uint32_t* __restrict__ cmat)
+{
+	extern __shared__ int s_diff[];   // [4 waves][nb + 1]
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t c = blockIdx.x * 4u + (uint32_t)wave;
+	int* diff = s_diff + wave * (nb + 1);
+	for (int b = lane; b <= nb; b += 64) diff[b] = 0;
+	if (c >= chunk0[nseg]) return;
+	const int s = seg_of(chunk0, nseg, c);
+	const uint32_t idx = segstart[s] + (c - chunk0[s]) * RCH + (uint32_t)lane, end = segstart[s + 1];
+	uint32_t lo = 0, hi = 0;
+	if (FROM_RANKS) {
+		if (idx < end) {
+			const uint32_t sp = rrec[idx].y;
+			lo = sp & 0xffffu;
+			hi = sp >> 16;
+		}
+	} else if (idx < end) {
+		const uint32_t sp = items[idx].y;
+		lo = sp & 0xffffu;
+		hi = sp >> 16;
+	}
+	if (hi > lo) {   // difference array: +1 where the span starts, -1 one past its end
+		atomicAdd(&diff[lo], 1);
+		atomicAdd(&diff[hi], -1);
+	}
+	int carry = 0;   // inclusive prefix over the bins = coverage count per bin
+	for (int b0 = 0; b0 < nb; b0 += 64) {
+		const int b = b0 + lane;
+		int v = b < nb ? diff[b] : 0;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int u = __shfl_up(v, o);
+			if (lane >= o) v += u;
+		}
+		v += carry;
+		if (b < nb) cmat[(size_t)c * nb + b] = (uint32_t)v;
+		carry = __shfl(v, 63);
+	}
+}
+
+// in-group exclusive prefix over the chunks of a scan group (in place), group total to gtot
+__global__ __launch_bounds__(256) void span_scan_groups_kernel(int nb, int nseg, const uint32_t* __restrict__ chunk0,
+								const uint32_t* __restrict__ grp0,
+								uint32_t* __restrict__ cmat, uint32_t* __restrict__ gtot)
+{
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t G = t / (uint32_t)nb;
+	const int b = (int)(t - G * (uint32_t)nb);
+	if (G >= grp0[nseg]) return;
+	int s = 0;   // (per-thread, not wave-uniform: plain binary search)
+	{
+		int lo = 0, hi = nseg;
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (grp0[mid] <= G) lo = mid;
+			else hi = mid;
+		}
+		s = lo;
+	}
+	const uint32_t cbeg = chunk0[s] + (G - grp0[s]) * RGRP;
+	const uint32_t cend = cbeg + RGRP < chunk0[s + 1] ? cbeg + RGRP : chunk0[s + 1];
+	uint32_t run = 0;
+	for (uint32_t c = cbeg; c < cend; c++) {
+		const uint32_t v = cmat[(size_t)c * nb + b];
+		cmat[(size_t)c * nb + b] = run;
+		run += v;
+	}
+	gtot[(size_t)G * nb + b] = run;
+}
+
+// per (segment, bin): exclusive prefix over the segment's groups (in place); its total is the length of
+// the output list `seg * seg_stride + bin * bin_stride`.  One wave per list: the groups are split into
+// 64 contiguous runs, run sums are wave-scanned (stage A has one segment with hundreds of groups).
+__global__ __launch_bounds__(256) void span_scan_lists_kernel(int nb, int nseg, const uint32_t* __restrict__ grp0,
+							       uint32_t* __restrict__ gtot, int seg_stride, int bin_stride,
+							       uint32_t* __restrict__ listlen)
+{
+	const int lane = threadIdx.x & 63;
+	const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (t >= nb * nseg) return;
+	const int s = t / nb, b = t - s * nb;
+	const uint32_t g0 = grp0[s], n = grp0[s + 1] - g0;
+	const uint32_t per = (n + 63) / 64;
+	const uint32_t beg = (uint32_t)lane * per < n ? (uint32_t)lane * per : n;
+	const uint32_t end = beg + per < n ? beg + per : n;
+	uint32_t sum = 0;
+	for (uint32_t i = beg; i < end; i++) sum += gtot[(size_t)(g0 + i) * nb + b];
+	uint32_t incl = sum;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+		if (lane >= o) incl += u;
+	}
+	uint32_t run = incl - sum;
+	for (uint32_t i = beg; i < end; i++) {
+		const uint32_t v = gtot[(size_t)(g0 + i) * nb + b];
+		gtot[(size_t)(g0 + i) * nb + b] = run;
+		run += v;
+	}
+	if (lane == 63) listlen[s * seg_stride + b * bin_stride] = incl;
+}
+
+// exclusive scan of n list lengths in list order.  RANGES: ranges[t] = [start, start + len), (0, 0) for an
+// empty tile as the reference's memset + identifyTileRanges leaves it (CR/cuda_rasterizer/
+// rasterizer_impl.cu:116-138,313); else starts[t] = start, starts[n] = total.  One workgroup.
+template <bool RANGES>
+__global__ __launch_bounds__(1024) void list_scan_kernel(int n, const uint32_t* __restrict__ len,
+							  uint2* __restrict__ ranges, uint32_t* __restrict__ starts)
+{
+	__shared__ uint32_t s_part[1024];
+	const int per = (n + 1023) / 1024;
+	const int t0 = threadIdx.x * per < n ? threadIdx.x * per : n, t1 = (t0 + per < n) ? t0 + per : n;
+	uint32_t sum = 0;
+	for (int t = t0; t < t1; t++) sum += len[t];
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the partials
+		const uint32_t v = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+		__syncthreads();
+		s_part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t run = s_part[threadIdx.x] - sum;
+	for (int t = t0; t < t1; t++) {
+		const uint32_t m = len[t];
+		if (RANGES) ranges[t] = m ? make_uint2(run, run + m) : make_uint2(0u, 0u);
+		else starts[t] = run;
+		run += m;
+	}
+	if (!RANGES && threadIdx.x == 1023) starts[n] = s_part[1023];
+}
+
+// the ballot sweep: every covering item is written to its final position in the list of
+// (segment, bin).  OUT_ITEMS: stage A (the item with its payload span); else the Gaussian id.
+template <bool FROM_RANKS>
+__global__ __launch_bounds__(256) void span_scatter_kernel(
+	int nb, int nseg, const uint32_t* __restrict__ segstart, const uint32_t* __restrict__ chunk0,
+	const uint32_t* __restrict__ grp0, const uint2* __restrict__ items, const uint4* __restrict__ rrec,
+	const uint32_t* __restrict__ cmat, const uint32_t* __restrict__ gtot, const uint32_t* __restrict__ starts,
+	const uint2* __restrict__ ranges, int seg_stride, int bin_stride, uint2* __restrict__ out_items,
+	uint32_t* __restrict__ point_list)
+{
+	extern __shared__ uint32_t s_base[];   // [4 waves][nb]: first position of this chunk in each list
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t c = blockIdx.x * 4u + (uint32_t)wave;
+	if (c >= chunk0[nseg]) return;   // (no barrier in this kernel: waves are independent)
+	const int s = seg_of(chunk0, nseg, c);
+	const uint32_t G = grp0[s] + (c - chunk0[s]) / RGRP;
+	uint32_t* base = s_base + wave * nb;
+	for (int b = lane; b < nb; b += 64) {
+		const int list = s * seg_stride + b * bin_stride;
+		base[b] = (FROM_RANKS ? starts[list] : ranges[list].x) + gtot[(size_t)G * nb + b] + cmat[(size_t)c * nb + b];
+	}
+	const uint32_t idx = segstart[s] + (c - chunk0[s]) * RCH + (uint32_t)lane, end = segstart[s + 1];
+	uint32_t g = 0, lo = 0, hi = 0, payload = 0;
+	if (FROM_RANKS) {
+		if (idx < end) {
+			const uint4 v = rrec[idx];
+			g = v.x;
+			lo = v.y & 0xffffu;
+			hi = v.y >> 16;
+			payload = v.z;
+		}
+	} else if (idx < end) {
+		const uint2 v = items[idx];
+		g = v.x;
+		lo = v.y & 0xffffu;
+		hi = v.y >> 16;
+	}
+	// the wave's bin range
+	uint32_t blo = hi > lo ? lo : 0xffffffffu, bhi = hi;
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) {
+		const uint32_t a = (uint32_t)__shfl_xor((int)blo, o), b2 = (uint32_t)__shfl_xor((int)bhi, o);
+		blo = a < blo ? a : blo;
+		bhi = b2 > bhi ? b2 : bhi;
+	}
+	blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo);
+	bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
+	const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	for (uint32_t b = blo; b < bhi; b++) {
+		const bool cov = lo <= b && b < hi;
+		const unsigned long long m = __ballot(cov);
+		if (cov) {
+			const uint32_t pos = base[b] + (uint32_t)__popcll(m & below);
+			if (FROM_RANKS) out_items[pos] = make_uint2(g, payload);
+			else point_list[pos] = g;
+		}
+	}
+}
+
+// sizes of the builder's scratch in 32-bit words.  R = major instances (stage A output)
+void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, size_t* cmat_words,
+			 size_t* gtot_words, size_t* len_words)
+{
+	const int nbA = gx >= gy ? gx : gy, nbB = gx >= gy ? gy : gx;
+	const size_t chA = ((size_t)P + RCH - 1) / RCH, grA = (chA + RGRP - 1) / RGRP;
+	const size_t chB = (size_t)R / RCH + (size_t)nbA, grB = chB / RGRP + (size_t)nbA;
+	const size_t cmA = chA * nbA, cmB = chB * nbB, gtA = grA * nbA, gtB = grB * nbB;
+	*tab_words = 3 * ((size_t)nbA + 2) + 8;          // segstart | chunk0 | grp0 of stage B (+ stage A's two-entry tables)
+	*cmat_words = cmA > cmB ? cmA : cmB;              // the stages run one after the other
+	*gtot_words = gtA > gtB ? gtA : gtB;
+	*len_words = (size_t)gx * gy + nbA + 2;           // tile lengths (stage B) | bin lengths (stage A)
+}
+
+hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
+			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list)
+{
+	const int ntiles = gx * gy;
+	if (R == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st);
+	const int major_x = gx >= gy;
+	const int nbA = major_x ? gx : gy, nbB = major_x ? gy : gx;
+	// tables: stage A (one segment) uses 3 x 2 words at the end; stage B: segstart = stage A's bin starts
+	uint32_t* segB = tabs;                    // nbA + 1 (+1 spare)
+	uint32_t* chunk0B = tabs + (nbA + 2);
+	uint32_t* grp0B = tabs + 2 * (nbA + 2);
+	uint32_t* segA = tabs + 3 * (nbA + 2);
+	uint32_t* chunk0A = segA + 2;
+	uint32_t* grp0A = segA + 4;
+	uint32_t* binlen = lens + ntiles;         // stage A list lengths
+	const uint32_t chA = ((uint32_t)P + RCH - 1) / RCH, grA = (chA + RGRP - 1) / RGRP;
+	const size_t ldsA = (size_t)4 * (nbA + 1) * 4, ldsB = (size_t)4 * (nbB + 1) * 4;
+
+	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
+	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A);
+	hipLaunchKernelGGL(span_hist_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A,
+			   (const uint2*)nullptr, rrec, cmat);
+	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grA * nbA + 255) / 256)), dim3(256), 0, st,
+			   nbA, 1, chunk0A, grp0A, cmat, gtot);
+	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
+			   binlen);
+	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB);
+	hipLaunchKernelGGL(span_scatter_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A, grp0A,
+			   (const uint2*)nullptr, rrec, cmat, gtot, segB, (const uint2*)nullptr, 0, 1, items,
+			   (uint32_t*)nullptr);
+
+	// ---- stage B: the major instances of each major bin -> per-tile lists
+	const uint32_t chB = R / RCH + (uint32_t)nbA, grB = chB / RGRP + (uint32_t)nbA;   // upper bounds
+	const int seg_stride = major_x ? 1 : gx, bin_stride = major_x ? gx : 1;          // tile = y * gx + x
+	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, nbA, R, segB, false, chunk0B, grp0B);
+	hipLaunchKernelGGL(span_hist_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B, items,
+			   rrec, cmat);
+	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grB * nbB + 255) / 256)), dim3(256), 0, st,
+			   nbB, nbA, chunk0B, grp0B, cmat, gtot);
+	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
+			   seg_stride, bin_stride, lens);
+	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, (uint32_t*)nullptr);
+	hipLaunchKernelGGL(span_scatter_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B,
+			   grp0B, items, rrec, cmat, gtot, (const uint32_t*)nullptr, ranges, seg_stride, bin_stride,
+			   (uint2*)nullptr, point_list);
+	return hipGetLastError();
+}
+
+// keys_sorted[i] = tile << 32 | depth bits of point_list[i], from `ranges` (parity tests only)
+__global__ __launch_bounds__(256) void reconstruct_keys_ranges_kernel(int ntiles, const uint2* __restrict__ ranges,
+								       const uint32_t* __restrict__ point_list,
+								       const float* __restrict__ depths,
+								       uint64_t* __restrict__ keys_sorted)
+{
+	const int t = blockIdx.x;
+	if (t >= ntiles) return;
+	const uint2 r = ranges[t];
+	for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256)
+		keys_sorted[i] = ((uint64_t)(uint32_t)t << 32) | (uint64_t)__float_as_uint(depths[point_list[i]]);
+}
+
+void launch_reconstruct_keys_ranges(hipStream_t st, int ntiles, const uint2* ranges, const uint32_t* point_list,
+				    const float* depths, uint64_t* keys_sorted)
+{
+	if (ntiles <= 0) return;
+	hipLaunchKernelGGL(reconstruct_keys_ranges_kernel, dim3(ntiles), dim3(256), 0, st, ntiles, ranges, point_list,
+			   depths, keys_sorted);
+}
+
+} // namespace sgs

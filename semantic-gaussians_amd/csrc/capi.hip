@@ -58,8 +58,10 @@ struct Carver {
 struct GeomLayout {
 	sgs_geometry_layout pub;
 	size_t scan_temp, scan_temp_bytes, trap_flag, total;
-	// depth presort of the Gaussians (binning mode 0)
+	// depth presort of the Gaussians (binning modes 0 and 2)
 	size_t perm, gkeys, counts_sorted, gsort_temp, gsort_temp_bytes;
+	// mode 0: rows | tiles counts of the ranked Gaussians and their inclusive scan
+	size_t counts64, offs64, scan64_temp, scan64_temp_bytes, rrec;
 };
 
 GeomLayout geom_layout(int P)
@@ -84,6 +86,11 @@ GeomLayout geom_layout(int P)
 	g.counts_sorted = c.take(p * 4);
 	g.gsort_temp_bytes = sgs::gaussian_sort_temp_bytes(P);
 	g.gsort_temp = c.take(g.gsort_temp_bytes);
+	g.counts64 = c.take(p * 8);
+	g.offs64 = c.take(p * 8);
+	g.scan64_temp_bytes = sgs::scan64_temp_bytes(P);
+	g.scan64_temp = c.take(g.scan64_temp_bytes);
+	g.rrec = c.take(p * 16);
 	g.total = align_up(c.off, 128) + 128;
 	g.pub.total = g.total;
 	return g;
@@ -93,13 +100,16 @@ struct BinLayout {
 	sgs_binning_layout pub;
 	size_t sort_temp, sort_temp_bytes, arena, total;
 	sgs::SplitArena arena_lay;
+	// mode 0 row builder scratch (forward only; 0 when not requested)
+	size_t rowtab, cmat, gtot, tilelen;
 };
 
 // Work-list capacity of the split blend (slots of 1 KB): adaptive, grown after an overflow.
 std::atomic<uint32_t> g_arena_hint{0};
 uint32_t* g_usage_host = nullptr;   // pinned: {slots used, overflow flag} of the last split forward
 
-BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int ntiles = 0)
+BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int ntiles = 0, uint32_t R = 0,
+		     int gx = 0, int gy = 0, int P = 0)
 {
 	BinLayout b;
 	Carver c;
@@ -117,6 +127,15 @@ BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int n
 	if (arena_capacity) {
 		const size_t bytes = sgs::split_arena_bytes(arena_capacity, L, ntiles, &b.arena_lay);
 		b.arena = c.take(bytes);
+	}
+	b.rowtab = b.cmat = b.gtot = b.tilelen = 0;
+	if (R) {
+		size_t w0, w1, w2, w3;
+		sgs::row_binning_scratch(P, R, gx, gy, &w0, &w1, &w2, &w3);
+		b.rowtab = c.take(w0 * 4);
+		b.cmat = c.take(w1 * 4);
+		b.gtot = c.take(w2 * 4);
+		b.tilelen = c.take(w3 * 4);
 	}
 	b.total = align_up(c.off, 128) + 128;
 	b.pub.total = b.total;
@@ -335,17 +354,26 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	tm.mark();
 	// binning mode 0: sort the P Gaussians by depth bits and emit instances in that order, so
 	// that the big instance sort only has to be stable on the tile bits (binning.hip)
-	const bool presort = g_binning_mode.load() == 0;
+	const int bmode = g_binning_mode.load();
+	const bool presort = bmode == 0 || bmode == 2;
+	const bool rows = bmode == 0;   // per-tile lists from row instances (binning_rows.hip)
 	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
+	uint64_t* offs64 = (uint64_t*)(gchunk + gl.offs64);
 	if (presort) {
-		uint32_t* counts_sorted = (uint32_t*)(gchunk + gl.counts_sorted);
 		e = sgs::launch_gaussian_depth_sort(st, gchunk + gl.gsort_temp, gl.gsort_temp_bytes,
 						    (const uint32_t*)depths, (uint32_t*)(gchunk + gl.gkeys),
 						    perm, P);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
-		sgs::launch_gather_counts(st, P, perm, tiles_touched, counts_sorted);
-		e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, counts_sorted,
-					       point_offsets, P);
+		if (rows) {
+			e = sgs::launch_row_counts_scan(st, gchunk + gl.scan64_temp, gl.scan64_temp_bytes, P, perm, radii,
+							means2D, gx, gy, (uint64_t*)(gchunk + gl.counts64), offs64,
+							(uint4*)(gchunk + gl.rrec));
+		} else {
+			uint32_t* counts_sorted = (uint32_t*)(gchunk + gl.counts_sorted);
+			sgs::launch_gather_counts(st, P, perm, tiles_touched, counts_sorted);
+			e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, counts_sorted,
+						       point_offsets, P);
+		}
 	} else {
 		e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, tiles_touched,
 					       point_offsets, P);
@@ -355,13 +383,17 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 
 	// the one blocking read-back of the forward (rasterizer_impl.cu:283)
 	int host_vals[2] = {0, 0};
-	e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
+	uint64_t host_rl = 0;   // mode 0: row instances << 32 | num_rendered
+	if (rows) e = hipMemcpyAsync(&host_rl, offs64 + (P - 1), 8, hipMemcpyDeviceToHost, st);
+	else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	if (e != hipSuccess) return fail_hip(e, "num_rendered read-back");
 	if (host_vals[1] != 0)
 		return fail(SGS_ETRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
-	const uint32_t L = (uint32_t)host_vals[0];
+	const uint32_t L = rows ? (uint32_t)(host_rl & 0xffffffffull) : (uint32_t)host_vals[0];
+	const uint32_t Rrows = rows ? (uint32_t)(host_rl >> 32) : 0u;
+	if (rows && (host_rl & 0xffffffffull) > 0x7fffffffull) return fail(SGS_EINVAL, "num_rendered exceeds 2^31-1");
 	if (L > 0x7fffffffu) return fail(SGS_EINVAL, "num_rendered exceeds 2^31-1");
 	tm.mark();
 
@@ -390,7 +422,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		arena_max = (uint64_t)L + 128ull * (uint64_t)ntiles;
 		arena_cap = (uint64_t)hint < arena_max ? hint : (uint32_t)arena_max;
 	}
-	const BinLayout bl = bin_layout(L, sort_bits, arena_cap, ntiles);
+	const BinLayout bl = bin_layout(L, sort_bits, arena_cap, ntiles, Rrows, gx, gy, P);
 	char* bchunk = (char*)binning_buffer(binning_user, bl.total);
 	if (!bchunk) return fail(SGS_EALLOC, "binning buffer allocation failed");
 	bchunk = align_ptr(bchunk);
@@ -400,8 +432,19 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	uint32_t* point_list = (uint32_t*)(bchunk + bl.pub.point_list);
 
 	uint2* ranges = (uint2*)(ichunk + il.ranges);
-	if (presort) {
-		// mode 0: 32-bit tile keys (depth order is already in the emission order).  The
+	if (rows) {
+		// mode 0: two span partitions, no instance sort (binning_rows.hip).  The 8-B-per-instance
+		// keys_unsorted area holds the major instances (8 B each, R <= L).
+		tm.mark();   // (no separate emission stage)
+		e = sgs::launch_row_binning(st, P, Rrows, gx, gy, (const uint4*)(gchunk + gl.rrec), (uint2*)keys_u,
+					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
+					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list);
+		if (e != hipSuccess) return fail_hip(e, "row binning");
+		SGS_CHECK_STAGE("row binning");
+		tm.mark();
+		tm.mark();   // (ranges come out of the same pass)
+	} else if (presort) {
+		// mode 2: 32-bit tile keys (depth order is already in the emission order).  The
 		// 8-B-per-instance "keys_unsorted" area holds the unsorted and the sorted tile ids.
 		uint32_t* tiles_u = (uint32_t*)keys_u;
 		uint32_t* tiles_s = tiles_u + L;
@@ -572,21 +615,24 @@ int sgs_knn_mean_dist2(int P, const float* points, float* meanDists, sgs_alloc_f
 	return 0;
 }
 
-int sgs_debug_sorted_keys(int P, int num_rendered, const char* geom_buffer, char* binning_buffer,
-			  void* stream)
+int sgs_debug_sorted_keys(int P, int num_rendered, int width, int height, const char* geom_buffer,
+			  char* binning_buffer, const char* image_buffer, void* stream)
 {
-	if (P < 0 || num_rendered < 0) return fail(SGS_EINVAL, "bad sizes");
+	if (P < 0 || num_rendered < 0 || width <= 0 || height <= 0) return fail(SGS_EINVAL, "bad sizes");
 	if (num_rendered == 0) return 0;
-	if (!geom_buffer || !binning_buffer) return fail(SGS_EINVAL, "null state buffer");
+	if (!geom_buffer || !binning_buffer || !image_buffer) return fail(SGS_EINVAL, "null state buffer");
 	const GeomLayout gl = geom_layout(P);
 	const BinLayout bl = bin_layout((size_t)num_rendered, 64);
+	const sgs_image_layout il = img_layout(width, height);
 	const char* gchunk = align_ptr(const_cast<char*>(geom_buffer));
 	char* bchunk = align_ptr(binning_buffer);
-	const uint32_t* tiles_s = (const uint32_t*)(bchunk + bl.pub.keys_unsorted) + num_rendered;
-	sgs::launch_reconstruct_keys((hipStream_t)stream, (size_t)num_rendered, tiles_s,
-				     (const uint32_t*)(bchunk + bl.pub.point_list),
-				     (const float*)(gchunk + gl.pub.depths),
-				     (uint64_t*)(bchunk + bl.pub.keys_sorted));
+	const char* ichunk = align_ptr(const_cast<char*>(image_buffer));
+	const int ntiles = ((width + SGS_TILE - 1) / SGS_TILE) * ((height + SGS_TILE - 1) / SGS_TILE);
+	// tile of position i = the tile whose range holds it (valid for every binning mode)
+	sgs::launch_reconstruct_keys_ranges((hipStream_t)stream, ntiles, (const uint2*)(ichunk + il.ranges),
+					    (const uint32_t*)(bchunk + bl.pub.point_list),
+					    (const float*)(gchunk + gl.pub.depths),
+					    (uint64_t*)(bchunk + bl.pub.keys_sorted));
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return fail_hip(e, "reconstruct keys");
 	return 0;

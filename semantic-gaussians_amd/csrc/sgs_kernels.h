@@ -41,6 +41,17 @@ hipError_t launch_sort32_pairs(hipStream_t st, void* temp, size_t temp_bytes, ui
 void launch_tile_ranges32(hipStream_t st, size_t L, const uint32_t* tiles, uint2* ranges, int ntiles);
 void launch_reconstruct_keys(hipStream_t st, size_t L, const uint32_t* tiles,
 			     const uint32_t* point_list, const float* depths, uint64_t* keys_sorted);
+// ---- binning_rows.hip (binning mode 0)
+size_t scan64_temp_bytes(int P);
+hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes, int P, const uint32_t* perm,
+				  const int* radii, const float2* means2D, int gx, int gy, uint64_t* counts64,
+				  uint64_t* offs64, uint4* rrec);
+void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, size_t* cmat_words,
+			 size_t* gtot_words, size_t* len_words);
+hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
+			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list);
+void launch_reconstruct_keys_ranges(hipStream_t st, int ntiles, const uint2* ranges, const uint32_t* point_list,
+				    const float* depths, uint64_t* keys_sorted);
 size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit);
 hipError_t launch_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint64_t* keys_in,
 			     uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,

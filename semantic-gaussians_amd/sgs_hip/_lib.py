@@ -91,7 +91,7 @@ def load():
     lib.sgs_sort_bits.restype = i
     lib.sgs_sort_bits.argtypes = [i, i]
     lib.sgs_debug_sorted_keys.restype = i
-    lib.sgs_debug_sorted_keys.argtypes = [i, i, p, p, p]
+    lib.sgs_debug_sorted_keys.argtypes = [i, i, i, i, p, p, p, p]
     lib.sgs_debug_expf.restype = i
     lib.sgs_debug_expf.argtypes = [i, p, p, p]
     lib.sgs_set_blend_variant.restype = i

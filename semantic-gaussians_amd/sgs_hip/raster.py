@@ -251,13 +251,15 @@ def geometry_views(geomBuffer, P):
         point_offsets=v(lay.point_offsets, 4 * P, torch.int32, (P,)))
 
 
-def binning_views(binningBuffer, L, geomBuffer=None, P=None):
-    """Typed views into the opaque binning buffer.  In binning mode 0 the sorted 64-bit keys are
-    only materialised here (pass geomBuffer and P); unsorted 64-bit keys exist only in mode 1."""
+def binning_views(binningBuffer, L, geomBuffer=None, P=None, imgBuffer=None, width=None, height=None):
+    """Typed views into the opaque binning buffer.  In binning modes 0 and 2 the sorted 64-bit keys
+    are only materialised here (pass geomBuffer, P, imgBuffer, width, height); unsorted 64-bit keys
+    exist only in mode 1."""
     if geomBuffer is not None and L > 0:
         with torch.cuda.device(binningBuffer.device):
-            _lib.check(_lib.load().sgs_debug_sorted_keys(int(P), int(L), geomBuffer.data_ptr(),
-                                                         binningBuffer.data_ptr(),
+            _lib.check(_lib.load().sgs_debug_sorted_keys(int(P), int(L), int(width), int(height),
+                                                         geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                                                         imgBuffer.data_ptr(),
                                                          _stream_ptr(binningBuffer.device)), "keys")
     lay = _lib.BinningLayout()
     _lib.check(_lib.load().sgs_binning_layout_of(int(L), C.byref(lay)), "layout")

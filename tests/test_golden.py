@@ -52,7 +52,7 @@ def test_hip_matches_golden():
         c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, e, 0, c.camera_center, False, False, C, False)
     assert n == int(G["num_rendered"])
     assert np.array_equal(radii.cpu().numpy(), G["radii"])
-    b = raster.binning_views(binn, n, geom, s.means3D.shape[0])
+    b = raster.binning_views(binn, n, geom, s.means3D.shape[0], img, W, H)
     assert _digest(b["keys_sorted"].cpu().numpy().view(np.uint64)) == str(G["keys_sorted_sha256"])
     assert _digest(b["point_list"].cpu().numpy().view(np.uint32)) == str(G["point_list_sha256"])
     iv = raster.image_views(img, W, H)

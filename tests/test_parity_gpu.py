@@ -66,7 +66,7 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0,
         assert np.array_equal(b["keys_unsorted"].view(np.uint64), fw["keys_unsorted"])
         assert np.array_equal(b["vals_unsorted"].view(np.uint32), fw["vals_unsorted"])
     else:                   # mode 0 sorts 32-bit tile ids; the 64-bit sorted keys are rebuilt on demand
-        b = {k: v.cpu().numpy() for k, v in raster.binning_views(binn, n, geom, P).items()}
+        b = {k: v.cpu().numpy() for k, v in raster.binning_views(binn, n, geom, P, img, W, H).items()}
     assert np.array_equal(b["keys_sorted"].view(np.uint64), fw["keys_sorted"])
     assert np.array_equal(b["point_list"].view(np.uint32), fw["point_list"])
     im = {k: v.cpu().numpy() for k, v in raster.image_views(img, W, H).items()}
@@ -141,7 +141,7 @@ def test_forward_channel_counts(orc, C):
         _check_forward(orc, scene, cam, variant=15)   # SGS_BLEND_EXACT: bit-identical
 
 
-@pytest.mark.parametrize("binning_mode", [0, 1])
+@pytest.mark.parametrize("binning_mode", [0, 1, 2])
 def test_binning_modes_bit_exact(orc, binning_mode):
     """Both binning algorithms give the oracle's sorted keys / lists / ranges; the reference-order
     mode additionally reproduces point_offsets and the emission-order (unsorted) arrays."""
