@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override P (debug)")
     ap.add_argument("--channels", type=int, default=None, help="override C (debug)")
     ap.add_argument("--variant", type=int, default=0, help="blend kernel variant (tuning)")
-    ap.add_argument("--views", type=int, default=2,
+    ap.add_argument("--views", type=int, default=4,
                     help="views in flight per GPU: a step renders this many views of the scene, one per HIP "
                          "stream, so one view's front-end and host round trip overlap another view's blend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
