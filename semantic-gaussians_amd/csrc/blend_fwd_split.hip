@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	__shared__ uint32_t s_amask;           // entries of the batch taken by at least one pixel
 	__shared__ int s_nkeep;                // entries of the batch that survive the tile-level rejection
 	__shared__ int s_alive[4];
-	__shared__ uint32_t s_cnt, s_mask, s_ovf;
+	__shared__ uint32_t s_ovf;
 	__shared__ uint32_t s_chunk[64];   // first slot of each chunk (re-read from `table` beyond 64)
 	__shared__ float s_pend[BF ? 8 * 256 : 1];   // BF: the entry group being filled, [k][px]
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	uint32_t last = 0;
 	bool done = !inside;
 	uint32_t total = 0;     // active entries emitted so far (tile-uniform)
-	uint32_t nchunks = 0;   // chunks reserved so far (only thread 0's copy is authoritative)
+	uint32_t nchunks = 0;   // chunks reserved so far (tile-uniform)
 	if (threadIdx.x == 0) s_ovf = 0u;
 
 	// Staging runs one batch ahead in registers (lanes < WB): at the top of batch b the Gaussian
@@ -266,32 +266,32 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			for (int j = 0; j < nkeep; j++) s_wt[j * 256 + wave * 64 + lane] = 0.0f;
 		}
 		__syncthreads();
-		// ---- compaction into the tile's contiguous chunks
-		if (wave == 0) {
-			const unsigned long long m = (unsigned long long)s_amask;
-			if (lane == 0) {
-				const uint32_t cnt = (uint32_t)__popcll(m);
-				// reserve chunks until [total, total+cnt) is covered
-				while (nchunks * ACH < total + cnt && s_ovf == 0u) {
-					const uint32_t start = atomicAdd(&counter[0], (uint32_t)ACH);
-					if (start + ACH > capacity) {   // arena overflow: flag it, emit nothing more
-						atomicExch(&counter[1], 1u);
-						s_ovf = 1u;
-						break;
-					}
-					table[chunk_base + nchunks] = start;
-					if (nchunks < 64) s_chunk[nchunks] = start;
-					nchunks++;
-				}
-				s_cnt = cnt;
-				s_mask = (uint32_t)m;
-			}
-		}
-		__syncthreads();
+		// ---- compaction into the tile's contiguous chunks.  Every thread derives the same counts from
+		// the activity mask; only when the batch crosses into a new 128-slot chunk (about once per tile)
+		// does thread 0 reserve it and a barrier publish the chunk start.
 		{
-			const uint32_t cnt = s_cnt;
+			const uint32_t amask = s_amask;
+			const uint32_t cnt = (uint32_t)__popc(amask);
+			if (nchunks * ACH < total + cnt) {   // (tile-uniform)
+				if (threadIdx.x == 0) {
+					uint32_t nc = nchunks;
+					while (nc * ACH < total + cnt && s_ovf == 0u) {
+						const uint32_t start = atomicAdd(&counter[0], (uint32_t)ACH);
+						if (start + ACH > capacity) {   // arena overflow: flag it, emit nothing more
+							atomicExch(&counter[1], 1u);
+							s_ovf = 1u;
+							break;
+						}
+						table[chunk_base + nc] = start;
+						if (nc < 64) s_chunk[nc] = start;
+						nc++;
+					}
+				}
+				__syncthreads();
+				nchunks = (total + cnt + ACH - 1) / ACH;
+			}
 			if (s_ovf == 0u) {
-				uint32_t m = s_mask;
+				uint32_t m = amask;
 				for (uint32_t r = 0; r < cnt; r++) {
 					const int e = __builtin_ctz(m);
 					m &= m - 1;
