@@ -202,11 +202,16 @@ int sgs_debug_sorted_keys(int P, int num_rendered, int width, int height,
 int sgs_debug_expf(int n, const float *in, float *out, void *stream);
 
 /* Tuning / measurement hooks (not part of the reference's interface). */
-/* Selects the blend-forward kernel variant (tuning / A-B measurements; all variants are
- * bit-identical).  0 = default: weights pre-pass + LDS-DMA-fed f32-MFMA accumulate for the
- * 128-channel-aligned part, px1 for the rest.  1/2/3 = px1 with 64/128/32 channels per
- * workgroup; 4/5/6 = single-kernel px4 forms; 7/8/9 = split path with scalar-fed VALU
- * accumulate; 10 = split path with LDS-fed VALU accumulate.
+/* Selects the forward blend kernels (tuning / A-B measurements).
+ *   0 (default) = for num_channels >= 128: weights pre-pass + row-sweep split-bf16 MFMA accumulate for the
+ *                 128-channel-aligned part (feature map within 5e-5 of the absolute composite, every
+ *                 integer output bit-exact), px1 for the remainder; px1 below 128 channels / RGB-D;
+ *  15           = as 0 but the accumulate is the fp32-input MFMA kernel: bit-identical feature map
+ *                 (what SGS_BLEND_EXACT=1 selects in the Python layer);
+ *  1/2/3        = single-kernel px1 with 64/128/32 channels per workgroup; 4/5/6 = single-kernel px4
+ *                 forms (all bit-identical);
+ *  >= 16        = sweep tuning word: bits [3:0] = 8, [7:4] segment length / 8 (0 = adaptive),
+ *                 [11:8] development ablations, [15:12] tile-row bands, bit 16 bands on one stream.
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.

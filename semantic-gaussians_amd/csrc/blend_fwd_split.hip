@@ -8,17 +8,15 @@
 //      a compact "work list" in HBM.  This is the only place exp() and the sequential
 //      transmittance chain are evaluated: once per tile instead of once per channel chunk.
 //
-//   2. blend_accum_kernel     one wave = one tile x CW channels, 4 pixels per lane.  A pure
-//      streaming weighted sum  acc[px][ch] += w[px] * feature[id][ch]  over the work list:
-//      weights arrive as one coalesced 1-KB vector load per entry, the wave-uniform feature
-//      slice as scalar loads (s_load_dwordx16) consumed as the SGPR-pair operand of
-//      v_pk_fma_f32 -- the 143 TFLOP/s form measured by tools/ubench_fma.hip.  No LDS, no
-//      barriers, no data-dependent branches inside the loop; both streams are prefetched one
-//      entry ahead.  Each feature byte is fetched once per tile, each weight once per
-//      128 channels (from L2).
+//   2. the accumulate kernel: a pure streaming weighted sum  out[ch][px] = sum_k F[k][ch] * W[k][px]
+//      over the work list, i.e. a matrix product per tile:
+//        blend_accum_sweep_kernel (default)  split-bf16 MFMA products, tile-row sweeps, full-line stores;
+//        blend_accum_mfma_kernel  (SGS_BLEND_EXACT)  fp32-input MFMA, bit-identical to the contract.
+//      (Measured and removed on the way, see DESIGN.md 5 and the git history: scalar-fed and LDS-fed VALU
+//      forms, a 3-stage-ring fp32 MFMA, a per-tile and a tile-pair split-bf16 kernel.)
 //
-// Results are bit-identical to the single-kernel paths (same contract arithmetic, same
-// accumulation order; adding w = 0 is exact).
+// The fp32 path is bit-identical to the single-kernel paths (same contract arithmetic, same
+// accumulation order; adding w = 0 is exact); the default's tolerance is derived in DESIGN.md 5.2.
 //
 // Work-list storage ("arena") is carved from the binning buffer.  A tile's entries are kept
 // contiguous in chunks of 128 slots, bump-allocated with one atomicAdd per chunk (most tiles
@@ -30,13 +28,7 @@
 #include "sgs_kernels.h"
 #include <type_traits>
 
-#ifndef SGS_ACC_PREFETCH
-#define SGS_ACC_PREFETCH 1
-#endif
-
 namespace sgs {
-
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -59,7 +51,7 @@ constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the T * bg pseu
 // MODE 2: as MODE 1, plus one closing pseudo entry per tile whose "weights" are the pixels'
 //         final transmittance and whose id is SGS_BG_ID: the accumulate kernel feeds the
 //         background vector as its feature row, so  + T * bg  falls out of the matrix product.
-// MODE 1: weights split into bf16 hi + bf16 lo (w = hi + lo + O(2^-18 w)) and stored
+// MODE 2 splits the weights into bf16 hi + bf16 lo (w = hi + lo + O(2^-18 w)) and stored
 //             k-major for the bf16 MFMA's B operand: per group of 8 consecutive entries
 //             [256 px][8 x hi] (4 KB) then [256 px][8 x lo] (4 KB); the tile's last 16-entry
 //             batch is padded with zero weights.  Pixels are in row-parity-major order,
@@ -348,267 +340,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	}
 }
 
-// One wave: tile x CW channels, 4 pixels per lane.  Lane l owns work-list pixel indices
-// 4l..4l+3, i.e. strip l>>4, positions 4(l&15)..+3: four consecutive x of one image row.
-//
-// Scalar loads return out of order, so a wave can only wait for ALL of its outstanding ones
-// (lgkmcnt(0)); a measured ~1500-cycle HBM-miss latency per feature fetch therefore cannot be
-// pipelined entry by entry.  Instead the loop works on groups of G entries: issue the G feature
-// slices (G*CW SGPRs), wait once, then run G*CW*2 packed FMAs -- one exposed latency per G
-// entries, hidden by the other resident waves.
-template <int CW, int G>
-__global__ __launch_bounds__(256) void blend_accum_kernel(
-	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
-	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
-	const float4* __restrict__ wgt, const float* __restrict__ features,
-	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
-	int total_blocks, int dbg)
-{
-	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
-	const int b = blockIdx.x;
-	const int v = (b & 7) * per_xcd + (b >> 3);
-	if (v >= total_blocks) return;
-	const int tile = v / nchunks_c;
-	const int chunk = v - tile * nchunks_c;
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int c0 = (chunk * 4 + wave) * CW;
-	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
-	const uint32_t total = nact[tile];
-	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
-
-	f2 acc[4][CW / 2];
-#pragma unroll
-	for (int p = 0; p < 4; p++)
-#pragma unroll
-		for (int c = 0; c < CW / 2; c++) acc[p][c] = (f2){0.f, 0.f};
-
-	for (uint32_t done = 0; done < total; done += ACH) {
-		const uint32_t slot0 = table[chunk_base + done / ACH];
-		const uint32_t cnt = (total - done) < (uint32_t)ACH ? (total - done) : (uint32_t)ACH;
-		// ids of the whole chunk in two coalesced loads; id k is readlane(ids[k>>6], k&63).
-		// Lanes past the end repeat the chunk's first id: a valid row whose weight is 0.
-		const uint32_t idf = act_id[slot0];
-		const uint32_t ids0 = (uint32_t)lane < cnt ? act_id[slot0 + lane] : idf;
-		const uint32_t ids1 = (uint32_t)lane + 64u < cnt ? act_id[slot0 + 64 + lane] : idf;
-		const float4* __restrict__ wrow = wgt + (size_t)slot0 * 64 + lane;
-		// Weights run three entries ahead in four explicitly rotated register sets (vector
-		// loads return in order, so the compiler's counted vmcnt waits expose none of them).
-		// Loads are unconditional with a clamped row index: a conditional float4 load would be
-		// split into four branchy dword loads.
-		const uint32_t last = cnt - 1u;
-#define SGS_WLOAD(k_) wrow[(dbg & 2) ? (size_t)0 : (size_t)((k_) < last ? (k_) : last) * 64]
-#define SGS_STEP(k_, w_)                                                                            \
-	if ((k_) < cnt) {                                                                           \
-		const uint32_t kk_ = (k_);                                                          \
-		const uint32_t idv_ = (kk_ & 64u) ? ids1 : ids0;                                    \
-		const uint32_t id_ = (dbg & 1) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)idv_, (int)(kk_ & 63u)); \
-		const f2* __restrict__ f_ = reinterpret_cast<const f2*>(features + (size_t)id_ * C + c0); \
-		const f2 w0_ = {w_.x, w_.x}, w1_ = {w_.y, w_.y}, w2_ = {w_.z, w_.z}, w3_ = {w_.w, w_.w}; \
-		_Pragma("unroll") for (int c = 0; c < CW / 2; c++) {                                \
-			const f2 fv_ = f_[c];                                                       \
-			acc[0][c] = __builtin_elementwise_fma(fv_, w0_, acc[0][c]);                 \
-			acc[1][c] = __builtin_elementwise_fma(fv_, w1_, acc[1][c]);                 \
-			acc[2][c] = __builtin_elementwise_fma(fv_, w2_, acc[2][c]);                 \
-			acc[3][c] = __builtin_elementwise_fma(fv_, w3_, acc[3][c]);                 \
-		}                                                                                   \
-	}
-		float4 wA = SGS_WLOAD(0u), wB = SGS_WLOAD(1u), wC = SGS_WLOAD(2u), wD;
-		for (uint32_t k = 0; k < cnt; k += 4) {
-			wD = SGS_WLOAD(k + 3u);
-			SGS_STEP(k, wA)
-			wA = SGS_WLOAD(k + 4u);
-			SGS_STEP(k + 1u, wB)
-			wB = SGS_WLOAD(k + 5u);
-			SGS_STEP(k + 2u, wC)
-			wC = SGS_WLOAD(k + 6u);
-			SGS_STEP(k + 3u, wD)
-		}
-#undef SGS_STEP
-#undef SGS_WLOAD
-	}
-
-	// epilogue: lane's 4 pixels are x0..x0+3 of row y -> one 16-B store per channel
-	const int x0 = tx * SGS_TILE + 4 * (lane & 3);
-	const int y = ty * SGS_TILE + (lane >> 4) * 4 + ((lane & 15) >> 2);
-	if (y < H && x0 < W) {
-		const size_t pix = (size_t)y * W + x0;
-		float Tp[4];
-#pragma unroll
-		for (int p = 0; p < 4; p++) Tp[p] = (x0 + p < W) ? final_T[pix + p] : 0.f;
-		const bool full = (x0 + 3 < W) && ((W & 3) == 0);   // 16-B aligned, fully inside
-#pragma unroll
-		for (int c = 0; c < CW; c++) {
-			const float bgc = bg[c0 + c];
-			float o[4];
-#pragma unroll
-			for (int p = 0; p < 4; p++) o[p] = __builtin_fmaf(Tp[p], bgc, acc[p][c >> 1][c & 1]);
-			float* dst = out + (size_t)(c0 + c) * HW + pix;
-			if (full) {
-				*reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-			} else {
-#pragma unroll
-				for (int p = 0; p < 4; p++)
-					if (x0 + p < W) dst[p] = o[p];
-			}
-		}
-	}
-}
-
-// -------------------------------------------------------------------------------------
-// LDS-fed accumulate: one workgroup = tile x 128 channels (4 waves x 32 channels, 4 pixels
-// per lane).  The work list is consumed in batches of AB entries; while batch q is being
-// accumulated, the feature slices (AB x 512 B) and weight rows (AB x 1 KB) of batch q+1 are
-// in flight as LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, one barrier per batch,
-// a whole batch of compute to land) -- this hides the ~1500-cycle HBM-miss latency of the
-// feature gather that per-wave scalar loads cannot pipeline.  Features are then broadcast
-// from LDS (ds_read_b128, 16 FMAs per read with 4 pixels per lane = 48 % LDS utilisation) and
-// consumed by plain v_fmac_f32, which sustains a higher rate than v_pk_fma_f32 at the 3
-// waves/SIMD that 128 accumulators allow (tools/ubench_fma.hip).
 constexpr int AB = 16;   // work-list entries per batch (divides ACH)
-
-__global__ __launch_bounds__(256) void blend_accum_lds_kernel(
-	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
-	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
-	const float4* __restrict__ wgt, const float* __restrict__ features,
-	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
-	int total_blocks)
-{
-	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
-	const int b = blockIdx.x;
-	const int v = (b & 7) * per_xcd + (b >> 3);
-	if (v >= total_blocks) return;
-	const int tile = v / nchunks_c;
-	const int chunk = v - tile * nchunks_c;
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int cbase = chunk * 128;          // the workgroup's 128 channels
-	const int c0 = cbase + wave * 32;       // this wave's 32 channels
-	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
-	const uint32_t total = nact[tile];
-	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
-	const uint32_t Q = (total + AB - 1) / AB;   // batches; AB divides ACH so none straddles a chunk
-
-	// two buffers as four distinct LDS objects: the waitcnt pass can then prove that the
-	// ds_reads of one buffer do not alias the LDS-DMA in flight to the other
-	__shared__ float4 s_featA[AB * 32], s_featB[AB * 32];   // [entry][128 floats]
-	__shared__ float4 s_wA[AB * 64], s_wB[AB * 64];         // [entry][256 floats]
-
-	float acc[4][32];
-#pragma unroll
-	for (int p = 0; p < 4; p++)
-#pragma unroll
-		for (int c = 0; c < 32; c++) acc[p][c] = 0.f;
-
-	// first slot and entry count of batch q
-	auto batch_slot = [&](uint32_t q) -> uint32_t {
-		const uint32_t first = q * AB;
-		return table[chunk_base + (first >> 7)] + (first & 127u);
-	};
-	// ids of the two entries whose feature rows this thread fetches in batch q
-	const int sub = threadIdx.x >> 5;   // 0..7
-	auto load_ids = [&](uint32_t q, uint32_t& i0, uint32_t& i1) {
-		const uint32_t slot = batch_slot(q);
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		const uint32_t e0 = (uint32_t)sub < n ? (uint32_t)sub : n - 1u;
-		const uint32_t e1 = (uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u;
-		i0 = act_id[slot + e0];
-		i1 = act_id[slot + e1];
-	};
-	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
-		const uint32_t slot = batch_slot(q);
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		// features: instruction j covers entries 8j..8j+7, this wave lands 8j+2w, 8j+2w+1
-		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
-		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
-						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32],
-						 16, 0, 0);
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
-						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32],
-						 16, 0, 0);
-		// weights: instruction j lands entry 4j + w (one 1-KB row per wave)
-#pragma unroll
-		for (int j = 0; j < AB / 4; j++) {
-			const uint32_t e = (uint32_t)(4 * j + wave);
-			const uint32_t ec = e < n ? e : n - 1u;
-			const float4* src = wgt + (size_t)(slot + ec) * 64 + lane;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-							 (__attribute__((address_space(3))) void*)&s_w[e * 64],
-							 16, 0, 0);
-		}
-	};
-	auto compute = [&](uint32_t q, const float4* s_feat, const float4* s_w) {
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		for (uint32_t e = 0; e < n; e++) {
-			const float4 w4 = s_w[e * 64 + lane];
-			const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-			for (int c4 = 0; c4 < 8; c4++) {
-				const float4 f4 = s_feat[e * 32 + wave * 8 + c4];
-				const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
-#pragma unroll
-				for (int i = 0; i < 4; i++)
-#pragma unroll
-					for (int p = 0; p < 4; p++)
-						acc[p][4 * c4 + i] = __builtin_fmaf(fv[i], wv[p], acc[p][4 * c4 + i]);
-			}
-		}
-	};
-
-	if (Q > 0) {
-		uint32_t i0, i1, n0 = 0, n1 = 0;
-		load_ids(0, i0, i1);
-		issue(0, s_featA, s_wA, i0, i1);
-		if (Q > 1) load_ids(1, n0, n1);
-		for (uint32_t q = 0; q < Q; q += 2) {
-			__syncthreads();   // batch q has landed in A (vmcnt drained); B is free
-			if (q + 1 < Q) {
-				issue(q + 1, s_featB, s_wB, n0, n1);
-				if (q + 2 < Q) load_ids(q + 2, n0, n1);
-			}
-			compute(q, s_featA, s_wA);
-			if (q + 1 < Q) {
-				__syncthreads();   // batch q+1 has landed in B; A is free
-				if (q + 2 < Q) {
-					issue(q + 2, s_featA, s_wA, n0, n1);
-					if (q + 3 < Q) load_ids(q + 3, n0, n1);
-				}
-				compute(q + 1, s_featB, s_wB);
-			}
-		}
-	}
-
-	// epilogue: lane's 4 pixels are x0..x0+3 of row y -> one 16-B store per channel
-	const int x0 = tx * SGS_TILE + 4 * (lane & 3);
-	const int y = ty * SGS_TILE + (lane >> 4) * 4 + ((lane & 15) >> 2);
-	if (y < H && x0 < W) {
-		const size_t pix = (size_t)y * W + x0;
-		float Tp[4];
-#pragma unroll
-		for (int p = 0; p < 4; p++) Tp[p] = (x0 + p < W) ? final_T[pix + p] : 0.f;
-		const bool full = (x0 + 3 < W) && ((W & 3) == 0);
-#pragma unroll
-		for (int c = 0; c < 32; c++) {
-			const float bgc = bg[c0 + c];
-			float o[4];
-#pragma unroll
-			for (int p = 0; p < 4; p++) o[p] = __builtin_fmaf(Tp[p], bgc, acc[p][c]);
-			float* dst = out + (size_t)(c0 + c) * HW + pix;
-			if (full) {
-				*reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-			} else {
-#pragma unroll
-				for (int p = 0; p < 4; p++)
-					if (x0 + p < W) dst[p] = o[p];
-			}
-		}
-	}
-}
 
 // -------------------------------------------------------------------------------------
 // MFMA accumulate.  The accumulate step IS a matrix product per tile:
@@ -770,408 +502,6 @@ __global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
 				out[(size_t)c * HW + pix] = __builtin_fmaf(Tp, bg[c], acc[nb][r]);
 			}
 		}
-	}
-}
-
-// -------------------------------------------------------------------------------------
-// Split-bf16 MFMA accumulate ("bf16x3").  out[ch][px] = sum_k F[k][ch] * W[k][px] with both
-// operands split into two bf16 terms, F = Fh + Fl, W = Wh + Wl (each split drops O(2^-18) of
-// the value), and three bf16 MFMAs per block, Fl*Wh + Fh*Wl + Fh*Wh, accumulated in fp32:
-// every product is exact in fp32, the dropped Fl*Wl term and the split remainders are
-// <= 3 * 2^-18 ~ 1.1e-5 of |F*W| per term.  Against the exact path the result differs by
-// <= ~1.2e-5 * sum_k |F_k| W_k  -- inside the north star's 1e-4, asserted by the parity tests
-// against the oracle's absolute composite -- while v_mfma_f32_32x32x16_bf16 runs at 16x the
-// f32 MFMA rate, so three of them cost 3/16 of the exact kernel's matrix time and the kernel
-// becomes memory-bound.  The exact f32-MFMA kernel above stays available (blend variant 4).
-//
-// One workgroup = tile x 128 channels; wave w owns channels [64(w&1), +64) x pixels
-// [128(w>>1), +128): 2 x 4 MFMA blocks (128 accumulator VGPRs), which needs 12 KB of LDS
-// operand reads per wave and batch instead of 18 KB for a 32 x 256 wave tile.  Per batch of 16
-// entries: features arrive as fp32 (8 KB) and are split in registers (A: lane l -> channel
-// l&31, entries 8(l>>5)..+7); weights arrive pre-split and k-major from blend_weights_kernel
-// (16 KB; B: lane l -> pixel l&31, entries 8(l>>5)..+7 = one ds_read_b128).
-__global__ __launch_bounds__(256, 2) void blend_accum_bf16_kernel(
-	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
-	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
-	const char* __restrict__ wgt, const float* __restrict__ features,
-	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
-	int total_blocks, int dbg)
-{
-	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
-	const int b = blockIdx.x;
-	const int v = (b & 7) * per_xcd + (b >> 3);
-	if (v >= total_blocks) return;
-	const int tile = v / nchunks_c;
-	const int chunk = v - tile * nchunks_c;
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int cbase = chunk * 128;
-	const int cgrp = wave & 1, pgrp = wave >> 1;
-	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
-	const uint32_t total = nact[tile];
-	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
-	const uint32_t Q = (total + AB - 1) / AB;
-
-	__shared__ float4 s_featA[AB * 32], s_featB[AB * 32];   // [entry][128 floats]
-	__shared__ float4 s_wA[1024], s_wB[1024];               // [group 2][hi, lo][256 px][8 bf16]
-
-	f32x16 acc[2][4];
-#pragma unroll
-	for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-		for (int pb = 0; pb < 4; pb++)
-#pragma unroll
-			for (int r = 0; r < 16; r++) acc[cb][pb][r] = 0.f;
-
-	auto batch_slot = [&](uint32_t q) -> uint32_t {
-		const uint32_t first = q * AB;
-		return table[chunk_base + (first >> 7)] + (first & 127u);
-	};
-	const int sub = threadIdx.x >> 5;
-	auto load_ids = [&](uint32_t q, uint32_t& i0, uint32_t& i1) {
-		const uint32_t slot = batch_slot(q);
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		const uint32_t e0 = (uint32_t)sub < n ? (uint32_t)sub : n - 1u;
-		const uint32_t e1 = (uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u;
-		i0 = act_id[slot + e0];
-		i1 = act_id[slot + e1];
-	};
-	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
-		const uint32_t slot = batch_slot(q);
-		if (!(dbg & 4)) {
-		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
-		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
-						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32],
-						 16, 0, 0);
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
-						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32],
-						 16, 0, 0);
-		}
-		if (dbg & 8) return;
-		const char* wsrc = wgt + (size_t)(slot >> 3) * 8192 + (size_t)threadIdx.x * 16;
-#pragma unroll
-		for (int j = 0; j < 4; j++)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + j * 4096),
-							 (__attribute__((address_space(3))) void*)&s_w[j * 256 + wave * 64],
-							 16, 0, 0);
-	};
-	const int half = lane >> 5, l31 = lane & 31;
-	auto compute = [&](uint32_t q, const float4* s_feat4, const float4* s_w4) {
-		if (dbg & 2) return;
-		const float* s_feat = reinterpret_cast<const float*>(s_feat4);
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		bf16x8 ah[2], al[2];
-#pragma unroll
-		for (int cb = 0; cb < 2; cb++) {
-			const float* fcol = s_feat + (8 * half) * 128 + cgrp * 64 + cb * 32 + l31;
-#pragma unroll
-			for (int k = 0; k < 8; k++) {
-				// rows past n hold a clamped duplicate of the last entry; their weights are
-				// zero, and zeroing the feature too keeps a non-finite duplicate out
-				float f = fcol[k * 128];
-				f = (uint32_t)(8 * half + k) < n ? f : 0.f;
-				ah[cb][k] = (__bf16)f;
-				al[cb][k] = (__bf16)(f - (float)ah[cb][k]);
-			}
-		}
-		const bf16x8* wrow = reinterpret_cast<const bf16x8*>(s_w4) + half * 512 + pgrp * 128 + l31;
-		bf16x8 bh[4], bl[4];
-#pragma unroll
-		for (int pb = 0; pb < 4; pb++) {
-			bh[pb] = wrow[pb * 32];
-			bl[pb] = wrow[256 + pb * 32];
-		}
-#pragma unroll
-		for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-			for (int pb = 0; pb < 4; pb++)
-				acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
-#pragma unroll
-		for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-			for (int pb = 0; pb < 4; pb++)
-				acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
-#pragma unroll
-		for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-			for (int pb = 0; pb < 4; pb++)
-				acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
-	};
-
-	if (Q > 0) {
-		uint32_t i0, i1, n0 = 0, n1 = 0;
-		load_ids(0, i0, i1);
-		issue(0, s_featA, s_wA, i0, i1);
-		if (Q > 1) load_ids(1, n0, n1);
-		for (uint32_t q = 0; q < Q; q += 2) {
-			__syncthreads();
-			if (q + 1 < Q) {
-				issue(q + 1, s_featB, s_wB, n0, n1);
-				if (q + 2 < Q) load_ids(q + 2, n0, n1);
-			}
-			compute(q, s_featA, s_wA);
-			if (q + 1 < Q) {
-				__syncthreads();
-				if (q + 2 < Q) {
-					issue(q + 2, s_featA, s_wA, n0, n1);
-					if (q + 3 < Q) load_ids(q + 3, n0, n1);
-				}
-				compute(q + 1, s_featB, s_wB);
-			}
-		}
-	}
-
-	// epilogue.  D layout: column = lane & 31 -> pixel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-	for (int pb = 0; pb < 4; pb++) {
-		const int qidx = pgrp * 128 + pb * 32 + l31;   // parity-major pixel index
-		const int x = tx * SGS_TILE + (qidx & 15);
-		const int y = ty * SGS_TILE + 2 * ((qidx >> 4) & 7) + (qidx >> 7);
-		if (x < W && y < H && !((dbg & 1) && acc[0][pb][0] != 123.f)) {
-			const size_t pix = (size_t)y * W + x;
-			const float Tp = final_T[pix];
-#pragma unroll
-			for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-				for (int r = 0; r < 16; r++) {
-					const int c = cbase + cgrp * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-					out[(size_t)c * HW + pix] = __builtin_fmaf(Tp, bg[c], acc[cb][pb][r]);
-				}
-		}
-	}
-}
-
-// -------------------------------------------------------------------------------------
-// Split-bf16 accumulate over TILE PAIRS with full-line stores (the default).
-//
-// tools/ubench_store.hip (profiles/r01_ubench_store.txt): writing the (C,H,W) image in the
-// 64-B pieces a single 16-px-wide tile owns runs at 3.5 TB/s, the same bytes as complete,
-// aligned 128-B lines at 4.8-5.2 TB/s -- and with the matrix work on the bf16 pipe the
-// epilogue store is the largest part of the kernel.  A 128-B line of channel c, row y covers
-// 32 pixels = two horizontally adjacent tiles; with a pitch of W*4 bytes (W % 16 == 0) the
-// lines start at x = 0 mod 32 on rows whose y*W is a multiple of 32 and at x = 16 mod 32 on
-// the others (W % 32 == 16: odd rows).  So a workgroup owns, for 128 channels and the rows of
-// one parity p, the pixels of one line column: tiles A = 2k - p*stagger and B = A + 1.  It runs
-// tile A's work list and then tile B's through the same pipeline into two accumulator sets,
-// and the epilogue exchanges 16-lane rows between them (v_permlane16_swap_b32) so that every
-// store instruction writes two complete lines.
-//
-// Wave tile: 64 channels x (64 px of A + 64 px of B): 2 x 2 x 2 MFMA blocks, 128 accumulator
-// VGPRs.  Batch = 32 entries (two k-steps of the 32x32x16 MFMA), two LDS stages of
-// 16 KB fp32 features + 16 KB pre-split weights (only the parity's half of each tile's
-// pixels is fetched).  The Gaussian ids and chunk starts of both tiles are loaded into LDS
-// once, so the per-batch critical path is a single DMA round trip.
-constexpr int PB = 32;      // entries per batch
-constexpr int IDW = 512;    // ids kept in LDS per tile (refilled for longer lists)
-constexpr int NTAB = 32;    // chunk starts kept in LDS per tile
-
-__global__ __launch_bounds__(256, 2) void blend_accum_pair_kernel(
-	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
-	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
-	const char* __restrict__ wgt, const float* __restrict__ features,
-	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int nk,
-	int stagger, int per_xcd, int total_items, int dbg)
-{
-	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
-	const int b = blockIdx.x;
-	const int v = (b & 7) * per_xcd + (b >> 3);
-	if (v >= total_items) return;
-	const int chunk = v % nchunks_c;
-	int rest = v / nchunks_c;
-	const int par = rest & 1;
-	rest >>= 1;
-	const int k = rest % nk, ty = rest / nk;
-	const int txA = 2 * k - par * stagger, txB = txA + 1;
-	const bool validA = txA >= 0 && txA < gx, validB = txB < gx;
-	if (!validA && !validB) return;
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int cbase = chunk * 128;
-	const int cgrp = wave & 1, ph = wave >> 1;
-	const size_t HW = (size_t)H * W;
-	const int tileA = ty * gx + txA, tileB = tileA + 1;
-	const uint32_t totA = validA ? nact[tileA] : 0u, totB = validB ? nact[tileB] : 0u;
-	const uint32_t cbA = validA ? (ranges[tileA].x >> 7) + (uint32_t)tileA : 0u;
-	const uint32_t cbB = validB ? (ranges[tileB].x >> 7) + (uint32_t)tileB : 0u;
-	const uint32_t QA = (totA + PB - 1) / PB, QB = (totB + PB - 1) / PB, QT = QA + QB;
-
-	__shared__ float4 s_f0[PB * 32], s_f1[PB * 32];   // [entry][128 floats]
-	__shared__ float4 s_w0[1024], s_w1[1024];         // [k-group 4][hi, lo][128 px][8 bf16]
-	__shared__ uint32_t s_ids[2][IDW];
-	__shared__ uint32_t s_tab[2][NTAB];
-
-	f32x16 acc[2][2][2];   // [tile][channel block][pixel block]
-#pragma unroll
-	for (int t = 0; t < 2; t++)
-#pragma unroll
-		for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-			for (int pb = 0; pb < 2; pb++)
-#pragma unroll
-				for (int r = 0; r < 16; r++) acc[t][cb][pb][r] = 0.f;
-
-	// ---- chunk starts, then ids, of both tiles into LDS
-	if (threadIdx.x < 2 * NTAB) {
-		const int t = threadIdx.x / NTAB, i = threadIdx.x % NTAB;
-		const uint32_t tot = t ? totB : totA;
-		if ((uint32_t)i * ACH < tot) s_tab[t][i] = table[(t ? cbB : cbA) + i];
-	}
-	__syncthreads();
-	auto chunk_start = [&](int t, uint32_t ci) __attribute__((always_inline)) -> uint32_t {
-		return ci < (uint32_t)NTAB ? s_tab[t][ci] : table[(t ? cbB : cbA) + ci];
-	};
-	auto fill_ids = [&](int t, uint32_t first) __attribute__((always_inline)) {   // entries [first, first + IDW) of tile t
-		const uint32_t tot = t ? totB : totA;
-		for (uint32_t e = first + threadIdx.x; e < first + IDW && e < tot; e += 256)
-			s_ids[t][e - first] = act_id[chunk_start(t, e >> 7) + (e & 127u)];
-	};
-	fill_ids(0, 0);
-	fill_ids(1, 0);
-	__syncthreads();
-
-	// flattened batch j: tile A's batches, then tile B's
-	auto issue = [&](uint32_t j, float4* s_feat, float4* s_w) __attribute__((always_inline)) {
-		const int t = j >= QA ? 1 : 0;
-		const uint32_t q = t ? j - QA : j;
-		const uint32_t tot = t ? totB : totA;
-		const uint32_t first = q * PB;
-		if (first > 0 && (first % IDW) == 0) {   // (uniform) slide the id window
-			__syncthreads();
-			fill_ids(t, first);
-			__syncthreads();
-		}
-		const uint32_t n = (tot - first) < (uint32_t)PB ? (tot - first) : (uint32_t)PB;
-		const uint32_t slot = chunk_start(t, first >> 7) + (first & 127u);
-		const int ninstr = n > 16 ? 4 : 2;
-		if (!(dbg & 4)) {
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			if (i < ninstr) {
-				uint32_t e = (uint32_t)(8 * i + 2 * wave + (lane >> 5));
-				e = e < n ? e : n - 1u;
-				const uint32_t id = s_ids[t][(first % IDW) + e];
-				const float* src = features + (size_t)id * C + cbase + (lane & 31) * 4;
-				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-								 (__attribute__((address_space(3))) void*)&s_feat[(8 * i + 2 * wave) * 32],
-								 16, 0, 0);
-			}
-		}
-		}
-		if (dbg & 8) return;
-		// weights: k-group `wave` (8 entries), hi and lo halves of this parity: 2 x 2 KB
-		if (wave * 8 < (int)((n + 15u) & ~15u)) {
-			const char* wsrc = wgt + (size_t)((slot >> 3) + wave) * 8192 + par * 2048 + lane * 16;
-#pragma unroll
-			for (int hl = 0; hl < 2; hl++)
-#pragma unroll
-				for (int hh = 0; hh < 2; hh++)
-					__builtin_amdgcn_global_load_lds(
-						(const __attribute__((address_space(1))) void*)(wsrc + hl * 4096 + hh * 1024),
-						(__attribute__((address_space(3))) void*)&s_w[(wave * 2 + hl) * 128 + hh * 64],
-						16, 0, 0);
-		}
-	};
-	const int half = lane >> 5, l31 = lane & 31;
-	auto compute = [&](uint32_t j, const float4* s_feat4, const float4* s_w4, auto tsel) __attribute__((always_inline)) {
-		constexpr int T = decltype(tsel)::value;
-		if (dbg & 2) return;
-		const uint32_t q = T ? j - QA : j;
-		const uint32_t tot = T ? totB : totA;
-		const uint32_t n = (tot - q * PB) < (uint32_t)PB ? (tot - q * PB) : (uint32_t)PB;
-		const float* s_feat = reinterpret_cast<const float*>(s_feat4);
-#pragma unroll
-		for (int ks = 0; ks < 2; ks++) {
-			if (ks == 1 && n <= 16) break;
-			bf16x8 ah[2], al[2];
-#pragma unroll
-			for (int cb = 0; cb < 2; cb++) {
-				const float* fcol = s_feat + (ks * 16 + 8 * half) * 128 + cgrp * 64 + cb * 32 + l31;
-				const int nrel = (int)n - (ks * 16 + 8 * half);   // live entries of this lane's k-group
-#pragma unroll
-				for (int kk = 0; kk < 8; kk++) {
-					float f = fcol[kk * 128];
-					f = kk < nrel ? f : 0.f;   // padding rows: see bf16 kernel
-					ah[cb][kk] = (__bf16)f;
-					al[cb][kk] = (__bf16)(f - (float)ah[cb][kk]);
-				}
-			}
-			const bf16x8* wrow = reinterpret_cast<const bf16x8*>(s_w4) + (ks * 2 + half) * 256 + ph * 64 + l31;
-			bf16x8 bh[2], bl[2];
-#pragma unroll
-			for (int pb = 0; pb < 2; pb++) {
-				bh[pb] = wrow[pb * 32];
-				bl[pb] = wrow[128 + pb * 32];
-			}
-#pragma unroll
-			for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-				for (int pb = 0; pb < 2; pb++)
-					acc[T][cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[T][cb][pb], 0, 0, 0);
-#pragma unroll
-			for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-				for (int pb = 0; pb < 2; pb++)
-					acc[T][cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[T][cb][pb], 0, 0, 0);
-#pragma unroll
-			for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-				for (int pb = 0; pb < 2; pb++)
-					acc[T][cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[T][cb][pb], 0, 0, 0);
-		}
-	};
-	auto compute_any = [&](uint32_t j, const float4* s_feat4, const float4* s_w4) __attribute__((always_inline)) {
-		if (j >= QA) compute(j, s_feat4, s_w4, std::integral_constant<int, 1>{});
-		else compute(j, s_feat4, s_w4, std::integral_constant<int, 0>{});
-	};
-
-	if (QT > 0) {
-		issue(0, s_f0, s_w0);
-		for (uint32_t j = 0; j < QT; j += 2) {
-			__syncthreads();
-			if (j + 1 < QT) issue(j + 1, s_f1, s_w1);
-			compute_any(j, s_f0, s_w0);
-			if (j + 1 < QT) {
-				__syncthreads();
-				if (j + 2 < QT) issue(j + 2, s_f0, s_w0);
-				compute_any(j + 1, s_f1, s_w1);
-			}
-		}
-	}
-
-	// ---- epilogue.  Block pb of this wave holds, per tile, rows rp0 = 2*(2*ph + pb) and rp0 + 1
-	// of this parity (lanes 0-15 / 16-31; lanes 32-63 the same for channel + 4).  After the
-	// row swap, register `lo` is row rp0 of A|B and `hi` is row rp0 + 1 of A|B: 32 consecutive x.
-	const int xA0 = txA * SGS_TILE;
-#pragma unroll
-	for (int pb = 0; pb < 2; pb++) {
-		const int rp = 2 * (2 * ph + pb) + ((l31 >> 4) & 1);        // row pair of this lane before the swap
-		const int yown = ty * SGS_TILE + 2 * rp + par;
-		const int xa = xA0 + (l31 & 15), xb = xa + SGS_TILE;
-		const float TA = (validA && yown < H && xa < W) ? final_T[(size_t)yown * W + xa] : 0.f;
-		const float TB = (validB && yown < H && xb < W) ? final_T[(size_t)yown * W + xb] : 0.f;
-		// after the swap lanes 0-31 / 32-63 hold row y0 (register lo) or y0 + 2 (register hi)
-		const int y0 = ty * SGS_TILE + 2 * (2 * (2 * ph + pb)) + par;
-		const int x = xA0 + l31;
-		const bool xok = x >= 0 && x < W && (l31 < 16 ? validA : validB);
-#pragma unroll
-		for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-			for (int r = 0; r < 16; r++) {
-				const int c = cbase + cgrp * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-				const float bgc = bg[c];
-				const float va = __builtin_fmaf(TA, bgc, acc[0][cb][pb][r]);
-				const float vb = __builtin_fmaf(TB, bgc, acc[1][cb][pb][r]);
-				const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
-				float* dst = out + (size_t)c * HW + (size_t)y0 * W + x;
-				if (xok && !((dbg & 1) && va != 123.f)) {
-					if (y0 < H) *dst = __uint_as_float(sw[0]);
-					if (y0 + 2 < H) dst[2 * (size_t)W] = __uint_as_float(sw[1]);
-				}
-			}
 	}
 }
 
@@ -1552,228 +882,6 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the dummy tail bundles before LDS is released
 }
 
-// -------------------------------------------------------------------------------------
-// MFMA accumulate, 3-stage LDS ring.  Same arithmetic as blend_accum_mfma_kernel; the operand
-// bundles (features + weights + the Gaussian ids two batches ahead) run TWO batches ahead of
-// the MFMAs instead of one: with one batch in flight a workgroup spends most of its life
-// waiting for a ~3-4 us DMA round trip per 16 entries (measured: MFMA pipe 54 % busy).
-// There is no ordinary VGPR-returning load inside the loop (ids travel in the DMA bundles),
-// so the only vmcnt waits are the explicit counted ones: `s_waitcnt vmcnt(NDMA)` leaves the
-// next bundle in flight across the raw s_barrier (cdna_hip_programming.md, "glds span").
-constexpr int NDMA = 7;   // LDS-DMA instructions per wave per bundle: 2 feature + 4 weight + 1 id
-
-__global__ __launch_bounds__(256, 2) void blend_accum_mfma3_kernel(
-	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
-	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
-	const float4* __restrict__ wgt, const float* __restrict__ features,
-	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
-	int total_blocks)
-{
-	if (counter[1] != 0u) return;
-	const int b = blockIdx.x;
-	const int v = (b & 7) * per_xcd + (b >> 3);
-	if (v >= total_blocks) return;
-	const int tile = v / nchunks_c;
-	const int chunk = v - tile * nchunks_c;
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int cbase = chunk * 128;
-	const int c0 = cbase + wave * 32;
-	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
-	const uint32_t total = nact[tile];
-	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
-	const uint32_t Q = (total + AB - 1) / AB;
-
-	// three ring stages as distinct LDS objects (alias analysis for the DMA / ds_read overlap)
-	__shared__ float4 s_f0[AB * 32], s_f1[AB * 32], s_f2[AB * 32];
-	// weight stage + 1 KB tail holding, per wave, the ids of batch q+2 (kept inside the same
-	// object: the waitcnt pass tracks at most 8 distinct LDS-DMA destinations precisely)
-	__shared__ float4 s_w0[AB * 64 + 64], s_w1[AB * 64 + 64], s_w2[AB * 64 + 64];
-
-	f32x16 acc[8];
-#pragma unroll
-	for (int nb = 0; nb < 8; nb++)
-#pragma unroll
-		for (int r = 0; r < 16; r++) acc[nb][r] = 0.f;
-
-	auto batch_slot = [&](uint32_t q) -> uint32_t {
-		const uint32_t first = q * AB;
-		return table[chunk_base + (first >> 7)] + (first & 127u);
-	};
-	auto batch_n = [&](uint32_t q) -> uint32_t {
-		return (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-	};
-	const int sub = threadIdx.x >> 5;   // 0..7: which entry of an 8-entry group this lane fetches
-	// bundle q -> (features q, weights q, ids of batch q+2) into one ring stage
-	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
-		uint32_t* s_id = reinterpret_cast<uint32_t*>(s_w + AB * 64);
-		const uint32_t slot = batch_slot(q);
-		const uint32_t n = batch_n(q);
-		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
-		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
-						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32], 16, 0, 0);
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
-						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32], 16, 0, 0);
-#pragma unroll
-		for (int j = 0; j < AB / 4; j++) {
-			const uint32_t e = (uint32_t)(4 * j + wave);
-			const uint32_t ec = e < n ? e : n - 1u;
-			const float4* src = wgt + (size_t)(slot + ec) * 64 + lane;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-							 (__attribute__((address_space(3))) void*)&s_w[e * 64], 16, 0, 0);
-		}
-		// ids of batch q+2 (clamped to the list end; harmless duplicates when it does not exist)
-		const uint32_t q2 = q + 2 < Q ? q + 2 : Q - 1;
-		const uint32_t slot2 = batch_slot(q2);
-		const uint32_t n2 = batch_n(q2);
-		const uint32_t li = (uint32_t)(lane & 15) < n2 ? (uint32_t)(lane & 15) : n2 - 1u;
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(act_id + slot2 + li),
-						 (__attribute__((address_space(3))) void*)&s_id[wave * 64], 4, 0, 0);
-	};
-	const int half = lane >> 5, l31 = lane & 31;
-	// The LDS reads of the ring are issued from inline asm: the compiler's waitcnt pass would
-	// otherwise put s_waitcnt vmcnt(0) in front of every ds_read of an object that ever was an
-	// LDS-DMA destination inside this loop and drain the bundles in flight.  Rules kept here
-	// (cdna_hip_programming.md 5.7): outputs are early-clobber, nothing consumes an output
-	// before the explicit lgkmcnt(0), and that wait takes the values as "+v" so that no use can
-	// be scheduled above it.
-	auto lds_off = [](const void* p) -> uint32_t {
-		return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
-	};
-	auto compute = [&](uint32_t q, const float4* s_feat4, const float4* s_w4) {
-		const uint32_t n = batch_n(q);
-		uint32_t fa = lds_off(s_feat4) + (uint32_t)(half * 128 + wave * 32 + l31) * 4u;   // + e*512
-		uint32_t wa = lds_off(s_w4) + (uint32_t)(half * 256 + l31) * 4u;                  // + e*1024
-		float a, b0, b1, b2, b3;
-		asm volatile(
-			"ds_read_b32 %0, %5\n\t"
-			"ds_read_b32 %1, %6\n\t"
-			"ds_read_b32 %2, %6 offset:128\n\t"
-			"ds_read_b32 %3, %6 offset:256\n\t"
-			"ds_read_b32 %4, %6 offset:384\n\t"
-			"s_waitcnt lgkmcnt(0)"
-			: "=&v"(a), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
-			: "v"(fa), "v"(wa)
-			: "memory");
-		__builtin_amdgcn_sched_barrier(0);
-		for (uint32_t e = 0; e < n; e += 2) {
-			const bool live = e + (uint32_t)half < n;   // odd tail: the second entry is padding
-			float c0_, c1_, c2_, c3_;
-			asm volatile(
-				"ds_read_b32 %0, %4 offset:512\n\t"
-				"ds_read_b32 %1, %4 offset:640\n\t"
-				"ds_read_b32 %2, %4 offset:768\n\t"
-				"ds_read_b32 %3, %4 offset:896"
-				: "=&v"(c0_), "=&v"(c1_), "=&v"(c2_), "=&v"(c3_)
-				: "v"(wa)
-				: "memory");
-			const float z0 = live ? b0 : 0.f, z1 = live ? b1 : 0.f, z2 = live ? b2 : 0.f, z3 = live ? b3 : 0.f;
-			acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z0, acc[0], 0, 0, 0);
-			acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z1, acc[1], 0, 0, 0);
-			acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z2, acc[2], 0, 0, 0);
-			acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z3, acc[3], 0, 0, 0);
-			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0_), "+v"(c1_), "+v"(c2_), "+v"(c3_) : : "memory");
-			__builtin_amdgcn_sched_barrier(0);
-			// next pair (rows past the batch hold the clamped duplicate of the last entry:
-			// finite, masked by `live` when used; never read past the stage: en stays < AB)
-			const uint32_t step = (e + 2 < (uint32_t)AB) ? 1u : 0u;
-			fa += step * 1024u;   // 2 entries x 512 B
-			wa += step * 2048u;   // 2 entries x 1 KB
-			float an, n0, n1, n2, n3;
-			asm volatile(
-				"ds_read_b32 %0, %5\n\t"
-				"ds_read_b32 %1, %6\n\t"
-				"ds_read_b32 %2, %6 offset:128\n\t"
-				"ds_read_b32 %3, %6 offset:256\n\t"
-				"ds_read_b32 %4, %6 offset:384"
-				: "=&v"(an), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
-				: "v"(fa), "v"(wa)
-				: "memory");
-			const float y0 = live ? c0_ : 0.f, y1 = live ? c1_ : 0.f, y2 = live ? c2_ : 0.f, y3 = live ? c3_ : 0.f;
-			acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y0, acc[4], 0, 0, 0);
-			acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y1, acc[5], 0, 0, 0);
-			acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y2, acc[6], 0, 0, 0);
-			acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y3, acc[7], 0, 0, 0);
-			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
-			__builtin_amdgcn_sched_barrier(0);
-			a = an; b0 = n0; b1 = n1; b2 = n2; b3 = n3;
-		}
-	};
-	// this lane's two feature-row ids for a batch, read from the id slot a landed bundle carries
-	auto ids_from = [&](const float4* s_w, uint32_t& i0, uint32_t& i1) {
-		const uint32_t ia = lds_off(s_w + AB * 64) + (uint32_t)(wave * 64 + sub) * 4u;
-		asm volatile(
-			"ds_read_b32 %0, %2\n\t"
-			"ds_read_b32 %1, %2 offset:32\n\t"
-			"s_waitcnt lgkmcnt(0)"
-			: "=&v"(i0), "=&v"(i1)
-			: "v"(ia)
-			: "memory");
-		__builtin_amdgcn_sched_barrier(0);
-	};
-
-#define SGS_WAIT_BUNDLE(n_) __builtin_amdgcn_s_waitcnt((n_) | (7 << 4) | (15 << 8))
-	if (Q > 0) {
-		// prologue: ids of batches 0 and 1 by ordinary loads (nothing in flight yet)
-		uint32_t i0, i1, j0, j1;
-		{
-			const uint32_t n = batch_n(0), slot = batch_slot(0);
-			i0 = act_id[slot + ((uint32_t)sub < n ? (uint32_t)sub : n - 1u)];
-			i1 = act_id[slot + ((uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u)];
-			const uint32_t q1 = Q > 1 ? 1u : 0u;
-			const uint32_t n1 = batch_n(q1), slot1 = batch_slot(q1);
-			j0 = act_id[slot1 + ((uint32_t)sub < n1 ? (uint32_t)sub : n1 - 1u)];
-			j1 = act_id[slot1 + ((uint32_t)sub + 8u < n1 ? (uint32_t)sub + 8u : n1 - 1u)];
-		}
-		issue(0, s_f0, s_w0, i0, i1);
-		issue(Q > 1 ? 1u : 0u, s_f1, s_w1, j0, j1);   // (a dummy re-issue of batch 0 when Q == 1)
-		// straight-line 3-stage body, no early exits: every stage issues exactly one bundle
-		// (clamped to the last batch when the list is exhausted; its data is never consumed)
-		// and computes its batch only if it exists.
-		const uint32_t QL = Q - 1;
-		for (uint32_t q = 0; q < Q; q += 3) {
-			SGS_WAIT_BUNDLE(7);                 // bundle q landed, bundle q+1 may still fly
-			__builtin_amdgcn_s_barrier();
-			ids_from(s_w0, i0, i1);
-			issue(q + 2 < Q ? q + 2 : QL, s_f2, s_w2, i0, i1);
-			compute(q, s_f0, s_w0);
-
-			SGS_WAIT_BUNDLE(7);
-			__builtin_amdgcn_s_barrier();
-			ids_from(s_w1, i0, i1);
-			issue(q + 3 < Q ? q + 3 : QL, s_f0, s_w0, i0, i1);
-			if (q + 1 < Q) compute(q + 1, s_f1, s_w1);
-
-			SGS_WAIT_BUNDLE(7);
-			__builtin_amdgcn_s_barrier();
-			ids_from(s_w2, i0, i1);
-			issue(q + 4 < Q ? q + 4 : QL, s_f1, s_w1, i0, i1);
-			if (q + 2 < Q) compute(q + 2, s_f2, s_w2);
-		}
-		__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the tail bundles before LDS is released
-	}
-#undef SGS_WAIT_BUNDLE
-
-#pragma unroll
-	for (int nb = 0; nb < 8; nb++) {
-		const int qidx = nb * 32 + l31;
-		const int x = tx * SGS_TILE + (qidx & 15);
-		const int y = ty * SGS_TILE + (qidx >> 6) * 4 + ((qidx & 63) >> 4);
-		if (x < W && y < H) {
-			const size_t pix = (size_t)y * W + x;
-			const float Tp = final_T[pix];
-#pragma unroll
-			for (int r = 0; r < 16; r++) {
-				const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-				out[(size_t)c * HW + pix] = __builtin_fmaf(Tp, bg[c], acc[nb][r]);
-			}
-		}
-	}
-}
-
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
 {
 	size_t off = 0;
@@ -1889,55 +997,17 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		}
 		return hipGetLastError();
 	}
-	{
-		const int sm_ = split_mode & 15;
-		if (sm_ == 6 || sm_ == 7) SGS_LAUNCH_W(1, st, 0, ntiles);
-		else SGS_LAUNCH_W(0, st, 0, ntiles);
-		if (mark) mark(mark_user);
-	}
+	// ---- exact path: fp32 weight rows, fp32-input MFMA accumulate, one workgroup per tile x 128 channels
+	SGS_LAUNCH_W(0, st, 0, ntiles);
+	if (mark) mark(mark_user);
 #undef SGS_LAUNCH_W
 	{
-		// split_mode: 0 = 32 channels per wave, 1 entry per scalar wait (default);
-		//             1 = (32, 2);  2 = (16, 4)
-		const int sm = split_mode & 15;
-		const int cw = (sm == 2) ? 16 : 32;
-		const int nchunks = a.C / 128 * (32 / cw);
+		const int nchunks = a.C / 128;
 		const int total = ntiles * nchunks;
 		const int per_xcd = (total + 7) / 8;
-#define SGS_LAUNCH_ACC(CW_, G_)                                                                   \
-	hipLaunchKernelGGL((blend_accum_kernel<CW_, G_>), dim3(per_xcd * 8), dim3(256), 0, st,       \
-			   a.ranges, table, nbatches, act_id, (const float4*)wgt, a.features,        \
-			   a.final_T, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd,   \
-			   total, (split_mode >> 4))
-		if (sm == 7) {
-			const int stagger = (a.W % 32) == 16 ? 1 : 0;
-			const int nk = (a.gx + stagger) / 2 + 1;
-			const int nc = a.C / 128;
-			const int items = a.gy * nk * 2 * nc;
-			const int pxcd = (items + 7) / 8;
-			hipLaunchKernelGGL(blend_accum_pair_kernel, dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table,
-					   nbatches, act_id, (const char*)wgt, a.features, a.final_T, a.bg, a.out,
-					   counter, a.W, a.H, a.C, a.gx, nc, nk, stagger, pxcd, items, split_mode >> 4);
-		} else if (sm == 6)
-			hipLaunchKernelGGL(blend_accum_bf16_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
-					   table, nbatches, act_id, (const char*)wgt, a.features, a.final_T, a.bg,
-					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, split_mode >> 4);
-		else if (sm == 5)
-			hipLaunchKernelGGL(blend_accum_mfma3_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
-					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
-					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);
-		else if (sm == 4)
-			hipLaunchKernelGGL(blend_accum_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
-					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
-					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);
-		else if (sm == 3)
-			hipLaunchKernelGGL(blend_accum_lds_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges,
-					   table, nbatches, act_id, (const float4*)wgt, a.features, a.final_T, a.bg,
-					   a.out, counter, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total);
-		else if (sm == 2) SGS_LAUNCH_ACC(16, 4);
-		else if (sm == 1) SGS_LAUNCH_ACC(32, 2);
-		else SGS_LAUNCH_ACC(32, 1);
-#undef SGS_LAUNCH_ACC
+		hipLaunchKernelGGL(blend_accum_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges, table, nbatches,
+				   act_id, (const float4*)wgt, a.features, a.final_T, a.bg, a.out, counter, a.W, a.H, a.C,
+				   a.gx, nchunks, per_xcd, total);
 	}
 	return hipGetLastError();
 }

@@ -400,7 +400,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	const int sort_bits = 32 + (int)higher_msb((uint32_t)ntiles);
 	// split blend (weights pre-pass + streaming accumulate) for the 128-channel-aligned part
 	const int variant = g_blend_variant.load();
-	const bool use_split = (variant == 0 || (variant >= 7 && variant <= 15) || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
+	const bool use_split = (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
 	if (use_split) {
@@ -499,7 +499,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	if (use_split) {
 		char* arena = bchunk + bl.arena;
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
-		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 0 ? (8 | (1 << 12)) : variant == 7 ? 1 : (variant == 8 ? 2 : (variant == 9 ? 0 : (variant == 10 ? 3 : (variant == 11 ? 5 : (variant == 12 ? 6 : (variant == 13 ? 7 : (variant == 14 ? 8 : 4)))))))));
+		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 15 ? 4 : (8 | (1 << 12))));
 		if (e != hipSuccess) return fail_hip(e, "blend forward (split)");
 		const uint32_t* counter = (const uint32_t*)(arena + bl.arena_lay.counter);
 		const int c_split = (num_channels / 128) * 128;

@@ -40,7 +40,7 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0,
     from sgs_hip import raster
     if exact is None:   # the C >= 128 default (0) and variants 12-14 accumulate in split bf16; all else is bit-exact
         Cn = 3 if kw.get("shs") is not None else (scene.features.shape[1] if kw.get("colors") is None else kw["colors"].shape[1])
-        bf16 = variant in (0, 12, 13, 14) or (variant >= 16 and (variant & 15) in (6, 7, 8))
+        bf16 = variant in (0, 14) or (variant >= 16 and (variant & 15) == 8)
         exact = not (bf16 and Cn >= 128 and not want_depth)
     fw = oracle_forward(orc, scene, cam, want_depth=want_depth, **kw)
     raster.set_binning_mode(binning_mode)
@@ -101,18 +101,18 @@ def test_expf_contract_bit_exact(orc):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [15, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [15, 1, 2, 3, 4, 5, 6])
 def test_forward_c128_all_variants(orc, variant):
-    """Every bit-exact blend variant (15 = the SGS_BLEND_EXACT default, fp32 MFMA)."""
+    """Every bit-exact blend variant (15 = SGS_BLEND_EXACT: fp32 MFMA accumulate; 1-6 single-kernel forms)."""
     scene, cam = small_scene(P=3000, C=128, W=200, H=120, fx=170.0, seed=1)
     fw = _check_forward(orc, scene, cam, variant=variant)
     assert fw["n_contrib"].max() > 20 and (fw["final_T"] < 1e-3).any()   # early stop exercised
 
 
-@pytest.mark.parametrize("variant", [0, 12, 13, 14])
+@pytest.mark.parametrize("variant", [0, 8 + 4096 + 16 * 1])
 @pytest.mark.parametrize("C,W,H", [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64)])
 def test_forward_split_bf16_within_tolerance(orc, variant, C, W, H):
-    """Split-bf16 accumulate (12: per tile, 13: tile pairs with full-line stores): integer state
+    """Split-bf16 row-sweep accumulate (default, and with forced 8-tile segments): integer state
     bit-exact, feature map within 5e-5 of the absolute composite.  Widths cover W % 32 == 16
     (staggered pairs), W % 32 == 0, ragged W and a single tile."""
     scene, cam = small_scene(P=3000, C=C, W=W, H=H, fx=170.0, seed=C + W)
