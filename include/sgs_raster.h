@@ -211,7 +211,7 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  *  1/2/3        = single-kernel px1 with 64/128/32 channels per workgroup; 4/5/6 = single-kernel px4
  *                 forms (all bit-identical);
  *  >= 16        = sweep tuning word: bits [3:0] = 8, [7:4] segment length / 8 (0 = adaptive),
- *                 [11:8] development ablations, [15:12] tile-row bands, bit 16 bands on one stream.
+ *                 [11:8] development ablations (1 = no stores, 2 = no matrix work, 4 = plain C++ stores).
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.

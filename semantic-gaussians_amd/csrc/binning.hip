@@ -307,25 +307,4 @@ void launch_tile_ranges32(hipStream_t st, size_t L, const uint32_t* tiles, uint2
 			   (uint32_t)L, tiles, ranges);
 }
 
-// keys_sorted[i] = tile << 32 | depth bits of point_list[i]: the reference's sorted 64-bit keys,
-// materialised on demand (parity tests); nothing on the render path reads them.
-__global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t L,
-								const uint32_t* __restrict__ tiles,
-								const uint32_t* __restrict__ point_list,
-								const float* __restrict__ depths,
-								uint64_t* __restrict__ keys_sorted)
-{
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= L) return;
-	keys_sorted[i] = ((uint64_t)tiles[i] << 32) | (uint64_t)__float_as_uint(depths[point_list[i]]);
-}
-
-void launch_reconstruct_keys(hipStream_t st, size_t L, const uint32_t* tiles,
-			     const uint32_t* point_list, const float* depths, uint64_t* keys_sorted)
-{
-	if (L == 0) return;
-	hipLaunchKernelGGL(reconstruct_keys_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st,
-			   (uint32_t)L, tiles, point_list, depths, keys_sorted);
-}
-
 } // namespace sgs

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const char* __restrict__ wgt, const float* __restrict__ features,
 	const float* __restrict__ bg, float* __restrict__ out, const uint32_t* __restrict__ counter,
-	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int ty0)
+	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items)
 {
 	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
 	const int b = blockIdx.x;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const int g = (v / nchunks_c) & 1;   // row parity of this workgroup
 	const int rest = v / (2 * nchunks_c);
 	const int stagger = (W & 31) == 16 ? 1 : 0;   // odd rows start 64 B into a line (else every row is aligned alike)
-	const int sg = rest % nseg, ty = ty0 + rest / nseg;   // tile rows [ty0, ...) of this band
+	const int sg = rest % nseg, ty = rest / nseg;
 	const int tx0 = sg * seg;   // even (seg is even)
 	const int nt = (gx - tx0) < seg ? (gx - tx0) : seg;
 	const int lane = threadIdx.x & 63;
@@ -898,31 +898,6 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	return a.total;
 }
 
-namespace {
-// Helper stream + events for the banded overlap of the two blend kernels (one set per device).
-struct BandCtx {
-	hipStream_t wstream = nullptr;
-	hipEvent_t start = nullptr;
-	hipEvent_t wdone[8] = {};
-};
-BandCtx* band_ctx()
-{
-	static BandCtx ctx[16];
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-	BandCtx& c = ctx[dev];
-	if (!c.wstream) {
-		int least = 0, greatest = 0;   // weights fill in around the sweep, not the other way round
-		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		if (hipStreamCreateWithPriority(&c.wstream, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-		if (hipEventCreateWithFlags(&c.start, hipEventDisableTiming) != hipSuccess) return nullptr;
-		for (int i = 0; i < 8; i++)
-			if (hipEventCreateWithFlags(&c.wdone[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-	}
-	return &c;
-}
-} // namespace
-
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
 				      int split_mode)
@@ -941,9 +916,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   act_id, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx,        \
 			   ((NT_) + 7) / 8, NT_, T0_)
 	if ((split_mode & 15) == 8) {
-		// ---- row-sweep path.  The weights kernel is instruction-bound, the sweep memory-bound, and
-		// one sweep workgroup leaves room for a weights workgroup on the same CU: the image is cut
-		// into bands of tile rows, weights of band i+1 run on a helper stream while band i is swept.
+		// ---- row-sweep path (default)
 		// segment length: long sweeps amortise the prologue and leave few half-line stores at segment
 		// ends (cfg3: 48 -> 2 segments per tile row is 3 % faster than 16), but there must be enough
 		// workgroups to fill 256 CUs x 2 a few times over.
@@ -954,47 +927,22 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			while (seg > 8 && (long long)a.gy * ((a.gx + seg - 1) / seg) * nc * 2 < 1536) seg /= 2;
 		const int nseg = (a.gx + seg - 1) / seg;
 		seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
-		int nbands = (split_mode >> 12) & 15;
-		if (nbands == 0) nbands = 4;
-		if (nbands > 8) nbands = 8;
-		if (nbands > a.gy) nbands = a.gy;
-		const bool serial = ((split_mode >> 16) & 1) != 0;   // bands back to back on `st`: a band's weights stay in the 256-MB Infinity Cache
-		BandCtx* ctx = (nbands > 1 && !serial) ? band_ctx() : nullptr;
-		if (!ctx && !serial) nbands = 1;
-		if (ctx) {
-			if ((e = hipEventRecord(ctx->start, st)) != hipSuccess) return e;
-			if ((e = hipStreamWaitEvent(ctx->wstream, ctx->start, 0)) != hipSuccess) return e;
-		}
-		hipStream_t ws = ctx ? ctx->wstream : st;
-		for (int bnd = 0; bnd < nbands && !serial; bnd++) {   // all weights launches first: they only queue
-			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
-			const int t0 = r0 * a.gx, nt = (r1 - r0) * a.gx;
-			SGS_LAUNCH_W(2, ws, t0, nt);
-			if (ctx && (e = hipEventRecord(ctx->wdone[bnd], ws)) != hipSuccess) return e;
-		}
-		for (int bnd = 0; bnd < nbands; bnd++) {
-			const int r0 = (int)((long long)a.gy * bnd / nbands), r1 = (int)((long long)a.gy * (bnd + 1) / nbands);
-			if (serial) {
-				const int t0 = r0 * a.gx, nt = (r1 - r0) * a.gx;
-				SGS_LAUNCH_W(2, st, t0, nt);
-			}
-			if (ctx && (e = hipStreamWaitEvent(st, ctx->wdone[bnd], 0)) != hipSuccess) return e;
-			if (bnd == 0 && mark) mark(mark_user);
-			const int items = (r1 - r0) * nseg * nc * 2;   // x 2 row parities
-			const int pxcd = (items + 7) / 8;
+		SGS_LAUNCH_W(2, st, 0, ntiles);
+		if (mark) mark(mark_user);
+		const int items = a.gy * nseg * nc * 2;   // x 2 row parities
+		const int pxcd = (items + 7) / 8;
 #define SGS_LAUNCH_SWEEP(D_)                                                                         \
 	hipLaunchKernelGGL(blend_accum_sweep_kernel<D_>, dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
-			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, r0)
-			switch ((split_mode >> 8) & 15) {
-			case 1: SGS_LAUNCH_SWEEP(1); break;
-			case 2: SGS_LAUNCH_SWEEP(2); break;
-			case 3: SGS_LAUNCH_SWEEP(3); break;
-			case 4: SGS_LAUNCH_SWEEP(4); break;
-			default: SGS_LAUNCH_SWEEP(0); break;
-			}
-#undef SGS_LAUNCH_SWEEP
+			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items)
+		switch ((split_mode >> 8) & 15) {
+		case 1: SGS_LAUNCH_SWEEP(1); break;
+		case 2: SGS_LAUNCH_SWEEP(2); break;
+		case 3: SGS_LAUNCH_SWEEP(3); break;
+		case 4: SGS_LAUNCH_SWEEP(4); break;
+		default: SGS_LAUNCH_SWEEP(0); break;
 		}
+#undef SGS_LAUNCH_SWEEP
 		return hipGetLastError();
 	}
 	// ---- exact path: fp32 weight rows, fp32-input MFMA accumulate, one workgroup per tile x 128 channels

@@ -39,8 +39,6 @@ hipError_t launch_sort32_pairs(hipStream_t st, void* temp, size_t temp_bytes, ui
 			       uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t L,
 			       int end_bit);
 void launch_tile_ranges32(hipStream_t st, size_t L, const uint32_t* tiles, uint2* ranges, int ntiles);
-void launch_reconstruct_keys(hipStream_t st, size_t L, const uint32_t* tiles,
-			     const uint32_t* point_list, const float* depths, uint64_t* keys_sorted);
 // ---- binning_rows.hip (binning mode 0)
 size_t scan64_temp_bytes(int P);
 hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes, int P, const uint32_t* perm,
