@@ -105,3 +105,18 @@ def test_shard_helpers_single_process():
     with pytest.raises(ValueError):
         sd.channel_slice(10, 0, 4)
     assert sd.world() == (0, 1)
+
+
+def test_render_views_pipelined_without_gpu_is_serial():
+    """On a host without a GPU the pipelining helper degrades to a plain loop (slot 0, view order)."""
+    from sgs_hip import dist as sd
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    calls = []
+
+    def render(view, slot):
+        calls.append((view, slot))
+        return view * 2
+
+    assert sd.render_views_pipelined(render, [3, 1, 2], in_flight=2) == [6, 2, 4]
+    assert calls == [(3, 0), (1, 0), (2, 0)]
