@@ -8,12 +8,13 @@
 //      a compact "work list" in HBM.  This is the only place exp() and the sequential
 //      transmittance chain are evaluated: once per tile instead of once per channel chunk.
 //
-//   2. the accumulate kernel: a pure streaming weighted sum  out[ch][px] = sum_k F[k][ch] * W[k][px]
-//      over the work list, i.e. a matrix product per tile:
-//        blend_accum_sweep_kernel (default)  split-bf16 MFMA products, tile-row sweeps, full-line stores;
-//        blend_accum_mfma_kernel  (SGS_BLEND_EXACT)  fp32-input MFMA, bit-identical to the contract.
+//   2. blend_accum_sweep_kernel   a pure streaming weighted sum  out[ch][px] = sum_k F[k][ch] * W[k][px]
+//      over the work list, i.e. a matrix product per tile, as tile-row sweeps with full-line stores:
+//        <.., false> (default)          split-bf16 MFMA products, fp32 accumulate;
+//        <.., true>  (SGS_BLEND_EXACT)  fp32-input MFMA, bit-identical to the contract.
 //      (Measured and removed on the way, see DESIGN.md 5 and the git history: scalar-fed and LDS-fed VALU
-//      forms, a 3-stage-ring fp32 MFMA, a per-tile and a tile-pair split-bf16 kernel.)
+//      forms, per-tile fp32-MFMA kernels with 2- and 3-stage rings, a per-tile and a tile-pair
+//      split-bf16 kernel.)
 //
 // The fp32 path is bit-identical to the single-kernel paths (same contract arithmetic, same
 // accumulation order; adding w = 0 is exact); the default's tolerance is derived in DESIGN.md 5.2.
@@ -43,20 +44,20 @@ struct StagedEntryW {   // 40 B per list entry in LDS
 
 constexpr int WB = 16;    // list entries per batch
 constexpr int ACH = 128;  // work-list slots per chunk
-constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the T * bg pseudo entry (weights MODE 2)
+constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the closing T * bg pseudo entry
 
 } // namespace
 
-// MODE 0: work-list rows of 256 fp32 weights per entry (the exact accumulate kernels).
-// MODE 2: as MODE 1, plus one closing pseudo entry per tile whose "weights" are the pixels'
-//         final transmittance and whose id is SGS_BG_ID: the accumulate kernel feeds the
-//         background vector as its feature row, so  + T * bg  falls out of the matrix product.
-// MODE 2 splits the weights into bf16 hi + bf16 lo (w = hi + lo + O(2^-18 w)) and stored
-//             k-major for the bf16 MFMA's B operand: per group of 8 consecutive entries
-//             [256 px][8 x hi] (4 KB) then [256 px][8 x lo] (4 KB); the tile's last 16-entry
-//             batch is padded with zero weights.  Pixels are in row-parity-major order,
-//             px' = (y & 1) * 128 + (y >> 1) * 16 + x, so that the rows of one parity are a
-//             contiguous 2-KB half (blend_accum_pair_kernel reads only one of them).
+// Work-list weight formats.  Common to both: pixels in row-parity-major order
+// px' = (y & 1) * 128 + (y >> 1) * 16 + x (the rows of one parity are a contiguous half: a sweep
+// workgroup reads only its own); every tile's list ends with a pseudo entry whose "weights" are the
+// pixels' final transmittance and whose id is SGS_BG_ID (the accumulate kernel feeds the background
+// vector as its feature row, so  + T * bg  falls out of the matrix product); the tile's last 16-entry
+// batch is padded with zero weights.
+// MODE 2 (default): weights split into bf16 hi + bf16 lo (w = hi + lo + O(2^-16 w)), k-major for the bf16
+//                   MFMA's B operand: per group of 8 consecutive entries [256 px'][8 x hi] (4 KB) then
+//                   [256 px'][8 x lo] (4 KB).
+// MODE 3 (exact):   fp32 rows, [entry][256 px'] (1 KB per entry).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE>
@@ -69,7 +70,9 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	int H, int gx, int per_xcd, int ntiles, int tile_begin)
 {
 	const int b = blockIdx.x;
-	constexpr bool BF = MODE != 0;
+	static_assert(MODE == 2 || MODE == 3, "weights format: 2 = split bf16 (default), 3 = fp32 rows (exact)");
+	constexpr bool BF = MODE == 2;   // weights as split bf16, k-major groups of 8 (else fp32 rows of 256)
+	constexpr bool SWEEP = true;     // parity-major pixel order, closing T * bg pseudo entry, zero padding to 16
 	const int tl = (b & 7) * per_xcd + (b >> 3);   // tiles [tile_begin, tile_begin + ntiles)
 	if (tl >= ntiles) return;
 	const int tile = tile_begin + tl;
@@ -79,6 +82,8 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	const int px = tx * SGS_TILE + (lane & 15);
 	const int py = ty * SGS_TILE + wave * 4 + (lane >> 4);
 	const bool inside = px < W && py < H;
+	// this pixel's index in row-parity-major order (the sweep kernels' layout)
+	const int pxp_own = ((wave * 4 + (lane >> 4)) & 1) * 128 + ((wave * 4 + (lane >> 4)) >> 1) * 16 + (lane & 15);
 	const float pxf = (float)px, pyf = (float)py;
 	const uint2 range = ranges[tile];
 	const int n_total = (int)(range.y - range.x);
@@ -107,10 +112,8 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			lo[k] = (__bf16)(v - (float)hi[k]);
 		}
 		bf16x8* dst = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * 8192);
-		const int yl = wave * 4 + (lane >> 4);
-		const int pxp = (yl & 1) * 128 + (yl >> 1) * 16 + (lane & 15);
-		dst[pxp] = hi;
-		dst[256 + pxp] = lo;
+		dst[pxp_own] = hi;
+		dst[256 + pxp_own] = lo;
 	};
 
 	float T = 1.0f;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 						s_pend[(g & 7u) * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
 						if ((g & 7u) == 7u) flush_group(g >> 3);
 					} else {
-						wgt[(size_t)slot * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
+						wgt[(size_t)slot * 256 + (SWEEP ? pxp_own : (int)threadIdx.x)] = s_wt[e * 256 + threadIdx.x];
 					}
 					if (threadIdx.x == 0) act_id[slot] = s_e[e].id;
 				}
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			total += cnt;
 		}
 	}
-	if (MODE == 2) {   // the closing T * bg pseudo entry (every tile gets one, also an empty tile)
+	if (SWEEP) {   // the closing T * bg pseudo entry (every tile gets one, also an empty tile)
 		__syncthreads();
 		if (threadIdx.x == 0 && nchunks * ACH < total + 1u && s_ovf == 0u) {
 			const uint32_t start = atomicAdd(&counter[0], (uint32_t)ACH);
@@ -319,17 +322,28 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		if (s_ovf == 0u) {
 			const uint32_t g = total, ci = g / ACH;
 			const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
-			s_pend[(g & 7u) * 256 + threadIdx.x] = inside ? T : 0.0f;
+			const float wT = inside ? T : 0.0f;
+			if (BF) {
+				s_pend[(g & 7u) * 256 + threadIdx.x] = wT;
+				if ((g & 7u) == 7u) flush_group(g >> 3);
+			} else {
+				wgt[(size_t)(cstart + (g % ACH)) * 256 + pxp_own] = wT;
+			}
 			if (threadIdx.x == 0) act_id[cstart + (g % ACH)] = SGS_BG_ID;
-			if ((g & 7u) == 7u) flush_group(g >> 3);
 		}
 		total += 1u;
 	}
-	if (BF && s_ovf == 0u) {   // zero-pad the last batch to 16 entries (all inside the tile's last chunk)
+	if (SWEEP && s_ovf == 0u) {   // zero-pad the last batch to 16 entries (all inside the tile's last chunk)
 		const uint32_t pad_end = (total + 15u) & ~15u;
 		for (uint32_t g = total; g < pad_end; g++) {
-			s_pend[(g & 7u) * 256 + threadIdx.x] = 0.0f;
-			if ((g & 7u) == 7u) flush_group(g >> 3);
+			if (BF) {
+				s_pend[(g & 7u) * 256 + threadIdx.x] = 0.0f;
+				if ((g & 7u) == 7u) flush_group(g >> 3);
+			} else {
+				const uint32_t ci = g / ACH;
+				const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+				wgt[(size_t)(cstart + (g % ACH)) * 256 + pxp_own] = 0.0f;
+			}
 		}
 	}
 	if (threadIdx.x == 0) nact[tile] = total;
@@ -342,168 +356,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 
 constexpr int AB = 16;   // work-list entries per batch (divides ACH)
 
-// -------------------------------------------------------------------------------------
-// MFMA accumulate.  The accumulate step IS a matrix product per tile:
-//     out[ch][px] = sum_k F[k][ch] * W[k][px]        (k = work-list entry, in list order)
-// and rocprof shows the VALU version pinned at the vector-FMA issue rate (profiles/r01a), not
-// at HBM.  gfx950's f32-input MFMA (v_mfma_f32_32x32x2_f32) evaluates exactly a k-ordered
-// fmaf chain -- D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per product, no wider
-// accumulation -- so it returns the SAME BITS as the scalar contract (and as the oracle) at
-// the full 64 FLOP/clk/SIMD rate that plain v_fmac_f32 cannot sustain.  Zero weights (pixels
-// an entry does not touch, odd-tail padding) add exactly +0.
-//
-// One workgroup = tile x 128 channels; wave w owns channels [32w, 32w+32) for all 256 pixels:
-// 8 MFMA blocks of 32 channels x 32 pixels (8 x 16 accumulator VGPRs).  Per pair of entries:
-// 1 ds_read_b32 of features (A: lane l -> channel l&31 of entry l>>5), 8 ds_read_b32 of
-// weights (B: lane l -> pixel 32*nb + (l&31) of entry l>>5), 8 MFMAs.  Operands are staged by
-// LDS-DMA one batch ahead exactly as in blend_accum_lds_kernel.  D has pixels along lanes, so
-// the epilogue stores 32 consecutive pixels of one channel per half wave (2 x 64-B rows).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__global__ __launch_bounds__(256, 3) void blend_accum_mfma_kernel(
-	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
-	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
-	const float4* __restrict__ wgt, const float* __restrict__ features,
-	const float* __restrict__ final_T, const float* __restrict__ bg, float* __restrict__ out,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int nchunks_c, int per_xcd,
-	int total_blocks)
-{
-	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
-	const int b = blockIdx.x;
-	const int v = (b & 7) * per_xcd + (b >> 3);
-	if (v >= total_blocks) return;
-	const int tile = v / nchunks_c;
-	const int chunk = v - tile * nchunks_c;
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int cbase = chunk * 128;
-	const int c0 = cbase + wave * 32;
-	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
-	const uint32_t total = nact[tile];
-	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
-	const uint32_t Q = (total + AB - 1) / AB;
-
-	__shared__ float4 s_featA[AB * 32], s_featB[AB * 32];   // [entry][128 floats]
-	__shared__ float4 s_wA[AB * 64], s_wB[AB * 64];         // [entry][256 floats]
-
-	f32x16 acc[8];
-#pragma unroll
-	for (int nb = 0; nb < 8; nb++)
-#pragma unroll
-		for (int r = 0; r < 16; r++) acc[nb][r] = 0.f;
-
-	auto batch_slot = [&](uint32_t q) -> uint32_t {
-		const uint32_t first = q * AB;
-		return table[chunk_base + (first >> 7)] + (first & 127u);
-	};
-	const int sub = threadIdx.x >> 5;
-	auto load_ids = [&](uint32_t q, uint32_t& i0, uint32_t& i1) {
-		const uint32_t slot = batch_slot(q);
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		const uint32_t e0 = (uint32_t)sub < n ? (uint32_t)sub : n - 1u;
-		const uint32_t e1 = (uint32_t)sub + 8u < n ? (uint32_t)sub + 8u : n - 1u;
-		i0 = act_id[slot + e0];
-		i1 = act_id[slot + e1];
-	};
-	auto issue = [&](uint32_t q, float4* s_feat, float4* s_w, uint32_t i0, uint32_t i1) {
-		const uint32_t slot = batch_slot(q);
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		const float* src0 = features + (size_t)i0 * C + cbase + (threadIdx.x & 31) * 4;
-		const float* src1 = features + (size_t)i1 * C + cbase + (threadIdx.x & 31) * 4;
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
-						 (__attribute__((address_space(3))) void*)&s_feat[(2 * wave) * 32],
-						 16, 0, 0);
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
-						 (__attribute__((address_space(3))) void*)&s_feat[(8 + 2 * wave) * 32],
-						 16, 0, 0);
-#pragma unroll
-		for (int j = 0; j < AB / 4; j++) {
-			const uint32_t e = (uint32_t)(4 * j + wave);
-			const uint32_t ec = e < n ? e : n - 1u;
-			const float4* src = wgt + (size_t)(slot + ec) * 64 + lane;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-							 (__attribute__((address_space(3))) void*)&s_w[e * 64],
-							 16, 0, 0);
-		}
-	};
-	const int half = lane >> 5, l31 = lane & 31;
-	// Software-pipelined at half-pair granularity: the four B operands of the next group are
-	// in flight (ds_read_b32) while the four MFMAs of the current group occupy the matrix pipe
-	// (4 x 64 cycles >> LDS latency), so one wave alone can keep the pipe busy.
-	auto compute = [&](uint32_t q, const float4* s_feat4, const float4* s_w4) {
-		const float* s_feat = reinterpret_cast<const float*>(s_feat4);
-		const float* s_w = reinterpret_cast<const float*>(s_w4);
-		const uint32_t n = (total - q * AB) < (uint32_t)AB ? (total - q * AB) : (uint32_t)AB;
-		const float* fcol = s_feat + half * 128 + wave * 32 + l31;   // + e*128
-		const float* wcol = s_w + half * 256 + l31;                   // + e*256 + nb*32
-		float a = fcol[0];
-		float b0 = wcol[0], b1 = wcol[32], b2 = wcol[64], b3 = wcol[96];
-		for (uint32_t e = 0; e < n; e += 2) {
-			const bool live = e + (uint32_t)half < n;   // odd tail: the second entry is padding
-			const float* wr = wcol + e * 256;
-			const float c0_ = wr[128], c1_ = wr[160], c2_ = wr[192], c3_ = wr[224];
-			const float z0 = live ? b0 : 0.f, z1 = live ? b1 : 0.f, z2 = live ? b2 : 0.f, z3 = live ? b3 : 0.f;
-			acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z0, acc[0], 0, 0, 0);
-			acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z1, acc[1], 0, 0, 0);
-			acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z2, acc[2], 0, 0, 0);
-			acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z3, acc[3], 0, 0, 0);
-			// next pair's feature column and first group (LDS rows past n hold the clamped
-			// duplicate of the last entry: finite, and masked by `live` when used)
-			const uint32_t en = (e + 2 < (uint32_t)AB) ? e + 2 : e;
-			const float an = fcol[en * 128];
-			const float* wn = wcol + en * 256;
-			b0 = wn[0]; b1 = wn[32]; b2 = wn[64]; b3 = wn[96];
-			const float y0 = live ? c0_ : 0.f, y1 = live ? c1_ : 0.f, y2 = live ? c2_ : 0.f, y3 = live ? c3_ : 0.f;
-			acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y0, acc[4], 0, 0, 0);
-			acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y1, acc[5], 0, 0, 0);
-			acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y2, acc[6], 0, 0, 0);
-			acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y3, acc[7], 0, 0, 0);
-			a = an;
-		}
-	};
-
-	if (Q > 0) {
-		uint32_t i0, i1, n0 = 0, n1 = 0;
-		load_ids(0, i0, i1);
-		issue(0, s_featA, s_wA, i0, i1);
-		if (Q > 1) load_ids(1, n0, n1);
-		for (uint32_t q = 0; q < Q; q += 2) {
-			__syncthreads();
-			if (q + 1 < Q) {
-				issue(q + 1, s_featB, s_wB, n0, n1);
-				if (q + 2 < Q) load_ids(q + 2, n0, n1);
-			}
-			compute(q, s_featA, s_wA);
-			if (q + 1 < Q) {
-				__syncthreads();
-				if (q + 2 < Q) {
-					issue(q + 2, s_featA, s_wA, n0, n1);
-					if (q + 3 < Q) load_ids(q + 3, n0, n1);
-				}
-				compute(q + 1, s_featB, s_wB);
-			}
-		}
-	}
-
-	// epilogue.  D layout (32x32x2, dtype-independent): column = lane & 31 -> pixel 32*nb + l31,
-	// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -> channel c0 + row.
-#pragma unroll
-	for (int nb = 0; nb < 8; nb++) {
-		const int qidx = nb * 32 + l31;              // work-list pixel index: strip*64 + pos
-		const int x = tx * SGS_TILE + (qidx & 15);
-		const int y = ty * SGS_TILE + (qidx >> 6) * 4 + ((qidx & 63) >> 4);
-		if (x < W && y < H) {
-			const size_t pix = (size_t)y * W + x;
-			const float Tp = final_T[pix];
-#pragma unroll
-			for (int r = 0; r < 16; r++) {
-				const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-				out[(size_t)c * HW + pix] = __builtin_fmaf(Tp, bg[c], acc[nb][r]);
-			}
-		}
-	}
-}
 
 // -------------------------------------------------------------------------------------
 // Row-sweep split-bf16 accumulate (the default when W % 32 == 16).
@@ -681,12 +534,58 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 	}
 }
 
+// The same batch with fp32-input MFMAs (SGS_BLEND_EXACT): weights are fp32 rows [entry][128 px], one
+// v_mfma_f32_32x32x2_f32 per pair of entries and pixel block -- an exact k-ordered fma chain, bit-identical
+// to the contract (the closing T * bg entry is the contract's final fma(T, bg, acc)).
+__device__ __forceinline__ void sweep_compute_exact(SweepSets& S, uint32_t st, int cg, int half, int l31)
+{
+	const uint32_t fa = st + (uint32_t)(half * 128 + cg * 32 + l31) * 4u;      // + pair * 1024
+	const uint32_t wa = st + 8192u + (uint32_t)(half * 128 + l31) * 4u;       // + pair * 1024 + pb * 128
+	float a, b0, b1, b2, b3;
+	asm volatile(
+		"ds_read_b32 %0, %5\n\t"
+		"ds_read_b32 %1, %6\n\t"
+		"ds_read_b32 %2, %6 offset:128\n\t"
+		"ds_read_b32 %3, %6 offset:256\n\t"
+		"ds_read_b32 %4, %6 offset:384\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=&v"(a), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+		: "v"(fa), "v"(wa)
+		: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int p = 0; p < 8; p++) {
+		float an = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+		if (p < 7) {
+			const uint32_t fn = fa + (uint32_t)(p + 1) * 1024u, wn = wa + (uint32_t)(p + 1) * 1024u;
+			asm volatile(
+				"ds_read_b32 %0, %5\n\t"
+				"ds_read_b32 %1, %6\n\t"
+				"ds_read_b32 %2, %6 offset:128\n\t"
+				"ds_read_b32 %3, %6 offset:256\n\t"
+				"ds_read_b32 %4, %6 offset:384"
+				: "=&v"(an), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+				: "v"(fn), "v"(wn)
+				: "memory");
+		}
+		S[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, S[1][0], 0, 0, 0);
+		S[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, S[1][1], 0, 0, 0);
+		S[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, S[1][2], 0, 0, 0);
+		S[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, S[1][3], 0, 0, 0);
+		if (p < 7) {
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
+			__builtin_amdgcn_sched_barrier(0);
+			a = an; b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+		}
+	}
+}
+
 // One workgroup = (tile-row segment, 128 channels, row parity g): 4 waves = 4 channel groups of 32.
 // The two parities are separate workgroups (two per CU) so that one's store phase overlaps the
 // other's multiply phase; each fetches the features (the second copy comes from L2) and its own
 // half of the weights.
 // DBG (development ablations, 0 in production): 1 = no stores, 2 = no matrix work.
-template <int DBG>
+template <int DBG, bool EXACT>
 __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -775,12 +674,15 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row1 + cbase + l31 * 4),
 						 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(4 * wave + 2) * 512u),
 						 16, 0, 0);
-		// weights piece `wave` = (k-group wave >> 1, hi/lo wave & 1): this parity's 2 KB half
-		const char* wsrc = wgt + (size_t)((slot >> 3) + (wave >> 1)) * 8192 + (size_t)(wave & 1) * 4096 +
-				   (size_t)g * 2048 + (size_t)lane * 16;
+		// weights.  bf16: piece `wave` = (k-group wave >> 1, hi/lo wave & 1), this parity's 2 KB half;
+		// exact: fp32 rows of 1 KB per entry, this parity's 512 B of entries 4*wave .. 4*wave+3
+		const char* wsrc = EXACT ? wgt + (size_t)(slot + 4 * wave + (lane >> 5)) * 1024 + (size_t)g * 512 +
+						   (size_t)(lane & 31) * 16
+					 : wgt + (size_t)((slot >> 3) + (wave >> 1)) * 8192 + (size_t)(wave & 1) * 4096 +
+						   (size_t)g * 2048 + (size_t)lane * 16;
 #pragma unroll
 		for (int j = 0; j < 2; j++)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + j * 1024),
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + j * (EXACT ? 2048 : 1024)),
 							 (__attribute__((address_space(3))) void*)(size_t)(st + 8192u + (uint32_t)(wave * 2 + j) * 1024u),
 							 16, 0, 0);
 		const uint32_t li = (uint32_t)(lane & 15) < n2 ? (uint32_t)(lane & 15) : n2 - 1u;
@@ -851,7 +753,10 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 		const uint32_t n = e0y & 255u;
 		const int tx = tx0 + (int)((e0y >> 8) & 255u);
 		const bool is_left = ((tx + g * stagger) & 1) == 0;   // even rows: even tiles are left halves; odd rows (staggered): odd tiles
-		if (!(DBG & 2)) sweep_compute(S, st0, n, cg, half, l31);   // always into S[1]
+		if (!(DBG & 2)) {   // always into S[1]
+			if (EXACT) sweep_compute_exact(S, st0, cg, half, l31);
+			else sweep_compute(S, st0, n, cg, half, l31);
+		}
 		if ((e0y >> 16) != 0u && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
 			const int hi = (l31 >> 4) & 1;
 			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * W;
@@ -915,7 +820,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, \
 			   act_id, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx,        \
 			   ((NT_) + 7) / 8, NT_, T0_)
-	if ((split_mode & 15) == 8) {
+	{
 		// ---- row-sweep path (default)
 		// segment length: long sweeps amortise the prologue and leave few half-line stores at segment
 		// ends (cfg3: 48 -> 2 segments per tile row is 3 % faster than 16), but there must be enough
@@ -927,36 +832,28 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			while (seg > 8 && (long long)a.gy * ((a.gx + seg - 1) / seg) * nc * 2 < 1536) seg /= 2;
 		const int nseg = (a.gx + seg - 1) / seg;
 		seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
-		SGS_LAUNCH_W(2, st, 0, ntiles);
+		const bool exact = (split_mode & 15) == 9;
+		if (exact) SGS_LAUNCH_W(3, st, 0, ntiles);
+		else SGS_LAUNCH_W(2, st, 0, ntiles);
 		if (mark) mark(mark_user);
 		const int items = a.gy * nseg * nc * 2;   // x 2 row parities
 		const int pxcd = (items + 7) / 8;
-#define SGS_LAUNCH_SWEEP(D_)                                                                         \
-	hipLaunchKernelGGL(blend_accum_sweep_kernel<D_>, dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
+#define SGS_LAUNCH_SWEEP(D_, E_)                                                                     \
+	hipLaunchKernelGGL((blend_accum_sweep_kernel<D_, E_>), dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items)
-		switch ((split_mode >> 8) & 15) {
-		case 1: SGS_LAUNCH_SWEEP(1); break;
-		case 2: SGS_LAUNCH_SWEEP(2); break;
-		case 3: SGS_LAUNCH_SWEEP(3); break;
-		case 4: SGS_LAUNCH_SWEEP(4); break;
-		default: SGS_LAUNCH_SWEEP(0); break;
-		}
+		if (exact) SGS_LAUNCH_SWEEP(0, true);
+		else
+			switch ((split_mode >> 8) & 15) {
+			case 1: SGS_LAUNCH_SWEEP(1, false); break;
+			case 2: SGS_LAUNCH_SWEEP(2, false); break;
+			case 3: SGS_LAUNCH_SWEEP(3, false); break;
+			case 4: SGS_LAUNCH_SWEEP(4, false); break;
+			default: SGS_LAUNCH_SWEEP(0, false); break;
+			}
 #undef SGS_LAUNCH_SWEEP
-		return hipGetLastError();
 	}
-	// ---- exact path: fp32 weight rows, fp32-input MFMA accumulate, one workgroup per tile x 128 channels
-	SGS_LAUNCH_W(0, st, 0, ntiles);
-	if (mark) mark(mark_user);
 #undef SGS_LAUNCH_W
-	{
-		const int nchunks = a.C / 128;
-		const int total = ntiles * nchunks;
-		const int per_xcd = (total + 7) / 8;
-		hipLaunchKernelGGL(blend_accum_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, st, a.ranges, table, nbatches,
-				   act_id, (const float4*)wgt, a.features, a.final_T, a.bg, a.out, counter, a.W, a.H, a.C,
-				   a.gx, nchunks, per_xcd, total);
-	}
 	return hipGetLastError();
 }
 

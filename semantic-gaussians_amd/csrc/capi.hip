@@ -499,7 +499,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	if (use_split) {
 		char* arena = bchunk + bl.arena;
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
-		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 15 ? 4 : 8));
+		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 15 ? 9 : 8));
 		if (e != hipSuccess) return fail_hip(e, "blend forward (split)");
 		const uint32_t* counter = (const uint32_t*)(arena + bl.arena_lay.counter);
 		const int c_split = (num_channels / 128) * 128;
