@@ -356,7 +356,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// that the big instance sort only has to be stable on the tile bits (binning.hip)
 	const int bmode = g_binning_mode.load();
 	const bool presort = bmode == 0 || bmode == 2;
-	const bool rows = bmode == 0;   // per-tile lists from row instances (binning_rows.hip)
+	// mode 0: per-tile lists from span partitions (binning_rows.hip); its per-wave bin tables live in LDS,
+	// so absurdly long grid axes (> 32k pixels) take the mode-2 path
+	const bool rows = bmode == 0 && gx <= 2048 && gy <= 2048;
 	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
 	uint64_t* offs64 = (uint64_t*)(gchunk + gl.offs64);
 	if (presort) {
