@@ -67,15 +67,14 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
 	uint32_t* __restrict__ act_id, float* __restrict__ wgt, uint32_t* __restrict__ table,
 	uint32_t* __restrict__ nact, uint32_t* __restrict__ counter, uint32_t capacity, int W,
-	int H, int gx, int per_xcd, int ntiles, int tile_begin)
+	int H, int gx, int per_xcd, int ntiles)
 {
 	const int b = blockIdx.x;
 	static_assert(MODE == 2 || MODE == 3, "weights format: 2 = split bf16 (default), 3 = fp32 rows (exact)");
 	constexpr bool BF = MODE == 2;   // weights as split bf16, k-major groups of 8 (else fp32 rows of 256)
 	constexpr bool SWEEP = true;     // parity-major pixel order, closing T * bg pseudo entry, zero padding to 16
-	const int tl = (b & 7) * per_xcd + (b >> 3);   // tiles [tile_begin, tile_begin + ntiles)
-	if (tl >= ntiles) return;
-	const int tile = tile_begin + tl;
+	const int tile = (b & 7) * per_xcd + (b >> 3);
+	if (tile >= ntiles) return;
 	const int tx = tile % gx, ty = tile / gx;
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -359,30 +358,29 @@ constexpr int AB = 16;   // work-list entries per batch (divides ACH)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // -------------------------------------------------------------------------------------
-// Row-sweep split-bf16 accumulate (the default when W % 32 == 16).
+// Row-sweep accumulate (blend_accum_sweep_kernel).
 //
-// Measured on the per-tile kernel above: the epilogue's 64-B pieces (a tile is 16 px wide)
-// cost 0.77 ms of its 1.3 ms, because the memory system writes partial 128-B lines at
-// 3.5 TB/s but complete aligned lines at 4.8-5.2 TB/s (tools/ubench_store.hip,
-// profiles/r01_ubench_store.txt); splitting the work by row parity to own whole lines
-// (blend_accum_pair_kernel) fetches and converts every feature twice and loses more than
-// it gains.  This kernel instead SWEEPS: one workgroup walks `seg` consecutive tiles of a
-// tile row for 128 channels, one pipeline across all of them, and keeps the half lines that
-// still wait for their right-hand neighbour in registers:
+// With the matrix work on the MFMA pipe the output store decides the kernel: the memory system writes
+// the 64-B pieces a 16-px-wide tile owns at 3.5 TB/s but complete aligned 128-B lines at 4.8-5.2 TB/s,
+// and L2 does not merge halves written by different waves (tools/ubench_store.hip,
+// profiles/r01_ubench_store.txt).  A line of channel c, row y covers 32 pixels = two horizontally
+// adjacent tiles; with a pitch of W*4 bytes and W % 32 == 16 the lines start at x = 0 (mod 32) on even
+// rows and x = 16 (mod 32) on odd rows (`stagger`; W % 32 == 0: every row alike):
 //     even rows: line = tiles (2k, 2k+1)      odd rows: line = tiles (2k-1, 2k)
-// (pitch W*4 with W % 32 == 16: odd rows start 64 B into a line).  After an even tile its odd
-// rows complete the lines begun by the previous (odd) tile, after an odd tile its even rows
-// complete the previous tile's; v_permlane16_swap_b32 merges the two 16-lane half rows so
-// each store instruction writes two complete 128-B lines.  Only the first/last tile of a
-// segment writes half lines.  Three accumulator sets of 4 blocks rotate through the roles
-// (even rows, odd rows, pending) with period two tiles, so nothing is ever copied.
+// So a workgroup SWEEPS: it walks `seg` consecutive tiles of a tile row for 128 channels and ONE row
+// parity, all their batches as one pipeline, accumulates the current tile in one set of accumulators
+// (S[1]), keeps a finished LEFT half in a second set (S[0]), and when the right-hand tile is finished
+// v_permlane16_swap_b32 merges the two 16-lane half rows so that every store instruction writes two
+// complete 128-B lines.  Only the first / last tile of a segment writes half lines.
 //
-// The sweep also amortises the per-workgroup prologue (work-list metadata, ids, final_T and
-// background staged in LDS once per segment) and never drains the DMA pipeline between
-// tiles: the next tile's first batch is in flight while the finished tile is stored.
+// The sweep also amortises the per-workgroup prologue (the segment's batches flattened into one LDS
+// table) and never drains the DMA pipeline between tiles: the next tiles' batches are in flight while a
+// finished tile is stored.  The closing T * bg term is a work-list entry (blend_weights_kernel), so
+// there is no epilogue arithmetic.
 //
-// Wave tile 32 channels x 256 px (8 MFMA blocks, parity-major pixel order: blocks 0-3 even
-// rows, 4-7 odd rows); batch = 16 entries; two LDS stages of 8 KB features + 16 KB weights.
+// Workgroup = 4 waves = 4 channel groups of 32; wave tile 32 channels x the 128 pixels of the parity
+// (4 MFMA blocks of 32 px = two rows each); batch = 16 entries; ring of NST stages of 8 KB fp32
+// features + 8 KB weights (this parity's half) + the ids of the batch LA bundles on.
 constexpr int SEGMAX = 96;   // tiles per sweep (upper bound, the launcher picks the length)
 constexpr int SW_JMAX = 1024; // batch-table window (batches of a segment kept in LDS)
 constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
@@ -819,7 +817,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3((((NT_) + 7) / 8) * 8), dim3(256), 0, ST_,    \
 			   a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, \
 			   act_id, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx,        \
-			   ((NT_) + 7) / 8, NT_, T0_)
+			   ((NT_) + 7) / 8, NT_)
 	{
 		// ---- row-sweep path (default)
 		// segment length: long sweeps amortise the prologue and leave few half-line stores at segment

@@ -83,8 +83,8 @@ struct SplitArena {   // byte offsets inside the arena chunk
 	uint32_t capacity;   // work-list slots (1 KB of weights + 4 B id each)
 };
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay);
-// `mark` is called (with `mark_user`) between the weights pre-pass and the accumulate kernel(s), on
-// `st` (stage timing); with several bands only the first band's weights precede it.
+// `mark` is called (with `mark_user`) between the weights pre-pass and the accumulate kernel, on `st`
+// (stage timing).
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
 				      int split_mode);
