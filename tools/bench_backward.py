@@ -10,8 +10,9 @@ from sgs_hip.synthetic import CONFIGS, make_scene
 from sgs_hip.camera import pinhole
 
 dev = "cuda:0"
-for name, C in (("cfg2", 3), ("cfg2", 32)):
+for name, C in (("cfg2", 3), ("cfg2", 32), ("cfg3", 512)):
     P, _, W, H, fx = CONFIGS[name]
+    N = 10 if C <= 32 else 3
     scene = make_scene(P, C, W, H, fx, seed=0).to(dev)
     cam = pinhole(W, H, fx).to(dev)
     mod = rr if C == 3 else cr
@@ -27,12 +28,11 @@ for name, C in (("cfg2", 3), ("cfg2", 32)):
     def fwd():
         return rast(means3D=leaves[0], means2D=m2d, opacities=leaves[1], colors_precomp=leaves[2], scales=leaves[3], rotations=leaves[4])
 
-    for _ in range(3):
+    for _ in range(2):
         out = fwd()
         out[0].sum().backward()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    N = 10
     for _ in range(N):
         out = fwd()
     torch.cuda.synchronize()
