@@ -1,0 +1,146 @@
+"""BASELINE.json's headline configuration at FULL size (cfg3: 1M Gaussians, C=512, 968x1296) on the GPU.
+
+The oracle cannot blend a whole 1M x 512 frame in seconds, so this file checks what does not need it:
+size-independent properties of the domain (sortedness and consistency of the per-tile lists, agreement
+of the three binning algorithms on all 16.5M instances, determinism, the partition-of-unity identity
+sum_k w_k = 1 - T_final, linearity in the features), plus the oracle itself on everything integer
+(preprocess + binning of the full frame) and on a sample of tile rows of the feature map."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    from sgs_hip.synthetic import CONFIGS, make_scene
+    from sgs_hip.camera import pinhole
+    P, C, W, H, fx = CONFIGS["cfg3"]
+    scene = make_scene(P, C, W, H, fx, seed=0)
+    return scene, pinhole(W, H, fx), (P, C, W, H)
+
+
+def _render(scene_dev, cam_dev, C, W, H, feats=None, bg=None):
+    from sgs_hip import raster
+    e = torch.Tensor([])
+    s, c = scene_dev, cam_dev
+    return raster.rasterize_forward(
+        s.bg[:C] if bg is None else bg, s.means3D, s.features if feats is None else feats, s.opacities, s.scales,
+        s.rotations, 1.0, e, c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, e, 0,
+        c.camera_center, False, False, C, False)
+
+
+def test_cfg3_lists_sorted_consistent_and_identical_across_binning_modes(cfg3, orc):
+    from sgs_hip import raster
+    scene, cam, (P, C, W, H) = cfg3
+    s, c = scene.to(DEV), cam.to(DEV)
+    feats = s.features[:, :4].contiguous()   # the lists do not depend on the channels
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    got = {}
+    for mode in (0, 1, 2):
+        raster.set_binning_mode(mode)
+        try:
+            n, color, radii, geom, binn, img, _ = _render(s, c, 4, W, H, feats=feats)
+        finally:
+            raster.set_binning_mode(0)
+        args = (geom, P, img, W, H) if mode != 1 else (None, None, None, None, None)
+        b = raster.binning_views(binn, n, *args)
+        iv = raster.image_views(img, W, H)
+        got[mode] = dict(n=n, keys=b["keys_sorted"].clone(), plist=b["point_list"].clone(), ranges=iv["ranges"].clone(),
+                         radii=radii.clone(), color=color.clone(), n_contrib=iv["n_contrib"].clone())
+    a = got[0]
+    for mode in (1, 2):   # the span-partition lists == the reference-order 45-bit sort == the 32-bit tile sort
+        o = got[mode]
+        assert o["n"] == a["n"] and torch.equal(o["plist"], a["plist"]) and torch.equal(o["ranges"], a["ranges"])
+        assert torch.equal(o["keys"], a["keys"]) and torch.equal(o["color"], a["color"])
+    n, keys, plist, ranges = a["n"], a["keys"], a["plist"].long(), a["ranges"].long()
+    assert n > 10_000_000
+    assert bool((keys[1:] >= keys[:-1]).all())                                  # sortedness of (tile, depth)
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.sum()) == n and bool((lens >= 0).all())
+    nz = lens > 0
+    starts = torch.cumsum(lens, 0) - lens
+    assert torch.equal(ranges[nz, 0], starts[nz])                               # ranges partition [0, L) in tile order
+    tile_of = torch.repeat_interleave(torch.arange(gx * gy, device=DEV), lens)
+    assert torch.equal(keys >> 32, tile_of)                                     # every key carries its tile
+    # every listed Gaussian's rect covers its tile (reference getRect, CR/cuda_rasterizer/auxiliary.h:46-57)
+    g = raster.geometry_views(geom, P)
+    m2d, rad = g["means2D"][plist], a["radii"][plist].float()
+    tx, ty = (tile_of % gx).float(), (tile_of // gx).float()
+    x0 = torch.clamp(torch.floor((m2d[:, 0] - rad) / 16.0), 0, gx)
+    x1 = torch.clamp(torch.floor((m2d[:, 0] + rad + 15.0) / 16.0), 0, gx)
+    y0 = torch.clamp(torch.floor((m2d[:, 1] - rad) / 16.0), 0, gy)
+    y1 = torch.clamp(torch.floor((m2d[:, 1] + rad + 15.0) / 16.0), 0, gy)
+    assert bool(((tx >= x0) & (tx < x1) & (ty >= y0) & (ty < y1)).all())
+    # the oracle on everything integer at full size
+    pre = orc.preprocess(scene.means3D.numpy(), scene.opacities.numpy(), cam.world_view_transform.numpy(),
+                         cam.full_proj_transform.numpy(), cam.camera_center.numpy(), W, H, cam.tanfovx, cam.tanfovy,
+                         scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
+                         colors_precomp=np.zeros((1, 1), np.float32))
+    binn_o = orc.binning(pre, W, H)
+    assert binn_o["num_rendered"] == n
+    assert np.array_equal(a["radii"].cpu().numpy(), pre["radii"])
+    assert np.array_equal(a["plist"].cpu().numpy().view(np.uint32), binn_o["point_list"])
+    assert np.array_equal(a["ranges"].cpu().numpy().view(np.uint32), binn_o["ranges"])
+    assert np.array_equal(keys.cpu().numpy().view(np.uint64), binn_o["keys_sorted"])
+    # ... and on the feature map of two tile rows (4 channels), bit for bit
+    lo, hi = 30 * gx, 32 * gx
+    ob = orc.blend_forward(pre, binn_o, feats.cpu().numpy(), scene.bg[:4].numpy(), W, H, tile_lo=lo, tile_hi=hi)
+    rows = slice(30 * 16, 32 * 16)
+    assert np.array_equal(a["color"][:, rows].cpu().numpy().view(np.uint32), ob["out"][:, rows].view(np.uint32))
+    assert np.array_equal(a["n_contrib"][rows].cpu().numpy().view(np.uint32), ob["n_contrib"][rows])
+
+
+def test_cfg3_feature_map_properties(cfg3, orc):
+    """C = 512 at full size: determinism, partition of unity, linearity, default vs exact arithmetic, and
+    the oracle on a sample of tile rows."""
+    from sgs_hip import raster
+    scene, cam, (P, C, W, H) = cfg3
+    s, c = scene.to(DEV), cam.to(DEV)
+    gx = (W + 15) // 16
+    n, out, radii, geom, binn, img, _ = _render(s, c, C, W, H)
+    T = raster.image_views(img, W, H)["final_T"].clone()
+    n2, out2, *_ = _render(s, c, C, W, H)
+    assert n2 == n and torch.equal(out, out2)                                   # deterministic
+    del out2
+    raster.set_blend_exact(True)
+    try:
+        exact = _render(s, c, C, W, H)[1]
+        absc = _render(s, c, C, W, H, feats=s.features.abs(), bg=s.bg[:C].abs())[1]   # the absolute composite
+        ones = _render(s, c, C, W, H, feats=torch.ones_like(s.features), bg=torch.zeros(C, device=DEV))[1]
+    finally:
+        raster.set_blend_exact(False)
+    # default arithmetic within 5e-5 of the absolute composite of the exact one (north star: 1e-4)
+    assert bool(((out - exact).abs() <= 5e-5 * absc + 1e-30).all())
+    # partition of unity: with all features 1 and bg 0 every channel is sum_k w_k = 1 - T_final
+    assert float((ones - (1.0 - T)[None]).abs().max()) < 2e-5
+    assert torch.equal(ones[0], ones[C - 1])
+    del ones, absc
+    # linearity in the features (exact arithmetic, fp32 rounding only)
+    f2 = torch.roll(s.features, 1, dims=1)
+    lin = _render_exact(raster, s, c, C, W, H, s.features + 2.0 * f2)
+    rhs = exact + 2.0 * _render_exact(raster, s, c, C, W, H, f2, bg=torch.zeros(C, device=DEV))
+    assert float((lin - rhs).abs().max()) < 2e-5
+    del lin, rhs, f2
+    # the oracle on two tile rows, first 8 channels: bit-identical in exact mode
+    pre = orc.preprocess(scene.means3D.numpy(), scene.opacities.numpy(), cam.world_view_transform.numpy(),
+                         cam.full_proj_transform.numpy(), cam.camera_center.numpy(), W, H, cam.tanfovx, cam.tanfovy,
+                         scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
+                         colors_precomp=np.zeros((1, 1), np.float32))
+    binn_o = orc.binning(pre, W, H)
+    ob = orc.blend_forward(pre, binn_o, scene.features[:, :8].contiguous().numpy(), scene.bg[:8].numpy(), W, H,
+                           tile_lo=10 * gx, tile_hi=12 * gx)
+    rows = slice(10 * 16, 12 * 16)
+    assert np.array_equal(exact[:8, rows].cpu().numpy().view(np.uint32), ob["out"][:, rows].view(np.uint32))
+    assert np.array_equal(T[rows].cpu().numpy().view(np.uint32), ob["final_T"][rows].view(np.uint32))
+
+
+def _render_exact(raster, s, c, C, W, H, feats, bg=None):
+    raster.set_blend_exact(True)
+    try:
+        return _render(s, c, C, W, H, feats=feats, bg=bg)[1]
+    finally:
+        raster.set_blend_exact(False)
