@@ -7,6 +7,16 @@ For scenes whose feature table does not fit one GPU the exact alternative is CHA
 geometry is replicated, rank r holds feature columns [r*C/w, (r+1)*C/w), every rank runs the
 identical preprocess/sort and blends its own channel slice -- bit-identical to the single-GPU
 render with zero reduction; one all_gather only if a single rank needs the full map.
+
+GAUSSIAN sharding (scenes whose geometry does not fit either) is the one
+variant with a real exchange step: every rank renders its shard into a per-pixel partial
+(A in R^C, T), and partials combine with the associative, NON-commutative "over" operator
+(A1, T1) o (A2, T2) = (A1 + T1*A2, T1*T2) in front-to-back shard order -- exact only for
+depth-separable shards (view-space depth slabs).  The exchange is image-partitioned: rank g owns
+a band of rows, receives the other ranks' partials for that band (grouped point-to-point
+send/recv = an all-to-all over all xGMI links at once, not a ring), composites them in shard
+order and adds bg*T; an optional all_gather rebuilds the full map.  A ring all-reduce would be
+the wrong operator (it sums) and single-link bound.
 """
 import time
 
@@ -92,6 +102,75 @@ def render_channel_sharded(render_fn, features, bg, all_gather=True):
     parts = [torch.empty_like(part) for _ in range(w)]
     dist.all_gather(parts, part.contiguous())
     return torch.cat(parts, dim=0)
+
+
+def band_rows(H, rank=None, world_size=None):
+    """Rows [lo, hi) of the image band owned by `rank` (16-row tile granularity where possible)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    tiles = (H + 15) // 16
+    lo = min(H, 16 * (tiles * rank // world_size))
+    hi = min(H, 16 * (tiles * (rank + 1) // world_size))
+    return lo, hi
+
+
+def composite_over(partials, bg=None):
+    """Front-to-back "over" of [(A (C,h,W), T (h,W)), ...]; adds bg*T_total when bg is given."""
+    out = partials[0][0].clone()
+    t_acc = partials[0][1].clone()
+    for a, t in partials[1:]:
+        out += t_acc.unsqueeze(0) * a
+        t_acc = t_acc * t
+    if bg is not None:
+        out += bg.reshape(-1, 1, 1) * t_acc.unsqueeze(0)
+    return out, t_acc
+
+
+def render_gaussian_sharded(render_partial_fn, bg, order=None, all_gather=True):
+    """Gaussian-sharded render of one view.  Rank r holds shard r of the Gaussians;
+    `render_partial_fn() -> (A (C,H,W) rendered with a ZERO background, T (H,W) final transmittance)`
+    renders the local shard.  `order` lists the ranks front to back for this view (default
+    0..w-1): the shards must be depth-separable in that order for the result to equal the
+    single-GPU render (up to fp32 rounding and the per-shard instead of global T < 1e-4 stop).
+    Returns the full (C,H,W) map (all_gather=True) or this rank's band of rows."""
+    rank, w = world()
+    a, t = render_partial_fn()
+    if w == 1:
+        return composite_over([(a, t)], bg)[0]
+    order = list(range(w)) if order is None else list(order)
+    H = a.shape[1]
+    # image-partitioned all-to-all of the (A, T) partials: grouped point-to-point send / recv
+    mine = band_rows(H, rank, w)
+    recv = {}
+    ops, keep = [], []
+    for peer in range(w):
+        lo, hi = band_rows(H, peer, w)
+        if peer == rank:
+            recv[rank] = (a[:, lo:hi].contiguous(), t[lo:hi].contiguous())
+            continue
+        sa, st = a[:, lo:hi].contiguous(), t[lo:hi].contiguous()
+        ra = torch.empty((a.shape[0], mine[1] - mine[0], a.shape[2]), dtype=a.dtype, device=a.device)
+        rt = torch.empty((mine[1] - mine[0], a.shape[2]), dtype=t.dtype, device=t.device)
+        keep += [sa, st]
+        recv[peer] = (ra, rt)
+        if sa.numel():
+            ops += [dist.P2POp(dist.isend, sa, peer), dist.P2POp(dist.isend, st, peer)]
+        if ra.numel():
+            ops += [dist.P2POp(dist.irecv, ra, peer), dist.P2POp(dist.irecv, rt, peer)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    band, _ = composite_over([recv[r] for r in order], bg)
+    if not all_gather:
+        return band
+    sizes = [band_rows(H, r, w) for r in range(w)]
+    hmax = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((band.shape[0], hmax, band.shape[2]), dtype=band.dtype, device=band.device)
+    pad[:, :band.shape[1]] = band
+    parts = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(parts, pad)
+    return torch.cat([parts[r][:, :sizes[r][1] - sizes[r][0]] for r in range(w)], dim=1)
 
 
 def timed_steps(step_fn, steps, warmup, sync_fn=None):
