@@ -255,7 +255,8 @@ def _grad_close(a, b, tol):
 
 
 @pytest.mark.parametrize("C,use_sh,precomp_cov", [(3, True, False), (3, False, False), (3, False, True),
-                                                  (4, False, False), (32, False, False), (80, False, False)])
+                                                  (4, False, False), (32, False, False), (80, False, False),
+                                                  (128, False, False), (160, False, False)])
 def test_backward_parity(orc, C, use_sh, precomp_cov):
     """Backward (runtime C) against the oracle; fp32 atomics sum in unspecified order, so the
     bar is 1e-4 of the largest gradient entry (oracle accumulates in float64)."""
