@@ -32,22 +32,6 @@ struct StagedEntryB {
 	float pad0, pad1;
 };
 
-// wave64 sum -> valid in every lane (DPP butterflies inside rows of 16, then readlane).
-__device__ __forceinline__ float wave_sum(float v)
-{
-	// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
-	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-	// every lane of a 16-lane row now holds the row sum
-	const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-	const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-	const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-	const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-	return (r0 + r1) + (r2 + r3);
-}
-
 template <int CC>
 __global__ __launch_bounds__(256) void blend_bwd_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -56,8 +40,9 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 	const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
 	const float* __restrict__ dL_dpixels, float* __restrict__ dL_dmean2D,
 	float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
-	int W, int H, int C, int gx, int nchunks)
+	int W, int H, int C, int gx, int nchunks, const uint32_t* __restrict__ gate)
 {
+	if (gate && gate[1] == 0u) return;   // the work-list path did the job
 	const int tile = blockIdx.x / nchunks;
 	const int chunk = blockIdx.x - tile * nchunks;
 	const int c0 = chunk * CC;
@@ -188,7 +173,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 	}
 }
 
-hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a)
+hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const uint32_t* gate)
 {
 	const int ntiles = a.gx * a.gy;
 	if (ntiles == 0 || a.C == 0) return hipSuccess;
@@ -196,13 +181,13 @@ hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a)
 		hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(ntiles), dim3(256), 0, st, a.ranges,
 				   a.point_list, a.bg, a.means2D, a.conic_opacity, a.colors, a.final_T,
 				   a.n_contrib, a.dL_dpix, a.dL_dmean2D, a.dL_dconic, a.dL_dopacity,
-				   a.dL_dcolors, a.W, a.H, a.C, a.gx, 1);
+				   a.dL_dcolors, a.W, a.H, a.C, a.gx, 1, gate);
 	} else {
 		const int nch = (a.C + 31) / 32;
 		hipLaunchKernelGGL((blend_bwd_kernel<32>), dim3(ntiles * nch), dim3(256), 0, st, a.ranges,
 				   a.point_list, a.bg, a.means2D, a.conic_opacity, a.colors, a.final_T,
 				   a.n_contrib, a.dL_dpix, a.dL_dmean2D, a.dL_dconic, a.dL_dopacity,
-				   a.dL_dcolors, a.W, a.H, a.C, a.gx, nch);
+				   a.dL_dcolors, a.W, a.H, a.C, a.gx, nch, gate);
 	}
 	return hipGetLastError();
 }

@@ -1,0 +1,405 @@
+// blend_bwd_mfma.hip -- backward of the N-channel alpha-composite as matrix products (C >= 128).
+//
+// Behaviour: CR/cuda_rasterizer/backward.cu:394-552 (renderCUDA backward), restated for a runtime
+// channel count in blend_bwd.hip.  That kernel walks every tile's list once per 32-channel chunk and
+// does all of its channel work on the VALU (78 ms at 1M x 512 x 968x1296).  Per (list entry k, pixel p)
+// the channel dimension only enters through two contractions:
+//
+//   D[k][p]      = sum_c F[k][c] * g[c][p]             (g = dL/dpixel)       -> dL/dalpha
+//   dL/dF[k][c]  = sum_p w[k][p] * g[c][p]             (w = alpha * T, the forward's blend weight)
+//
+// and the reference's running "colour behind the entry" only ever appears dotted with g, so it
+// collapses to a scalar recurrence:  R_k = sum_c rec_k[c] g[c] = alpha_{k+1} D_{k+1} + (1 - alpha_{k+1}) R_{k+1},
+//   dL/dalpha_k = T_k (D_k - R_k) - T_final / (1 - alpha_k) * (bg . g).
+// So the backward blend is:
+//   1. blend_weights_kernel<3>   (blend_fwd_split.hip) the forward's work list again: per tile the
+//                                contributing entries, their fp32 weight rows w[k][256 px'], ids and
+//                                list positions; the list's closing pseudo entry (id SGS_BG_ID) stands
+//                                for the background: its D row is  bg . g.
+//   2. bwd_dcolor_kernel         dL/dF = W G^T per (tile, 128 channels): fp32 MFMA, one coalesced
+//                                atomic row per (entry, 32 channels).
+//   3. bwd_dot_kernel            D = F G per tile, fp32 MFMA; D rows overwrite the weight rows.
+//   4. bwd_geom_kernel           lane = pixel, back-to-front over the work list: recomputes G / alpha,
+//                                walks T back from T_final (as the reference does), the scalar
+//                                recurrence above, and the wave-reduced atomics of blend_bwd.hip for
+//                                mean2D / conic / opacity.
+// fp32 MFMA (v_mfma_f32_32x32x2_f32): products and sums are fp32; only the summation order differs from
+// blend_bwd.hip (the test bar is 1e-4 of the largest gradient entry, same as for the atomics' order).
+// If the work list overflows its arena a device flag makes 2-4 exit and blend_bwd.hip's kernel
+// (launched behind them, gated on the same flag) do the work.
+#include "sgs_kernels.h"
+
+namespace sgs {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t BG_ID = 0xFFFFFFFFu;     // blend_fwd_split.hip SGS_BG_ID
+constexpr uint32_t NO_ID = 0xFFFFFFFEu;
+constexpr int CHUNK = 128;                  // work-list slots per arena chunk (blend_fwd_split.hip ACH)
+constexpr int LDP = 36;                     // LDS row pitch (floats) of the 32-wide operand slabs
+
+// row of the 32x32 MFMA result held in accumulator register r of a lane in half h
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- 3. D[slot][px'] = sum_c F[id(slot)][c] * g[c][px']
+__global__ __launch_bounds__(256) void bwd_dot_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float* __restrict__ features, const float* __restrict__ bg,
+	const float* __restrict__ dL_dpix, float* __restrict__ Drows,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int per_xcd, int ntiles)
+{
+	if (counter[1] != 0u) return;
+	const int b = blockIdx.x;
+	const int tile = (b & 7) * per_xcd + (b >> 3);
+	if (tile >= ntiles) return;
+	const int t = threadIdx.x;
+	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int l31 = lane & 31, h = lane >> 5;
+	const int tx = tile % gx, ty = tile / gx;
+	const int ry = t >> 4, rx = t & 15;
+	const int px = tx * SGS_TILE + rx, py = ty * SGS_TILE + ry;
+	const bool inside = px < W && py < H;
+	const int pxp = (ry & 1) * 128 + (ry >> 1) * 16 + rx;
+	const size_t HW = (size_t)H * W;
+	const size_t pix = (size_t)py * W + px;
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const int total = (int)nact[tile];
+
+	__shared__ float sF[CHUNK * LDP];
+	__shared__ float sG[32 * 256];
+	__shared__ uint32_t s_id[CHUNK];
+
+	for (int ci = 0; ci * CHUNK < total; ci++) {
+		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
+		const int mb = (cnt + 31) >> 5;
+		const uint32_t cstart = table[chunk_base + ci];
+		__syncthreads();
+		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
+		f32x16 acc[4][2];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+#pragma unroll
+			for (int n = 0; n < 2; n++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+		for (int c0 = 0; c0 < C; c0 += 32) {
+			__syncthreads();   // s_id visible; the previous slab's readers are done
+#pragma unroll 8
+			for (int c = 0; c < 32; c++)
+				sG[c * 256 + pxp] = inside ? dL_dpix[(size_t)(c0 + c) * HW + pix] : 0.f;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int q = t + 256 * i, e = q >> 3, f = q & 7;
+				const uint32_t id = s_id[e];
+				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (id == BG_ID) v = *reinterpret_cast<const float4*>(bg + c0 + 4 * f);
+				else if (id != NO_ID) v = *reinterpret_cast<const float4*>(features + (size_t)id * C + c0 + 4 * f);
+				*reinterpret_cast<float4*>(&sF[e * LDP + 4 * f]) = v;
+			}
+			__syncthreads();
+			// MFMA k index = lane half h  <->  channel c0 + 16 h + s
+#pragma unroll
+			for (int s4 = 0; s4 < 4; s4++) {
+				float4 a4[4];
+#pragma unroll
+				for (int m = 0; m < 4; m++)
+					if (m < mb) a4[m] = *reinterpret_cast<const float4*>(&sF[(32 * m + l31) * LDP + 16 * h + 4 * s4]);
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int s = 4 * s4 + u;
+					float bv[2];
+#pragma unroll
+					for (int n = 0; n < 2; n++) bv[n] = sG[(16 * h + s) * 256 + 64 * wave + 32 * n + l31];
+#pragma unroll
+					for (int m = 0; m < 4; m++)
+						if (m < mb) {
+							const float av = u == 0 ? a4[m].x : u == 1 ? a4[m].y : u == 2 ? a4[m].z : a4[m].w;
+#pragma unroll
+							for (int n = 0; n < 2; n++)
+								acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[n], acc[m][n], 0, 0, 0);
+						}
+				}
+			}
+		}
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			if (m < mb)
+#pragma unroll
+				for (int n = 0; n < 2; n++)
+#pragma unroll
+					for (int r = 0; r < 16; r++) {
+						const int e = 32 * m + mfma_row(r, h);
+						if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 64 * wave + 32 * n + l31] = acc[m][n][r];
+					}
+	}
+}
+
+// ---- 2. dL/dF[id(slot)][c] += sum_px' w[slot][px'] * g[c][px']
+__global__ __launch_bounds__(256) void bwd_dcolor_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float* __restrict__ Wrows, const float* __restrict__ dL_dpix,
+	float* __restrict__ dL_dcolors, const uint32_t* __restrict__ counter, int W, int H, int C, int gx,
+	int nch, int per_xcd, int items)
+{
+	if (counter[1] != 0u) return;
+	const int b = blockIdx.x;
+	const int item = (b & 7) * per_xcd + (b >> 3);
+	if (item >= items) return;
+	const int tile = item / nch, cc = item - tile * nch;
+	const int t = threadIdx.x;
+	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int l31 = lane & 31, h = lane >> 5;
+	const int tx = tile % gx, ty = tile / gx;
+	const size_t HW = (size_t)H * W;
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const int total = (int)nact[tile];
+	const int cbase = cc * 128;
+	const bool wave_on = cbase + 32 * wave < C;   // (C % 32 == 0)
+	const bool vec_ok = (W & 3) == 0;
+
+	__shared__ float sW[CHUNK * LDP];
+	__shared__ float sG[128 * LDP];
+	__shared__ uint32_t s_id[CHUNK];
+
+	for (int ci = 0; ci * CHUNK < total; ci++) {
+		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
+		const int cnt16 = (cnt + 15) & ~15;   // rows up to here are initialised (zero padding of the work list)
+		const int mb = (cnt + 31) >> 5;
+		const uint32_t cstart = table[chunk_base + ci];
+		__syncthreads();
+		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
+		f32x16 acc[4];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+		for (int j = 0; j < 8; j++) {   // slabs of 32 px' = two image rows of one parity
+			__syncthreads();
+			const int par = j >> 2;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int q = t + 256 * i, e = q >> 3, f = q & 7;
+				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (e < cnt16) v = *reinterpret_cast<const float4*>(Wrows + (size_t)(cstart + e) * 256 + 32 * j + 4 * f);
+				*reinterpret_cast<float4*>(&sW[e * LDP + 4 * f]) = v;
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int q = t + 256 * i, ch = q >> 3, f = q & 7;
+				const int r2 = f >> 2, x4 = (f & 3) * 4;
+				const int y = ty * SGS_TILE + 2 * ((j & 3) * 2 + r2) + par;
+				const int x = tx * SGS_TILE + x4;
+				const int c = cbase + ch;
+				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (c < C && y < H) {
+					const float* src = dL_dpix + (size_t)c * HW + (size_t)y * W + x;
+					if (vec_ok && x + 3 < W) v = *reinterpret_cast<const float4*>(src);
+					else {
+						if (x < W) v.x = src[0];
+						if (x + 1 < W) v.y = src[1];
+						if (x + 2 < W) v.z = src[2];
+						if (x + 3 < W) v.w = src[3];
+					}
+				}
+				*reinterpret_cast<float4*>(&sG[ch * LDP + 16 * r2 + x4]) = v;
+			}
+			__syncthreads();
+			if (wave_on) {
+				// MFMA k index = lane half h  <->  px' 32 j + 16 h + s
+#pragma unroll
+				for (int s4 = 0; s4 < 4; s4++) {
+					float4 a4[4];
+#pragma unroll
+					for (int m = 0; m < 4; m++)
+						if (m < mb) a4[m] = *reinterpret_cast<const float4*>(&sW[(32 * m + l31) * LDP + 16 * h + 4 * s4]);
+					const float4 b4 = *reinterpret_cast<const float4*>(&sG[(32 * wave + l31) * LDP + 16 * h + 4 * s4]);
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						const float bv = u == 0 ? b4.x : u == 1 ? b4.y : u == 2 ? b4.z : b4.w;
+#pragma unroll
+						for (int m = 0; m < 4; m++)
+							if (m < mb) {
+								const float av = u == 0 ? a4[m].x : u == 1 ? a4[m].y : u == 2 ? a4[m].z : a4[m].w;
+								acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+							}
+					}
+				}
+			}
+		}
+		if (wave_on) {
+#pragma unroll
+			for (int m = 0; m < 4; m++)
+				if (m < mb)
+#pragma unroll
+					for (int r = 0; r < 16; r++) {
+						const int e = 32 * m + mfma_row(r, h);
+						const uint32_t id = s_id[e];
+						if (id < NO_ID) atomicAdd(&dL_dcolors[(size_t)id * C + cbase + 32 * wave + l31], acc[m][r]);
+					}
+		}
+	}
+}
+
+struct StagedEntryG {
+	float a2, b2, c2, o;
+	float x, y;
+	uint32_t id;
+	float ca;
+	float cb, cc;
+	uint32_t slot, idx1;
+};
+
+// ---- 4. geometry gradients from D (lane = pixel, back to front)
+__global__ __launch_bounds__(256) void bwd_geom_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const uint32_t* __restrict__ act_idx, const float* __restrict__ Drows,
+	const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
+	const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+	float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+	const uint32_t* __restrict__ counter, int W, int H, int gx, int per_xcd, int ntiles)
+{
+	if (counter[1] != 0u) return;
+	const int b = blockIdx.x;
+	const int tile = (b & 7) * per_xcd + (b >> 3);
+	if (tile >= ntiles) return;
+	const int tx = tile % gx, ty = tile / gx;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int ry = wave * 4 + (lane >> 4), rx = lane & 15;
+	const int px = tx * SGS_TILE + rx, py = ty * SGS_TILE + ry;
+	const bool inside = px < W && py < H;
+	const int pxp = (ry & 1) * 128 + (ry >> 1) * 16 + rx;
+	const float pxf = (float)px, pyf = (float)py;
+	const size_t pix = (size_t)py * W + px;
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const int total = (int)nact[tile];
+	const int real = total - 1;   // the last entry is the background pseudo entry
+	if (real <= 0) return;
+
+	__shared__ StagedEntryG s_e[64];
+
+	const float T_final = inside ? final_Ts[pix] : 0.f;
+	float T = T_final;
+	const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+	int wave_max = last_contributor;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		const int o = __shfl_xor(wave_max, off);
+		wave_max = o > wave_max ? o : wave_max;
+	}
+	const uint32_t bg_slot = table[chunk_base + (uint32_t)real / CHUNK] + (uint32_t)real % CHUNK;
+	const float bg_dot = Drows[(size_t)bg_slot * 256 + pxp];
+	const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+	float R = 0.f;
+
+	for (int hi = real; hi > 0; hi -= 64) {
+		const int n = hi < 64 ? hi : 64;
+		__syncthreads();
+		if ((int)threadIdx.x < n) {
+			const uint32_t g = (uint32_t)(hi - 1 - (int)threadIdx.x);
+			const uint32_t slot = table[chunk_base + g / CHUNK] + g % CHUNK;
+			const uint32_t id = act_id[slot];
+			const float2 xy = means2D[id];
+			const float4 co = conic_opacity[id];
+			StagedEntryG e;
+			e.a2 = -0.5f * co.x;
+			e.b2 = -co.y;
+			e.c2 = -0.5f * co.z;
+			e.o = co.w;
+			e.x = xy.x;
+			e.y = xy.y;
+			e.id = id;
+			e.ca = co.x;
+			e.cb = co.y;
+			e.cc = co.z;
+			e.slot = slot;
+			e.idx1 = act_idx[slot];
+			s_e[threadIdx.x] = e;
+		}
+		__syncthreads();
+		for (int k = 0; k < n; k++) {
+			const StagedEntryG e = s_e[k];
+			const int idx = (int)e.idx1 - 1;
+			if (idx >= wave_max) continue;
+			const float dx = e.x - pxf, dy = e.y - pyf;
+			const float power =
+				__builtin_fmaf(e.b2 * dx, dy, __builtin_fmaf(e.c2 * dy, dy, (e.a2 * dx) * dx));
+			const float G = expf_contract(power);
+			const float alpha = fmin_(0.99f, e.o * G);
+			const bool valid = inside && (idx < last_contributor) && !(power > 0.0f) &&
+					   !(alpha < 1.0f / 255.0f);
+			if (__ballot(valid) == 0ull) continue;
+			const uint32_t slot = __builtin_amdgcn_readfirstlane(e.slot);
+			const float Dk = Drows[(size_t)slot * 256 + pxp];
+			const float oma = 1.f - alpha;
+			if (valid) T = T / oma;
+			float dL_dalpha = (Dk - R) * T;
+			dL_dalpha += (-T_final / oma) * bg_dot;
+			if (!valid) dL_dalpha = 0.f;
+			if (valid) R = alpha * Dk + oma * R;
+			const float dL_dG = e.o * dL_dalpha;
+			const float Gv = valid ? G : 0.f;
+			const float gdx = Gv * dx, gdy = Gv * dy;
+			const float dG_ddelx = -gdx * e.ca - gdy * e.cb;
+			const float dG_ddely = -gdy * e.cc - gdx * e.cb;
+			const float m0 = wave_sum(dL_dG * dG_ddelx * ddelx_dx);
+			const float m1 = wave_sum(dL_dG * dG_ddely * ddely_dy);
+			const float k0 = wave_sum(-0.5f * gdx * dx * dL_dG);
+			const float k1 = wave_sum(-0.5f * gdx * dy * dL_dG);
+			const float k3 = wave_sum(-0.5f * gdy * dy * dL_dG);
+			const float op = wave_sum(Gv * dL_dalpha);
+			const uint32_t id = __builtin_amdgcn_readfirstlane(e.id);
+			if (lane == 0) {
+				atomicAdd(&dL_dmean2D[3 * (size_t)id], m0);
+				atomicAdd(&dL_dmean2D[3 * (size_t)id + 1], m1);
+				atomicAdd(&dL_dconic[4 * (size_t)id], k0);
+				atomicAdd(&dL_dconic[4 * (size_t)id + 1], k1);
+				atomicAdd(&dL_dconic[4 * (size_t)id + 3], k3);
+				atomicAdd(&dL_dopacity[id], op);
+			}
+		}
+	}
+}
+
+} // namespace
+
+bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
+{
+	return a.C >= 128 && (a.C & 31) == 0 && (((uintptr_t)a.colors | (uintptr_t)a.bg) & 15u) == 0 &&
+	       ((uintptr_t)a.dL_dpix & 15u) == 0;
+}
+
+hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay)
+{
+	const int ntiles = a.gx * a.gy;
+	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
+						 const_cast<float*>(a.final_T), const_cast<uint32_t*>(a.n_contrib),
+						 arena, lay, a.W, a.H, a.gx, a.gy);
+	if (e != hipSuccess) return e;
+	const uint32_t* counter = (const uint32_t*)(arena + lay.counter);
+	const uint32_t* nact = (const uint32_t*)(arena + lay.nbatches);
+	const uint32_t* table = (const uint32_t*)(arena + lay.table);
+	const uint32_t* act_id = (const uint32_t*)(arena + lay.act_id);
+	const uint32_t* act_idx = (const uint32_t*)(arena + lay.act_idx);
+	float* rows = (float*)(arena + lay.wgt);
+	const int nch = (a.C + 127) / 128;
+	const int items = ntiles * nch;
+	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
+	hipLaunchKernelGGL(bwd_dcolor_kernel, dim3(ixcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, rows,
+			   a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);
+	hipLaunchKernelGGL(bwd_dot_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, a.colors,
+			   a.bg, a.dL_dpix, rows, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
+	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
+			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
+			   a.dL_dopacity, counter, a.W, a.H, a.gx, txcd, ntiles);
+	e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	return launch_blend_backward(st, a, counter);   // runs only if the work list overflowed
+}
+
+} // namespace sgs

@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-	uint32_t* __restrict__ act_id, float* __restrict__ wgt, uint32_t* __restrict__ table,
-	uint32_t* __restrict__ nact, uint32_t* __restrict__ counter, uint32_t capacity, int W,
-	int H, int gx, int per_xcd, int ntiles)
+	uint32_t* __restrict__ act_id, uint32_t* __restrict__ act_idx, float* __restrict__ wgt,
+	uint32_t* __restrict__ table, uint32_t* __restrict__ nact, uint32_t* __restrict__ counter,
+	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles)
 {
 	const int b = blockIdx.x;
 	static_assert(MODE == 2 || MODE == 3, "weights format: 2 = split bf16 (default), 3 = fp32 rows (exact)");
@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 					} else {
 						wgt[(size_t)slot * 256 + (SWEEP ? pxp_own : (int)threadIdx.x)] = s_wt[e * 256 + threadIdx.x];
 					}
-					if (threadIdx.x == 0) act_id[slot] = s_e[e].id;
+					if (threadIdx.x == 0) {
+						act_id[slot] = s_e[e].id;
+						if (act_idx) act_idx[slot] = s_e[e].idx1;   // (backward: position in the tile's list)
+					}
 				}
 			}
 			total += cnt;
@@ -785,6 +788,25 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the dummy tail bundles before LDS is released
 }
 
+// The exact-format work list alone (fp32 weight rows + ids + list positions): the backward's first step.
+hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
+				     const float2* means2D, const float4* conic_opacity, float* final_T,
+				     uint32_t* n_contrib, char* arena, const SplitArena& lay, int W, int H, int gx,
+				     int gy)
+{
+	const int ntiles = gx * gy;
+	uint32_t* counter = (uint32_t*)(arena + lay.counter);
+	hipError_t e = hipMemsetAsync(counter, 0, 8, st);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(blend_weights_kernel<3>, dim3(((ntiles + 7) / 8) * 8), dim3(256), 0, st, ranges,
+			   point_list, means2D, conic_opacity, final_T, n_contrib,
+			   (uint32_t*)(arena + lay.act_id), (uint32_t*)(arena + lay.act_idx),
+			   (float*)(arena + lay.wgt), (uint32_t*)(arena + lay.table),
+			   (uint32_t*)(arena + lay.nbatches), counter, lay.capacity, W, H, gx, (ntiles + 7) / 8,
+			   ntiles);
+	return hipGetLastError();
+}
+
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
 {
 	size_t off = 0;
@@ -795,6 +817,7 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	a.nbatches = take((size_t)ntiles * 4);                       // nact[tile]
 	a.table = take(((L >> 7) + (size_t)ntiles + 1) * 4);           // chunk starts
 	a.act_id = take((size_t)capacity * 4);
+	a.act_idx = take((size_t)capacity * 4);
 	a.wgt = take((size_t)capacity * 1024);
 	a.total = (off + 127) & ~(size_t)127;
 	if (lay) *lay = a;
@@ -816,7 +839,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 #define SGS_LAUNCH_W(M_, ST_, T0_, NT_)                                                             \
 	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3((((NT_) + 7) / 8) * 8), dim3(256), 0, ST_,    \
 			   a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, \
-			   act_id, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx,        \
+			   act_id, (uint32_t*)nullptr, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, \
 			   ((NT_) + 7) / 8, NT_)
 	{
 		// ---- row-sweep path (default)

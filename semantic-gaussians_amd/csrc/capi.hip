@@ -25,6 +25,7 @@ namespace {
 thread_local std::string g_err;
 std::atomic<int> g_blend_variant{0};
 std::atomic<int> g_stage_timing{0};
+std::atomic<int> g_backward_mode{0};   // 0 = work-list MFMA backward where eligible, 1 = per-chunk VALU kernel only
 std::atomic<int> g_binning_mode{0};   // 0 = depth-presorted emission (default), 1 = reference order
 float g_stage_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 
@@ -241,6 +242,7 @@ const char* sgs_last_error(void) { return g_err.c_str(); }
 int sgs_set_blend_variant(int variant) { return g_blend_variant.exchange(variant); }
 int sgs_set_stage_timing(int enable) { return g_stage_timing.exchange(enable); }
 int sgs_set_binning_mode(int mode) { return g_binning_mode.exchange(mode); }
+int sgs_set_backward_mode(int mode) { return g_backward_mode.exchange(mode); }
 int sgs_get_stage_ms(float* ms7)
 {
 	std::vector<EventSet> parked;
@@ -575,7 +577,29 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 	a.dL_dopacity = dL_dopacity;
 	a.dL_dcolors = dL_dcolor;
 	if (R > 0) {
-		hipError_t e = sgs::launch_blend_backward(st, a);
+		hipError_t e = hipSuccess;
+		bool done = false;
+		if (g_backward_mode.load() == 0 && sgs::blend_backward_mfma_eligible(a)) {
+			// the forward's work list again, in stream-ordered scratch sized like the forward's arena
+			const int ntiles = gx * gy;
+			uint32_t hint = g_arena_hint.load();
+			if (hint < (uint32_t)ntiles * 192u) hint = (uint32_t)ntiles * 192u;
+			hint = (hint + 0xffffu) & ~0xffffu;
+			const uint64_t cap_max = (uint64_t)R + 128ull * (uint64_t)ntiles;
+			const uint32_t cap = (uint64_t)hint < cap_max ? hint : (uint32_t)cap_max;
+			sgs::SplitArena lay;
+			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay);
+			void* scratch = nullptr;
+			if (hipMallocAsync(&scratch, bytes + 128, st) == hipSuccess && scratch) {
+				e = sgs::launch_blend_backward_mfma(st, a, align_ptr((char*)scratch), lay);
+				const hipError_t e2 = hipFreeAsync(scratch, st);
+				if (e == hipSuccess) e = e2;
+				done = true;
+			} else {
+				(void)hipGetLastError();
+			}
+		}
+		if (!done) e = sgs::launch_blend_backward(st, a);
 		if (e != hipSuccess) return fail_hip(e, "blend backward");
 	}
 	SGS_CHECK_STAGE("blend backward");

@@ -61,6 +61,22 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 	y1 = (uint32_t)imin_(gy, imax_(0, (int)((py + r + (float)(SGS_TILE - 1)) / (float)SGS_TILE)));
 }
 
+// wave64 sum -> valid in every lane (DPP butterflies inside rows of 16, then readlane).
+__device__ __forceinline__ float wave_sum(float v)
+{
+	// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+	// every lane of a 16-lane row now holds the row sum
+	const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+	const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+	const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+	const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+	return (r0 + r1) + (r2 + r3);
+}
+
 // Blend exponential ("exp contract"): range reduction by the 1.5*2^23 magic
 // add, two-term ln2, degree-5 Horner with explicit fma, exponent insertion by integer
 // add.  <= 5 ulp from exp(); reproduced bit for bit by the oracle so that the

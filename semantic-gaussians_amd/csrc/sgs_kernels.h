@@ -79,7 +79,7 @@ hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int varia
 
 // ---- blend_fwd_split.hip (weights pre-pass + streaming accumulate)
 struct SplitArena {   // byte offsets inside the arena chunk
-	size_t counter, nbatches, table, act_id, wgt, total;
+	size_t counter, nbatches, table, act_id, act_idx, wgt, total;
 	uint32_t capacity;   // work-list slots (1 KB of weights + 4 B id each)
 };
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay);
@@ -88,6 +88,11 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
 				      int split_mode);
+
+hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
+				     const float2* means2D, const float4* conic_opacity, float* final_T,
+				     uint32_t* n_contrib, char* arena, const SplitArena& lay, int W, int H, int gx,
+				     int gy);
 
 // ---- blend_bwd.hip
 struct BlendBwdArgs {
@@ -107,7 +112,13 @@ struct BlendBwdArgs {
 	float* dL_dopacity;          // (P)
 	float* dL_dcolors;           // (P,C)
 };
-hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a);
+// `gate` (optional): device flag pair; the kernel runs only if gate[1] != 0 (fallback of the MFMA path).
+hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const uint32_t* gate = nullptr);
+// ---- blend_bwd_mfma.hip: the backward blend for C >= 128, C % 32 == 0 as two matrix products over the
+// forward's work list + a scalar recurrence (see the file header).  `arena` is scratch of
+// split_arena_bytes(capacity, ...) bytes.
+bool blend_backward_mfma_eligible(const BlendBwdArgs& a);
+hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay);
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
 			   const int* radii, const float* shs, const uint8_t* clamped,
 			   const float* scales, const float* rotations, float mod,

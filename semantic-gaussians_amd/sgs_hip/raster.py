@@ -336,5 +336,11 @@ def set_binning_mode(mode):
     return int(_lib.load().sgs_set_binning_mode(int(mode)))
 
 
+def set_backward_mode(mode):
+    """0 = default (C >= 128, C % 32 == 0: the channel work of the backward blend as MFMA products over the
+    forward's work list); 1 = always the per-chunk kernel."""
+    return int(_lib.load().sgs_set_backward_mode(int(mode)))
+
+
 if os.environ.get("SGS_BLEND_EXACT", "0") not in ("", "0"):
     set_blend_exact(True)

@@ -301,6 +301,56 @@ def test_backward_parity(orc, C, use_sh, precomp_cov):
     assert np.abs(gr["dL_dmeans3D"]).max() > 0
 
 
+def _hip_backward(scene, cam, bg, dL, n, radii, geom, binn, img):
+    from sgs_hip import raster
+    s, c = scene.to(DEV), cam.to(DEV)
+    e = torch.Tensor([])
+    return raster.rasterize_backward(
+        torch.from_numpy(bg).to(DEV), s.means3D, radii, s.features, s.scales, s.rotations, 1.0, e,
+        c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, dL.to(DEV), e, 3, c.camera_center,
+        geom, n, binn, img, False)
+
+
+@pytest.mark.parametrize("C,P,W,H,fx,dense", [(128, 1500, 96, 80, 85.0, False), (192, 2500, 100, 70, 90.0, False),
+                                               (128, 12000, 150, 40, 300.0, True), (512, 1500, 64, 48, 60.0, False)])
+def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
+    """C >= 128, C % 32 == 0: the backward blend as matrix products over the work list (blend_bwd_mfma.hip)
+    against the oracle AND against the per-chunk kernel; ragged image edges, a partial 128-channel group,
+    and (dense) lists of several hundred active entries per tile = several arena chunks."""
+    from sgs_hip import raster
+    scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=fx, seed=40 + C + P)
+    if dense:
+        scene = scene._replace(scales=scene.scales * 2.0, opacities=scene.opacities * 0.05)
+    g = torch.Generator().manual_seed(5)
+    bg = np.linspace(0.1, 0.9, C).astype(np.float32)
+    dL = torch.randn(C, H, W, generator=g)
+    fw = oracle_forward(orc, scene, cam, bg=bg)
+    gr = orc.backward(fw, dL.numpy(), scene.means3D.numpy(), cam.world_view_transform.numpy(),
+                      cam.full_proj_transform.numpy(), cam.camera_center.numpy(), W, H, cam.tanfovx,
+                      cam.tanfovy, bg, scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
+                      cov3D_precomp=None, shs=None, sh_degree=3)
+    if dense:
+        assert fw["n_contrib"].max() > 300
+    outs = {}
+    for mode in (0, 1):
+        raster.set_backward_mode(mode)
+        try:
+            n, color, radii, geom, binn, img, _ = _hip_forward(scene, cam, bg=bg)
+            outs[mode] = [t.cpu().numpy() for t in _hip_backward(scene, cam, bg, dL, n, radii, geom, binn, img)]
+        finally:
+            raster.set_backward_mode(0)
+    names = ["dL_dmean2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
+             "dL_dscales", "dL_drotations"]
+    for i, name in enumerate(names):
+        want = gr[name]
+        if want.size == 0:
+            continue
+        for mode in (0, 1):
+            ok, err = _grad_close(outs[mode][i].reshape(want.shape), want, 1e-4)
+            assert ok, (name, mode, err)
+    assert np.abs(outs[0][1]).max() > 0
+
+
 def test_channel_rasterization_call_pattern_matches_render_chn(orc):
     """Executes the exact kwargs of model/renderer.py:169-183,228-237 (render_chn) and of
     :54-69,111 (render) against the drop-in packages, with autograd through both."""

@@ -10,8 +10,10 @@ from sgs_hip.synthetic import CONFIGS, make_scene
 from sgs_hip.camera import pinhole
 
 dev = "cuda:0"
-for name, C in (("cfg2", 3), ("cfg2", 32), ("cfg3", 512)):
+from sgs_hip import raster
+for name, C, bmode in (("cfg2", 3, 0), ("cfg2", 32, 0), ("cfg3", 512, 0), ("cfg3", 512, 1)):
     P, _, W, H, fx = CONFIGS[name]
+    raster.set_backward_mode(bmode)   # 0 = work-list MFMA backward for C >= 128, 1 = per-chunk kernel
     N = 10 if C <= 32 else 3
     scene = make_scene(P, C, W, H, fx, seed=0).to(dev)
     cam = pinhole(W, H, fx).to(dev)
@@ -43,4 +45,4 @@ for name, C in (("cfg2", 3), ("cfg2", 32), ("cfg3", 512)):
         out[0].sum().backward()
     torch.cuda.synchronize()
     tfb = (time.perf_counter() - t0) / N
-    print(f"{name} P={P} C={C} {W}x{H}: forward {tf * 1e3:.2f} ms, forward+backward {tfb * 1e3:.2f} ms")
+    print(f"{name} P={P} C={C} {W}x{H} backward_mode={bmode}: forward {tf * 1e3:.2f} ms, forward+backward {tfb * 1e3:.2f} ms")
