@@ -44,7 +44,9 @@ constexpr int LDP = 36;                     // LDS row pitch (floats) of the 32-
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---- 3. D[slot][px'] = sum_c F[id(slot)][c] * g[c][px']
-__global__ __launch_bounds__(256) void bwd_dot_kernel(
+// 512 threads: wave w owns the 32 px' [32 w, 32 w + 32) for up to 128 entries (4 x 16 accumulators), so
+// two workgroups fit a CU and one stages while the other multiplies.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_dot_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const float* __restrict__ features, const float* __restrict__ bg,
@@ -59,18 +61,20 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(
 	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 	const int l31 = lane & 31, h = lane >> 5;
 	const int tx = tile % gx, ty = tile / gx;
-	const int ry = t >> 4, rx = t & 15;
-	const int px = tx * SGS_TILE + rx, py = ty * SGS_TILE + ry;
-	const bool inside = px < W && py < H;
-	const int pxp = (ry & 1) * 128 + (ry >> 1) * 16 + rx;
 	const size_t HW = (size_t)H * W;
-	const size_t pix = (size_t)py * W + px;
 	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
 	const int total = (int)nact[tile];
+	const bool vec_ok = (W & 3) == 0;
 
 	__shared__ float sF[CHUNK * LDP];
 	__shared__ float sG[32 * 256];
 	__shared__ uint32_t s_id[CHUNK];
+
+	// this thread's share of a 32-channel slab of the tile's gradient: 4 x (channel, row, 4 px)
+	const int g_rem = t & 63, g_row = g_rem >> 2, g_x4 = (g_rem & 3) * 4;
+	const int g_y = ty * SGS_TILE + g_row, g_x = tx * SGS_TILE + g_x4;
+	const int g_pxp = (g_row & 1) * 128 + (g_row >> 1) * 16 + g_x4;
+	const float* g_src = dL_dpix + (size_t)g_y * W + g_x;
 
 	for (int ci = 0; ci * CHUNK < total; ci++) {
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
@@ -78,21 +82,32 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(
 		const uint32_t cstart = table[chunk_base + ci];
 		__syncthreads();
 		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
-		f32x16 acc[4][2];
+		f32x16 acc[4];
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 #pragma unroll
-			for (int n = 0; n < 2; n++)
-#pragma unroll
-				for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
 		for (int c0 = 0; c0 < C; c0 += 32) {
 			__syncthreads();   // s_id visible; the previous slab's readers are done
-#pragma unroll 8
-			for (int c = 0; c < 32; c++)
-				sG[c * 256 + pxp] = inside ? dL_dpix[(size_t)(c0 + c) * HW + pix] : 0.f;
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				const int q = t + 256 * i, e = q >> 3, f = q & 7;
+				const int c = (t >> 6) + 8 * i;
+				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (g_y < H) {
+					const float* src = g_src + (size_t)(c0 + c) * HW;
+					if (vec_ok && g_x + 3 < W) v = *reinterpret_cast<const float4*>(src);
+					else {
+						if (g_x < W) v.x = src[0];
+						if (g_x + 1 < W) v.y = src[1];
+						if (g_x + 2 < W) v.z = src[2];
+						if (g_x + 3 < W) v.w = src[3];
+					}
+				}
+				*reinterpret_cast<float4*>(&sG[c * 256 + g_pxp]) = v;
+			}
+#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				const int q = t + 512 * i, e = q >> 3, f = q & 7;
 				const uint32_t id = s_id[e];
 				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 				if (id == BG_ID) v = *reinterpret_cast<const float4*>(bg + c0 + 4 * f);
@@ -109,17 +124,12 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(
 					if (m < mb) a4[m] = *reinterpret_cast<const float4*>(&sF[(32 * m + l31) * LDP + 16 * h + 4 * s4]);
 #pragma unroll
 				for (int u = 0; u < 4; u++) {
-					const int s = 4 * s4 + u;
-					float bv[2];
-#pragma unroll
-					for (int n = 0; n < 2; n++) bv[n] = sG[(16 * h + s) * 256 + 64 * wave + 32 * n + l31];
+					const float bv = sG[(16 * h + 4 * s4 + u) * 256 + 32 * wave + l31];
 #pragma unroll
 					for (int m = 0; m < 4; m++)
 						if (m < mb) {
 							const float av = u == 0 ? a4[m].x : u == 1 ? a4[m].y : u == 2 ? a4[m].z : a4[m].w;
-#pragma unroll
-							for (int n = 0; n < 2; n++)
-								acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[n], acc[m][n], 0, 0, 0);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
 						}
 				}
 			}
@@ -128,17 +138,17 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(
 		for (int m = 0; m < 4; m++)
 			if (m < mb)
 #pragma unroll
-				for (int n = 0; n < 2; n++)
-#pragma unroll
-					for (int r = 0; r < 16; r++) {
-						const int e = 32 * m + mfma_row(r, h);
-						if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 64 * wave + 32 * n + l31] = acc[m][n][r];
-					}
+				for (int r = 0; r < 16; r++) {
+					const int e = 32 * m + mfma_row(r, h);
+					if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 32 * wave + l31] = acc[m][r];
+				}
 	}
 }
 
 // ---- 2. dL/dF[id(slot)][c] += sum_px' w[slot][px'] * g[c][px']
-__global__ __launch_bounds__(256) void bwd_dcolor_kernel(
+// 512 threads: wave w owns channels [32 (w & 3), +32) of the 128-channel group and entries
+// [64 (w >> 2), +64) of the chunk (2 x 16 accumulators).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_dcolor_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const float* __restrict__ Wrows, const float* __restrict__ dL_dpix,
@@ -152,13 +162,13 @@ __global__ __launch_bounds__(256) void bwd_dcolor_kernel(
 	const int tile = item / nch, cc = item - tile * nch;
 	const int t = threadIdx.x;
 	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int nb = wave & 3, mh = wave >> 2;
 	const int l31 = lane & 31, h = lane >> 5;
 	const int tx = tile % gx, ty = tile / gx;
 	const size_t HW = (size_t)H * W;
 	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
 	const int total = (int)nact[tile];
 	const int cbase = cc * 128;
-	const bool wave_on = cbase + 32 * wave < C;   // (C % 32 == 0)
 	const bool vec_ok = (W & 3) == 0;
 
 	__shared__ float sW[CHUNK * LDP];
@@ -168,28 +178,29 @@ __global__ __launch_bounds__(256) void bwd_dcolor_kernel(
 	for (int ci = 0; ci * CHUNK < total; ci++) {
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
 		const int cnt16 = (cnt + 15) & ~15;   // rows up to here are initialised (zero padding of the work list)
-		const int mb = (cnt + 31) >> 5;
+		const int mb = ((cnt + 31) >> 5) - 2 * mh;   // M blocks of this wave's entry half that hold entries
+		const bool wave_on = cbase + 32 * nb < C && mb > 0;   // (C % 32 == 0)
 		const uint32_t cstart = table[chunk_base + ci];
 		__syncthreads();
 		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
-		f32x16 acc[4];
+		f32x16 acc[2];
 #pragma unroll
-		for (int m = 0; m < 4; m++)
+		for (int m = 0; m < 2; m++)
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
 		for (int j = 0; j < 8; j++) {   // slabs of 32 px' = two image rows of one parity
 			__syncthreads();
 			const int par = j >> 2;
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				const int q = t + 256 * i, e = q >> 3, f = q & 7;
+			for (int i = 0; i < 2; i++) {
+				const int q = t + 512 * i, e = q >> 3, f = q & 7;
 				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 				if (e < cnt16) v = *reinterpret_cast<const float4*>(Wrows + (size_t)(cstart + e) * 256 + 32 * j + 4 * f);
 				*reinterpret_cast<float4*>(&sW[e * LDP + 4 * f]) = v;
 			}
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				const int q = t + 256 * i, ch = q >> 3, f = q & 7;
+			for (int i = 0; i < 2; i++) {
+				const int q = t + 512 * i, ch = q >> 3, f = q & 7;
 				const int r2 = f >> 2, x4 = (f & 3) * 4;
 				const int y = ty * SGS_TILE + 2 * ((j & 3) * 2 + r2) + par;
 				const int x = tx * SGS_TILE + x4;
@@ -212,16 +223,16 @@ __global__ __launch_bounds__(256) void bwd_dcolor_kernel(
 				// MFMA k index = lane half h  <->  px' 32 j + 16 h + s
 #pragma unroll
 				for (int s4 = 0; s4 < 4; s4++) {
-					float4 a4[4];
+					float4 a4[2];
 #pragma unroll
-					for (int m = 0; m < 4; m++)
-						if (m < mb) a4[m] = *reinterpret_cast<const float4*>(&sW[(32 * m + l31) * LDP + 16 * h + 4 * s4]);
-					const float4 b4 = *reinterpret_cast<const float4*>(&sG[(32 * wave + l31) * LDP + 16 * h + 4 * s4]);
+					for (int m = 0; m < 2; m++)
+						if (m < mb) a4[m] = *reinterpret_cast<const float4*>(&sW[(64 * mh + 32 * m + l31) * LDP + 16 * h + 4 * s4]);
+					const float4 b4 = *reinterpret_cast<const float4*>(&sG[(32 * nb + l31) * LDP + 16 * h + 4 * s4]);
 #pragma unroll
 					for (int u = 0; u < 4; u++) {
 						const float bv = u == 0 ? b4.x : u == 1 ? b4.y : u == 2 ? b4.z : b4.w;
 #pragma unroll
-						for (int m = 0; m < 4; m++)
+						for (int m = 0; m < 2; m++)
 							if (m < mb) {
 								const float av = u == 0 ? a4[m].x : u == 1 ? a4[m].y : u == 2 ? a4[m].z : a4[m].w;
 								acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
@@ -232,13 +243,13 @@ __global__ __launch_bounds__(256) void bwd_dcolor_kernel(
 		}
 		if (wave_on) {
 #pragma unroll
-			for (int m = 0; m < 4; m++)
+			for (int m = 0; m < 2; m++)
 				if (m < mb)
 #pragma unroll
 					for (int r = 0; r < 16; r++) {
-						const int e = 32 * m + mfma_row(r, h);
+						const int e = 64 * mh + 32 * m + mfma_row(r, h);
 						const uint32_t id = s_id[e];
-						if (id < NO_ID) atomicAdd(&dL_dcolors[(size_t)id * C + cbase + 32 * wave + l31], acc[m][r]);
+						if (id < NO_ID) atomicAdd(&dL_dcolors[(size_t)id * C + cbase + 32 * nb + l31], acc[m][r]);
 					}
 		}
 	}
@@ -390,9 +401,9 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const int nch = (a.C + 127) / 128;
 	const int items = ntiles * nch;
 	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
-	hipLaunchKernelGGL(bwd_dcolor_kernel, dim3(ixcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, rows,
+	hipLaunchKernelGGL(bwd_dcolor_kernel, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows,
 			   a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);
-	hipLaunchKernelGGL(bwd_dot_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, a.colors,
+	hipLaunchKernelGGL(bwd_dot_kernel, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, a.colors,
 			   a.bg, a.dL_dpix, rows, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
 			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
