@@ -229,10 +229,11 @@ int sgs_set_stage_timing(int mode);
  * ranges and the (reconstructed) sorted keys are bit-identical in all modes; point_offsets and
  * the UNSORTED key/value arrays exist only in mode 1.  Returns the previous mode. */
 int sgs_set_binning_mode(int mode);
-/* Backward blend: 0 (default) = for num_channels >= 128 with num_channels % 32 == 0 the channel work runs
+/* Backward blend: 0 (default) = for num_channels >= 32 with num_channels % 32 == 0 the channel work runs
  * as two fp32 MFMA products over the forward's work list (blend_bwd_mfma.hip; scratch comes from
  * hipMallocAsync on `stream`), the per-chunk kernel otherwise; 1 = always the per-chunk kernel
- * (blend_bwd.hip).  Same gradients up to fp32 summation order.  Returns the previous mode. */
+ * (blend_bwd.hip); 2 = as 0 with a deliberately undersized work-list arena (exercises the overflow
+ * fallback; tests only).  Same gradients up to fp32 summation order.  Returns the previous mode. */
 int sgs_set_backward_mode(int mode);
 int sgs_get_stage_ms(float *ms7);
 

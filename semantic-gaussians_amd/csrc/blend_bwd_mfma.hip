@@ -1,4 +1,4 @@
-// blend_bwd_mfma.hip -- backward of the N-channel alpha-composite as matrix products (C >= 128).
+// blend_bwd_mfma.hip -- backward of the N-channel alpha-composite as matrix products (C >= 32, C % 32 == 0).
 //
 // Behaviour: CR/cuda_rasterizer/backward.cu:394-552 (renderCUDA backward), restated for a runtime
 // channel count in blend_bwd.hip.  That kernel walks every tile's list once per 32-channel chunk and
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 {
-	return a.C >= 128 && (a.C & 31) == 0 && (((uintptr_t)a.colors | (uintptr_t)a.bg) & 15u) == 0 &&
+	return a.C >= 32 && (a.C & 31) == 0 && (((uintptr_t)a.colors | (uintptr_t)a.bg) & 15u) == 0 &&
 	       ((uintptr_t)a.dL_dpix & 15u) == 0;
 }
 

@@ -579,14 +579,16 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 	if (R > 0) {
 		hipError_t e = hipSuccess;
 		bool done = false;
-		if (g_backward_mode.load() == 0 && sgs::blend_backward_mfma_eligible(a)) {
+		const int bw_mode = g_backward_mode.load();
+		if (bw_mode != 1 && sgs::blend_backward_mfma_eligible(a)) {
 			// the forward's work list again, in stream-ordered scratch sized like the forward's arena
 			const int ntiles = gx * gy;
 			uint32_t hint = g_arena_hint.load();
 			if (hint < (uint32_t)ntiles * 192u) hint = (uint32_t)ntiles * 192u;
 			hint = (hint + 0xffffu) & ~0xffffu;
 			const uint64_t cap_max = (uint64_t)R + 128ull * (uint64_t)ntiles;
-			const uint32_t cap = (uint64_t)hint < cap_max ? hint : (uint32_t)cap_max;
+			uint32_t cap = (uint64_t)hint < cap_max ? hint : (uint32_t)cap_max;
+			if (bw_mode == 2) cap = 128u * (uint32_t)((ntiles + 1) / 2);   // (tests: guaranteed overflow -> gated fallback)
 			sgs::SplitArena lay;
 			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay);
 			void* scratch = nullptr;

@@ -337,8 +337,8 @@ def set_binning_mode(mode):
 
 
 def set_backward_mode(mode):
-    """0 = default (C >= 128, C % 32 == 0: the channel work of the backward blend as MFMA products over the
-    forward's work list); 1 = always the per-chunk kernel."""
+    """0 = default (C >= 32, C % 32 == 0: the channel work of the backward blend as MFMA products over the
+    forward's work list); 1 = always the per-chunk kernel; 2 = as 0 with an undersized arena (tests)."""
     return int(_lib.load().sgs_set_backward_mode(int(mode)))
 
 

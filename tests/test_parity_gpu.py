@@ -312,11 +312,14 @@ def _hip_backward(scene, cam, bg, dL, n, radii, geom, binn, img):
 
 
 @pytest.mark.parametrize("C,P,W,H,fx,dense", [(128, 1500, 96, 80, 85.0, False), (192, 2500, 100, 70, 90.0, False),
-                                               (128, 12000, 150, 40, 300.0, True), (512, 1500, 64, 48, 60.0, False)])
+                                               (128, 12000, 150, 40, 300.0, True), (512, 1500, 64, 48, 60.0, False),
+                                               (32, 2000, 101, 67, 90.0, False), (96, 1500, 64, 64, 70.0, False)])
 def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
-    """C >= 128, C % 32 == 0: the backward blend as matrix products over the work list (blend_bwd_mfma.hip)
-    against the oracle AND against the per-chunk kernel; ragged image edges, a partial 128-channel group,
-    and (dense) lists of several hundred active entries per tile = several arena chunks."""
+    """C >= 32, C % 32 == 0: the backward blend as matrix products over the work list (blend_bwd_mfma.hip)
+    against the oracle AND against the per-chunk kernel; ragged image edges (also a width that is not a
+    multiple of 4), partial 128-channel groups, (dense) lists of several hundred active entries per tile =
+    several arena chunks, and mode 2 = undersized arena: the device-side overflow flag hands over to the
+    per-chunk kernel."""
     from sgs_hip import raster
     scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=fx, seed=40 + C + P)
     if dense:
@@ -332,7 +335,7 @@ def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
     if dense:
         assert fw["n_contrib"].max() > 300
     outs = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         raster.set_backward_mode(mode)
         try:
             n, color, radii, geom, binn, img, _ = _hip_forward(scene, cam, bg=bg)
@@ -345,7 +348,7 @@ def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
         want = gr[name]
         if want.size == 0:
             continue
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             ok, err = _grad_close(outs[mode][i].reshape(want.shape), want, 1e-4)
             assert ok, (name, mode, err)
     assert np.abs(outs[0][1]).max() > 0
