@@ -43,9 +43,48 @@ constexpr int LDP = 36;                     // LDS row pitch (floats) of the 32-
 // row of the 32x32 MFMA result held in accumulator register r of a lane in half h
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Four consecutive pixels of a gradient row, branch free: `row` points at a (clamped, in-bounds) row, x is
+// the first pixel.  VEC (W % 4 == 0, x % 4 == 0): one 16-byte load, the piece is entirely inside or outside
+// the image.  Otherwise four clamped scalar loads.  The values of out-of-image pixels are zeroed by
+// mask_px4 -- LATER, when the piece is written to LDS: a select right behind the load would make the wave
+// wait for it before the matrix work the load is meant to overlap.
+template <bool VEC>
+__device__ __forceinline__ float4 load_px4(const float* __restrict__ row, int x, int W)
+{
+	float4 v;
+	if (VEC) {
+		v = *reinterpret_cast<const float4*>(row + (x < W ? x : W - 4));
+	} else {
+		v.x = row[x < W ? x : W - 1];
+		v.y = row[x + 1 < W ? x + 1 : W - 1];
+		v.z = row[x + 2 < W ? x + 2 : W - 1];
+		v.w = row[x + 3 < W ? x + 3 : W - 1];
+	}
+	return v;
+}
+__device__ __forceinline__ float4 mask_px4(float4 v, int x, int W, bool ok)
+{
+	v.x = (ok && x < W) ? v.x : 0.f;
+	v.y = (ok && x + 1 < W) ? v.y : 0.f;
+	v.z = (ok && x + 2 < W) ? v.z : 0.f;
+	v.w = (ok && x + 3 < W) ? v.w : 0.f;
+	return v;
+}
+__device__ __forceinline__ float4 mask4(float4 v, bool ok)
+{
+	v.x = ok ? v.x : 0.f;
+	v.y = ok ? v.y : 0.f;
+	v.z = ok ? v.z : 0.f;
+	v.w = ok ? v.w : 0.f;
+	return v;
+}
+
 // ---- 3. D[slot][px'] = sum_c F[id(slot)][c] * g[c][px']
 // 512 threads: wave w owns the 32 px' [32 w, 32 w + 32) for up to 128 entries (4 x 16 accumulators), so
-// two workgroups fit a CU and one stages while the other multiplies.
+// two workgroups fit a CU (the any-width instantiation spills; widths that are not a multiple of 4 are
+// rare).  All global loads are unconditional (clamped addresses + selects): with
+// branches around them the compiler can no longer count outstanding loads and drains them one by one.
+template <bool VEC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_dot_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -61,20 +100,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 	const int l31 = lane & 31, h = lane >> 5;
 	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
+	const uint32_t HW = (uint32_t)H * (uint32_t)W;
 	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
 	const int total = (int)nact[tile];
-	const bool vec_ok = (W & 3) == 0;
 
 	__shared__ float sF[CHUNK * LDP];
 	__shared__ float sG[32 * 256];
 	__shared__ uint32_t s_id[CHUNK];
 
-	// this thread's share of a 32-channel slab of the tile's gradient: 4 x (channel, row, 4 px)
+	// this thread's share of a 32-channel slab of the tile's gradient: 4 x (channel wave + 8 i, row, 4 px)
 	const int g_rem = t & 63, g_row = g_rem >> 2, g_x4 = (g_rem & 3) * 4;
 	const int g_y = ty * SGS_TILE + g_row, g_x = tx * SGS_TILE + g_x4;
 	const int g_pxp = (g_row & 1) * 128 + (g_row >> 1) * 16 + g_x4;
-	const float* g_src = dL_dpix + (size_t)g_y * W + g_x;
+	const bool g_ok = g_y < H;
+	const uint32_t g_off = (uint32_t)wave * HW + (uint32_t)(g_ok ? g_y : H - 1) * (uint32_t)W;   // row start within a slab
 
 	for (int ci = 0; ci * CHUNK < total; ci++) {
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
@@ -87,51 +126,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		for (int m = 0; m < 4; m++)
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-		for (int c0 = 0; c0 < C; c0 += 32) {
-			__syncthreads();   // s_id visible; the previous slab's readers are done
+		__syncthreads();   // s_id visible
+		// this thread's two feature-row pieces of the chunk (fixed for all slabs)
+		const float* frow[2];
+		bool fvalid[2];
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				const int c = (t >> 6) + 8 * i;
-				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (g_y < H) {
-					const float* src = g_src + (size_t)(c0 + c) * HW;
-					if (vec_ok && g_x + 3 < W) v = *reinterpret_cast<const float4*>(src);
-					else {
-						if (g_x < W) v.x = src[0];
-						if (g_x + 1 < W) v.y = src[1];
-						if (g_x + 2 < W) v.z = src[2];
-						if (g_x + 3 < W) v.w = src[3];
-					}
-				}
-				*reinterpret_cast<float4*>(&sG[c * 256 + g_pxp]) = v;
-			}
+		for (int i = 0; i < 2; i++) {
+			const int q = t + 512 * i, e = q >> 3, f = q & 7;
+			const uint32_t id = s_id[e];
+			fvalid[i] = id != NO_ID;
+			frow[i] = ((id == BG_ID || id == NO_ID) ? bg : features + (size_t)id * C) + 4 * f;
+		}
+		// the next 32-channel slab is fetched into registers while the current one is multiplied
+		float4 pg[4], pf[2];
+		auto fetch = [&](int c0) __attribute__((always_inline)) {
+			const float* gb = dL_dpix + (size_t)c0 * HW;   // (uniform)
+#pragma unroll
+			for (int i = 0; i < 4; i++) pg[i] = load_px4<VEC>(gb + g_off + (uint32_t)(8 * i) * HW, g_x, W);
+#pragma unroll
+			for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
+		};
+		fetch(0);
+		for (int c0 = 0; c0 < C; c0 += 32) {
+			__syncthreads();   // the previous slab's readers are done
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				*reinterpret_cast<float4*>(&sG[(wave + 8 * i) * 256 + g_pxp]) = mask_px4(pg[i], g_x, W, g_ok);
 #pragma unroll
 			for (int i = 0; i < 2; i++) {
 				const int q = t + 512 * i, e = q >> 3, f = q & 7;
-				const uint32_t id = s_id[e];
-				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (id == BG_ID) v = *reinterpret_cast<const float4*>(bg + c0 + 4 * f);
-				else if (id != NO_ID) v = *reinterpret_cast<const float4*>(features + (size_t)id * C + c0 + 4 * f);
-				*reinterpret_cast<float4*>(&sF[e * LDP + 4 * f]) = v;
+				*reinterpret_cast<float4*>(&sF[e * LDP + 4 * f]) = mask4(pf[i], fvalid[i]);
 			}
 			__syncthreads();
+			if (c0 + 32 < C) fetch(c0 + 32);
 			// MFMA k index = lane half h  <->  channel c0 + 16 h + s
 #pragma unroll
 			for (int s4 = 0; s4 < 4; s4++) {
-				float4 a4[4];
+				float bv[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) bv[u] = sG[(16 * h + 4 * s4 + u) * 256 + 32 * wave + l31];
 #pragma unroll
 				for (int m = 0; m < 4; m++)
-					if (m < mb) a4[m] = *reinterpret_cast<const float4*>(&sF[(32 * m + l31) * LDP + 16 * h + 4 * s4]);
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					const float bv = sG[(16 * h + 4 * s4 + u) * 256 + 32 * wave + l31];
-#pragma unroll
-					for (int m = 0; m < 4; m++)
-						if (m < mb) {
-							const float av = u == 0 ? a4[m].x : u == 1 ? a4[m].y : u == 2 ? a4[m].z : a4[m].w;
-							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-						}
-				}
+					if (m < mb) {
+						const float4 a = *reinterpret_cast<const float4*>(&sF[(32 * m + l31) * LDP + 16 * h + 4 * s4]);
+						acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[0], acc[m], 0, 0, 0);
+						acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[1], acc[m], 0, 0, 0);
+						acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[2], acc[m], 0, 0, 0);
+						acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[3], acc[m], 0, 0, 0);
+					}
 			}
 		}
 #pragma unroll
@@ -148,6 +190,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---- 2. dL/dF[id(slot)][c] += sum_px' w[slot][px'] * g[c][px']
 // 512 threads: wave w owns channels [32 (w & 3), +32) of the 128-channel group and entries
 // [64 (w >> 2), +64) of the chunk (2 x 16 accumulators).
+template <bool VEC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_dcolor_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -165,15 +208,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	const int nb = wave & 3, mh = wave >> 2;
 	const int l31 = lane & 31, h = lane >> 5;
 	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
+	const uint32_t HW = (uint32_t)H * (uint32_t)W;
 	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
 	const int total = (int)nact[tile];
 	const int cbase = cc * 128;
-	const bool vec_ok = (W & 3) == 0;
 
 	__shared__ float sW[CHUNK * LDP];
 	__shared__ float sG[128 * LDP];
 	__shared__ uint32_t s_id[CHUNK];
+
+	// this thread's two pieces of a slab: (row q >> 3, 4 floats at 4 (q & 7)) of BOTH operand slabs --
+	// entry q >> 3 of the weights, channel cbase + (q >> 3) of the gradient (image row 2 (f >> 2), px 4 (f & 3))
+	const float* gch[2];
+	bool cvalid[2];
+	int gy0[2], gxx[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		const int q = t + 512 * i, e = q >> 3, f = q & 7;
+		cvalid[i] = cbase + e < C;
+		gch[i] = dL_dpix + (size_t)(cvalid[i] ? cbase + e : cbase) * HW;
+		gy0[i] = ty * SGS_TILE + 2 * (f >> 2);
+		gxx[i] = tx * SGS_TILE + (f & 3) * 4;
+	}
 
 	for (int ci = 0; ci * CHUNK < total; ci++) {
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
@@ -188,56 +244,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		for (int m = 0; m < 2; m++)
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-		for (int j = 0; j < 8; j++) {   // slabs of 32 px' = two image rows of one parity
-			__syncthreads();
-			const int par = j >> 2;
+		const float* wrow[2];
+		bool wvalid[2];
+#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			const int q = t + 512 * i, e = q >> 3, f = q & 7;
+			wvalid[i] = e < cnt16;
+			wrow[i] = Wrows + (size_t)(cstart + (wvalid[i] ? e : 0)) * 256 + 4 * f;
+		}
+		// slabs of 32 px' = two image rows of one parity; slab j + 1 is fetched into registers while slab j
+		// is multiplied
+		float4 pw[2], pg[2];
+		bool pok[2];
+		auto fetch = [&](int j) __attribute__((always_inline)) {
+			const int yo = 4 * (j & 3) + (j >> 2);   // y = 16 ty + 4 (j & 3) + 2 r2 + parity
+#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				pw[i] = *reinterpret_cast<const float4*>(wrow[i] + 32 * j);
+				const int y = gy0[i] + yo;
+				pok[i] = cvalid[i] && y < H;
+				pg[i] = load_px4<VEC>(gch[i] + (uint32_t)(y < H ? y : H - 1) * (uint32_t)W, gxx[i], W);
+			}
+		};
+		fetch(0);
+		for (int j = 0; j < 8; j++) {
+			__syncthreads();   // the previous slab's readers are done (and s_id is visible)
 #pragma unroll
 			for (int i = 0; i < 2; i++) {
 				const int q = t + 512 * i, e = q >> 3, f = q & 7;
-				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (e < cnt16) v = *reinterpret_cast<const float4*>(Wrows + (size_t)(cstart + e) * 256 + 32 * j + 4 * f);
-				*reinterpret_cast<float4*>(&sW[e * LDP + 4 * f]) = v;
-			}
-#pragma unroll
-			for (int i = 0; i < 2; i++) {
-				const int q = t + 512 * i, ch = q >> 3, f = q & 7;
-				const int r2 = f >> 2, x4 = (f & 3) * 4;
-				const int y = ty * SGS_TILE + 2 * ((j & 3) * 2 + r2) + par;
-				const int x = tx * SGS_TILE + x4;
-				const int c = cbase + ch;
-				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (c < C && y < H) {
-					const float* src = dL_dpix + (size_t)c * HW + (size_t)y * W + x;
-					if (vec_ok && x + 3 < W) v = *reinterpret_cast<const float4*>(src);
-					else {
-						if (x < W) v.x = src[0];
-						if (x + 1 < W) v.y = src[1];
-						if (x + 2 < W) v.z = src[2];
-						if (x + 3 < W) v.w = src[3];
-					}
-				}
-				*reinterpret_cast<float4*>(&sG[ch * LDP + 16 * r2 + x4]) = v;
+				*reinterpret_cast<float4*>(&sW[e * LDP + 4 * f]) = mask4(pw[i], wvalid[i]);
+				*reinterpret_cast<float4*>(&sG[e * LDP + 4 * f]) = mask_px4(pg[i], gxx[i], W, pok[i]);
 			}
 			__syncthreads();
+			if (j + 1 < 8) fetch(j + 1);
 			if (wave_on) {
 				// MFMA k index = lane half h  <->  px' 32 j + 16 h + s
 #pragma unroll
 				for (int s4 = 0; s4 < 4; s4++) {
-					float4 a4[2];
-#pragma unroll
-					for (int m = 0; m < 2; m++)
-						if (m < mb) a4[m] = *reinterpret_cast<const float4*>(&sW[(64 * mh + 32 * m + l31) * LDP + 16 * h + 4 * s4]);
 					const float4 b4 = *reinterpret_cast<const float4*>(&sG[(32 * nb + l31) * LDP + 16 * h + 4 * s4]);
 #pragma unroll
-					for (int u = 0; u < 4; u++) {
-						const float bv = u == 0 ? b4.x : u == 1 ? b4.y : u == 2 ? b4.z : b4.w;
-#pragma unroll
-						for (int m = 0; m < 2; m++)
-							if (m < mb) {
-								const float av = u == 0 ? a4[m].x : u == 1 ? a4[m].y : u == 2 ? a4[m].z : a4[m].w;
-								acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-							}
-					}
+					for (int m = 0; m < 2; m++)
+						if (m < mb) {
+							const float4 a = *reinterpret_cast<const float4*>(&sW[(64 * mh + 32 * m + l31) * LDP + 16 * h + 4 * s4]);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b4.x, acc[m], 0, 0, 0);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b4.y, acc[m], 0, 0, 0);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b4.z, acc[m], 0, 0, 0);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b4.w, acc[m], 0, 0, 0);
+						}
 				}
 			}
 		}
@@ -382,7 +435,7 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 {
 	return a.C >= 32 && (a.C & 31) == 0 && (((uintptr_t)a.colors | (uintptr_t)a.bg) & 15u) == 0 &&
-	       ((uintptr_t)a.dL_dpix & 15u) == 0;
+	       ((uintptr_t)a.dL_dpix & 15u) == 0 && (size_t)a.H * a.W * 128 * 4 < ((size_t)1 << 32);   // 32-bit slab offsets
 }
 
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay)
@@ -401,10 +454,14 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const int nch = (a.C + 127) / 128;
 	const int items = ntiles * nch;
 	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
-	hipLaunchKernelGGL(bwd_dcolor_kernel, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows,
-			   a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);
-	hipLaunchKernelGGL(bwd_dot_kernel, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, a.colors,
-			   a.bg, a.dL_dpix, rows, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
+	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows
+#define SGS_LAUNCH_BWD(V_, DOT_)                                                                                 \
+	hipLaunchKernelGGL(bwd_dcolor_kernel<V_>, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, \
+			   rows, a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);        \
+	hipLaunchKernelGGL(DOT_, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, a.colors, a.bg,  \
+			   a.dL_dpix, rows, counter, a.W, a.H, a.C, a.gx, txcd, ntiles)
+	if (vec) { SGS_LAUNCH_BWD(true, bwd_dot_kernel<true>); } else { SGS_LAUNCH_BWD(false, bwd_dot_kernel<false>); }
+#undef SGS_LAUNCH_BWD
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
 			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
 			   a.dL_dopacity, counter, a.W, a.H, a.gx, txcd, ntiles);
