@@ -59,6 +59,8 @@ constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the closing T *
 //                   [256 px'][8 x lo] (4 KB).
 // MODE 3 (exact):   fp32 rows, [entry][256 px'] (1 KB per entry).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
 __global__ __launch_bounds__(256) void blend_weights_kernel(
@@ -510,6 +512,9 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 		ah[kk] = (__bf16)f[kk];
 		al[kk] = (__bf16)(f[kk] - (float)ah[kk]);
 	}
+	const s16x8 ahs = __builtin_bit_cast(s16x8, ah), als = __builtin_bit_cast(s16x8, al);
+	const s16x4 ah0 = {ahs[0], ahs[1], ahs[2], ahs[3]}, ah1 = {ahs[4], ahs[5], ahs[6], ahs[7]};
+	const s16x4 al0 = {als[0], als[1], als[2], als[3]}, al1 = {als[4], als[5], als[6], als[7]};
 #pragma unroll
 	for (int pb = 0; pb < 4; pb++) {   // the next block's operands fly while this block multiplies
 		v4i nh, nl;
@@ -522,10 +527,24 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 				: "v"(wn)
 				: "memory");
 		}
-		const bf16x8 h = __builtin_bit_cast(bf16x8, bh), l = __builtin_bit_cast(bf16x8, bl);
-		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h, S[1][pb], 0, 0, 0);
-		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l, S[1][pb], 0, 0, 0);
-		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h, S[1][pb], 0, 0, 0);
+		// Each of the three products is issued as two v_mfma_f32_32x32x8_bf16_1k over the two halves of the
+		// lane's 8 k-values (lane half h owns k = 8 h + j: the pairing of A and B stays consistent), NOT as one
+		// gfx950 v_mfma_f32_32x32x16_bf16.  With the double-rate instruction in this kernel, waves of OTHER
+		// kernels resident on the same CU (a second view's preprocess / binning / weights on another stream)
+		// sporadically received a wrong 256-byte beat of a global_load_dwordx4 return: ~1 forward in 1000
+		// with two views in flight came out with a handful of wrong radii (24 000-view stress runs: 16-26
+		// corrupted forwards with the x16 form, 0 with this form, 0 with the fp32-MFMA sweep, 0 with the MFMAs
+		// replaced by VALU work; stores and LDS prefetch pattern made no difference).  The
+		// halved matrix rate costs ~0.09 ms of the sweep at the headline size.
+		const s16x8 h = __builtin_bit_cast(s16x8, bh), l = __builtin_bit_cast(s16x8, bl);
+		const s16x4 h0 = {h[0], h[1], h[2], h[3]}, h1 = {h[4], h[5], h[6], h[7]};
+		const s16x4 l0 = {l[0], l[1], l[2], l[3]}, l1 = {l[4], l[5], l[6], l[7]};
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(al0, h0, S[1][pb], 0, 0, 0);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(al1, h1, S[1][pb], 0, 0, 0);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah0, l0, S[1][pb], 0, 0, 0);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah1, l1, S[1][pb], 0, 0, 0);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah0, h0, S[1][pb], 0, 0, 0);
+		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah1, h1, S[1][pb], 0, 0, 0);
 		if (pb < 3) {
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nh), "+v"(nl) : : "memory");
 			__builtin_amdgcn_sched_barrier(0);
