@@ -177,6 +177,11 @@ def main():
     torch.cuda.synchronize(dev)
     raster.set_stage_timing(0)
     stage_ms = raster.get_stage_ms()
+    # integrity reference: every view's num_rendered, rendered alone (concurrent forwards must reproduce it)
+    ref_n = []
+    for i in range(V):
+        ref_n.append(render(i)[0])
+        torch.cuda.synchronize(dev)
     # warm-up, second half: the batch as it is timed
     for _ in range(max(2, args.warmup - n_single)):
         out = step()
@@ -184,8 +189,10 @@ def main():
     barrier()
     step_marks = []
     t0 = time.perf_counter()
+    mismatches = 0
     for _ in range(args.steps):
         out = step()
+        mismatches += sum(int(o[0] != n) for o, n in zip(out, ref_n))   # host ints, no device work
         step_marks.append(time.perf_counter())
     barrier()
     t = time.perf_counter() - t0
@@ -280,6 +287,7 @@ def main():
                                  [round(v, 4) for v in stage_ms])),
             "stage_ms_timed_region": dict(zip(["preprocess", "scan_readback", "duplicate", "sort", "ranges",
                                                "blend_weights", "blend_accum"], [round(v, 4) for v in stage_ms_timed])),
+            "integrity": {"forwards_checked": args.steps * V, "num_rendered_mismatches_vs_serial": mismatches},
             "workload_stats": {"P_vis": p_vis, "num_rendered": num_rendered, "sum_n_t_eff": sum_neff,
                                "tiles": tiles},
         }

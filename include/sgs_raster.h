@@ -237,6 +237,33 @@ int sgs_set_binning_mode(int mode);
 int sgs_set_backward_mode(int mode);
 int sgs_get_stage_ms(float *ms7);
 
+/* ---- 2-D -> 3-D fusion step (the callers either side of the depth render) ----
+ *
+ * sgs_fusion_compute_mapping replaces PointCloudToImageMapper.compute_mapping
+ * (dataset/fusion_utils.py:30-78), which the reference evaluates in NumPy on the host once per view
+ * (fusion.py:127-133) after copying the Gaussian centres and the rendered depth off the device.
+ *   coords                (N,3) float32, device: Gaussian centres
+ *   world_view_transform  16 float32, device: the view's matrix exactly as the reference holds it
+ *                         (the TRANSPOSED world-to-camera matrix; it is applied transposed, :45)
+ *   intrinsics4           HOST doubles fx, fy, cx, cy AFTER the mapper's constructor adjustment (:22-28)
+ *   depth_mode            0 = no depth (front test z > 0, :71-73); 1 = `depth` is the (H,W) float32 map
+ *                         (occlusion test |d - z| <= vis_thres * d, :63-69); 2 = "surface": the z-buffer of
+ *                         the points themselves (:57-62), built in `zbuf` ((H,W) float64 scratch)
+ *   mapping               (N,3) int64 out: (y, x, 1) for visible points, (0,0,0) otherwise
+ *   weight                (N) float64 out: exp(-distance of the pixel from the image centre / 10) (:77)
+ * Arithmetic is float64 in the reference's operation order; the integer outputs are the reference's.
+ *
+ * sgs_fusion_accumulate is the per-view accumulation of fuse_one_scene (fusion.py:139-147): for every
+ * visible point  feat_sum[i,:] += features[y,x,:]  and  times[i] += 1.  `features_hwc` is the 2-D feature map
+ * channel-LAST, (H,W,C) float32 (the reference indexes a (C,H,W) map on the host); fp32 adds, one per
+ * point and channel, so the sums are the reference's bit for bit. */
+int sgs_fusion_compute_mapping(int N, const float *coords, const float *world_view_transform,
+                               const double *intrinsics4, int image_w, int image_h, int cut_bound,
+                               double vis_thres, int depth_mode, const float *depth, double *zbuf,
+                               long long *mapping, double *weight, void *stream);
+int sgs_fusion_accumulate(int N, int C, const float *features_hwc, int image_w, int image_h,
+                          const long long *mapping, float *feat_sum, float *times, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -629,6 +629,39 @@ int sgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 	return 0;
 }
 
+int sgs_fusion_compute_mapping(int N, const float* coords, const float* world_view_transform,
+			       const double* intrinsics4, int image_w, int image_h, int cut_bound,
+			       double vis_thres, int depth_mode, const float* depth, double* zbuf,
+			       long long* mapping, double* weight, void* stream)
+{
+	if (N < 0 || image_w <= 0 || image_h <= 0 || cut_bound < 0) return fail(SGS_EINVAL, "bad sizes");
+	if (N == 0) return 0;
+	if (!coords || !world_view_transform || !intrinsics4 || !mapping || !weight)
+		return fail(SGS_EINVAL, "null argument");
+	if (depth_mode < 0 || depth_mode > 2) return fail(SGS_EINVAL, "depth_mode must be 0 (none), 1 (map) or 2 (surface)");
+	if (depth_mode == 1 && !depth) return fail(SGS_EINVAL, "depth_mode 1 needs the (H,W) depth map");
+	if (depth_mode == 2 && !zbuf) return fail(SGS_EINVAL, "depth_mode 2 needs an (H,W) float64 scratch");
+	hipError_t e = sgs::launch_fusion_mapping((hipStream_t)stream, N, coords, world_view_transform, intrinsics4,
+						  image_w, image_h, cut_bound, vis_thres, depth_mode, depth, zbuf,
+						  mapping, weight);
+	if (e != hipSuccess) return fail_hip(e, "fusion mapping");
+	return 0;
+}
+
+int sgs_fusion_accumulate(int N, int C, const float* features_hwc, int image_w, int image_h,
+			  const long long* mapping, float* feat_sum, float* times, void* stream)
+{
+	if (N < 0 || C < 0 || image_w <= 0 || image_h <= 0) return fail(SGS_EINVAL, "bad sizes");
+	if (N == 0 || C == 0) return 0;
+	if (!features_hwc || !mapping || !feat_sum || !times) return fail(SGS_EINVAL, "null argument");
+	if ((C & 3) == 0 && ((((uintptr_t)features_hwc) | ((uintptr_t)feat_sum)) & 15u))
+		return fail(SGS_EINVAL, "features and sums must be 16-byte aligned");
+	hipError_t e = sgs::launch_fusion_accumulate((hipStream_t)stream, N, C, features_hwc, image_w, mapping,
+						     feat_sum, times);
+	if (e != hipSuccess) return fail_hip(e, "fusion accumulate");
+	return 0;
+}
+
 int sgs_knn_mean_dist2(int P, const float* points, float* meanDists, sgs_alloc_fn scratch,
 		       void* scratch_user, void* stream)
 {

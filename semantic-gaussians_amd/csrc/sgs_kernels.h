@@ -136,4 +136,11 @@ hipError_t launch_knn(hipStream_t st, int P, const float* points, float* out, vo
 // ---- misc
 void launch_debug_expf(hipStream_t st, int n, const float* in, float* out);
 
+// ---- fusion_map.hip (dataset/fusion_utils.py:30-78, fusion.py:127-147)
+hipError_t launch_fusion_mapping(hipStream_t st, int N, const float* coords, const float* wvt,
+				 const double intr[4], int W, int H, int cut, double vis_thres, int depth_mode,
+				 const float* depth, double* zbuf, long long* mapping, double* weight);
+hipError_t launch_fusion_accumulate(hipStream_t st, int N, int C, const float* feat_hwc, int W,
+				    const long long* mapping, float* feat_sum, float* times);
+
 } // namespace sgs
