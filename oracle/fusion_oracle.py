@@ -1,5 +1,5 @@
 """CPU oracle of the 2-D -> 3-D fusion step.  TEST INFRASTRUCTURE ONLY: nothing in the
-product path imports this file (tests/, __graft_entry__.smoke() and tools/bench_*'s CPU leg may).
+product path imports this file.
 
 Restates, in float64 numpy,
   * PointCloudToImageMapper.__init__ / compute_mapping   (dataset/fusion_utils.py:16-78)

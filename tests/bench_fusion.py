@@ -1,4 +1,4 @@
-"""N3 measurement: one view of the fusion step at fusion_scannet.yaml's image size (648x484), 1M Gaussian
+"""N3 measurement (lives under tests/ because its host leg uses the oracle): one view of the fusion step at fusion_scannet.yaml's image size (648x484), 1M Gaussian
 centres, a 512-channel 2-D feature map, occlusion test against a rendered depth map.
 
   device : sgs_hip.fusion (mapping kernel + accumulate kernel; (C,H,W) -> (H,W,C) transpose included)
@@ -7,10 +7,10 @@ centres, a 512-channel 2-D feature map, occlusion test against a rendered depth 
            features[:, y, x], (N, C) block copied back, masked += on the device."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "semantic-gaussians_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "semantic-gaussians_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-import fusion_oracle as fo
+from oracle import fusion_oracle as fo
 from sgs_hip.fusion import PointCloudToImageMapper, accumulate_features
 
 dev = "cuda:0"

@@ -13,8 +13,9 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import fusion_oracle as fo  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from oracle import fusion_oracle as fo  # noqa: E402
 
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "fusion_mapping.npz"))
 CASES = ("nodepth", "depthmap", "depthmap_tight", "surface")
