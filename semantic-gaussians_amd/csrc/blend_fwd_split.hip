@@ -42,6 +42,12 @@ struct StagedEntryW {   // 40 B per list entry in LDS
 	uint32_t pad;
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL
+// store (s_waitcnt vmcnt(0)): in the weights kernel that parks all four waves on the HBM round trip of the
+// weight rows written a moment earlier, three times per batch.  The barriers between the phases of a batch
+// only hand LDS data from wave to wave.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int WB = 16;    // list entries per batch
 constexpr int ACH = 128;  // work-list slots per chunk
 constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the closing T * bg pseudo entry
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	for (int base = 0; base < n_total; base += WB) {
 		const bool wave_alive = __ballot(!done) != 0ull;
 		if (lane == 0) s_alive[wave] = wave_alive ? 1 : 0;
-		__syncthreads();   // also: previous batch's copy-out has finished reading LDS
+		lds_barrier();   // also: previous batch's copy-out has finished reading LDS
 		const int alive = s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3];
 		if (!alive) break;
 		const int n = (n_total - base) < WB ? (n_total - base) : WB;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			if (threadIdx.x == 0) s_nkeep = nk;
 		}
 		if (threadIdx.x == 0) s_amask = 0u;
-		__syncthreads();
+		lds_barrier();
 		const int nkeep = s_nkeep;   // entries of this batch some pixel of the tile might take
 		// ---- weight phase: wave w evaluates strip w for the whole batch.  The quadratic form of
 		// four entries is evaluated together (independent, ILP); an entry then runs the exp /
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		} else {
 			for (int j = 0; j < nkeep; j++) s_wt[j * 256 + wave * 64 + lane] = 0.0f;
 		}
-		__syncthreads();
+		lds_barrier();
 		// ---- compaction into the tile's contiguous chunks.  Every thread derives the same counts from
 		// the activity mask; only when the batch crosses into a new 128-slot chunk (about once per tile)
 		// does thread 0 reserve it and a barrier publish the chunk start.
