@@ -180,3 +180,41 @@ def test_cfg3_backward_worklist_path_matches_chunk_kernel(cfg3):
     half = grads(0, 0.5 * dL)   # exact scaling by a power of two survives every fp32 rounding except the atomics' order
     for a, b in zip(new, half):
         assert float((a - 2.0 * b).abs().max()) <= 1e-4 * float(a.abs().max())
+
+
+def test_cfg3_pipelined_views_match_serial(cfg3):
+    """Four views of the headline scene in flight on four HIP streams (what bench.py times) against the same
+    views rendered alone: num_rendered, radii and the whole C = 512 feature map, bit for bit, 10 rounds."""
+    import math
+    from sgs_hip import raster, dist as sdist
+    from sgs_hip.camera import make_camera, focal2fov
+    from sgs_hip.synthetic import CONFIGS
+    scene, _, (P, C, W, H) = cfg3
+    s = scene.to(DEV)
+    fx = CONFIGS["cfg3"][4]
+    cams = []
+    for i in range(4):   # bench.py's view_camera: slightly yawed / shifted views of the same slab
+        a = 0.04 * i
+        R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+        cams.append(make_camera(R, np.array([0.02 * i, -0.01 * i, 0.0]), focal2fov(fx, W), focal2fov(fx, H), W, H).to(DEV))
+    pool = raster.ScratchPool()
+    e = torch.Tensor([])
+
+    def render(c, slot):
+        out = raster.rasterize_forward(s.bg[:C], s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e,
+                                       c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, e, 0,
+                                       c.camera_center, False, False, C, False, pool=pool)
+        return out[0], out[1].clone(), out[2].clone()
+
+    serial = []
+    for c in cams:
+        serial.append(render(c, 0))
+        torch.cuda.synchronize()
+    assert len({n for n, _, _ in serial}) > 1          # the views differ
+    for _ in range(10):
+        piped = sdist.render_views_pipelined(render, cams, in_flight=4)
+        for i, ((n0, c0, r0), (n1, c1, r1)) in enumerate(zip(serial, piped)):
+            assert n0 == n1, (i, n0, n1)
+            assert torch.equal(r0, r1), (i, "radii")
+            assert torch.equal(c0, c1), (i, "color")
+        del piped
