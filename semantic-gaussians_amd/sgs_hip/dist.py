@@ -56,6 +56,9 @@ def render_views_sharded(render_fn, views, gather_to=0):
     return [merged[i] for i in range(len(views))]
 
 
+_SIDE_STREAMS = {}
+
+
 def render_views_pipelined(render_fn, views, in_flight=2, device=None):
     """Render `views` on one GPU keeping `in_flight` of them in flight, one per HIP stream, from the
     calling thread: while one view waits for its num_rendered read-back and runs its small binning
@@ -68,7 +71,12 @@ def render_views_pipelined(render_fn, views, in_flight=2, device=None):
         return [render_fn(v, 0) for v in views]
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     n = max(1, min(in_flight, len(views)))
-    streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(n - 1)]
+    # the side streams are created once per device and reused: scratch pools are keyed by stream, so fresh
+    # streams on every call would leave a fresh set of state buffers behind each time
+    side = _SIDE_STREAMS.setdefault(device, [])
+    while len(side) < n - 1:
+        side.append(torch.cuda.Stream(device))
+    streams = [torch.cuda.current_stream(device)] + side[:n - 1]
     for st in streams[1:]:
         st.wait_stream(streams[0])   # inputs produced on the caller's stream are visible to the others
     out = []
