@@ -524,6 +524,25 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	return (int)L;
 }
 
+// The stream-ordered allocator returns unused memory to the driver at every synchronisation unless told
+// otherwise -- and every forward synchronises once (num_rendered).  Keep the default pool's memory resident so
+// that the backward's scratch is a pool hit, not a driver allocation, from the second iteration on.
+static void keep_async_pool_resident()
+{
+	static std::atomic<uint64_t> done_mask{0};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+	const uint64_t bit = 1ull << dev;
+	if (done_mask.load() & bit) return;
+	hipMemPool_t pool = nullptr;
+	if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+		uint64_t threshold = ~0ull;
+		(void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+	}
+	(void)hipGetLastError();
+	done_mask.fetch_or(bit);
+}
+
 int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, int width,
 			   int height, const float* means3D, const float* shs,
 			   const float* colors_precomp, const float* scales, float scale_modifier,
@@ -592,6 +611,7 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 			sgs::SplitArena lay;
 			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay);
 			void* scratch = nullptr;
+			keep_async_pool_resident();
 			if (hipMallocAsync(&scratch, bytes + 128, st) == hipSuccess && scratch) {
 				e = sgs::launch_blend_backward_mfma(st, a, align_ptr((char*)scratch), lay);
 				const hipError_t e2 = hipFreeAsync(scratch, st);
