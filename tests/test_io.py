@@ -86,3 +86,17 @@ def test_fusion_pt_round_trip(tmp_path):
     assert d["feat"].shape == (int(mask.sum()), 16) and torch.equal(d["mask_full"], mask)
     back, m2 = sio.load_fusion_features(p2)
     assert torch.equal(m2, mask) and torch.equal(back[mask], feat[mask].half().float()) and float(back[~mask].abs().sum()) == 0
+
+
+def test_ascii_ply_is_read_too(tmp_path):
+    m = _model(P=3, deg=0)
+    names = sio.gaussian_attribute_names(3, 0)
+    rows = torch.cat([m["xyz"], torch.zeros(3, 3), m["features_dc"][:, 0, :], m["opacity"], m["scaling"], m["rotation"]], dim=1)
+    path = str(tmp_path / "ascii.ply")
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 3\n" + "".join(f"property float {n}\n" for n in names) + "end_header\n")
+        for r in rows.tolist():
+            f.write(" ".join(repr(float(v)) for v in r) + "\n")
+    back = sio.read_gaussian_ply(path, max_sh_degree=0)
+    for k in ("xyz", "features_dc", "opacity", "scaling", "rotation"):
+        assert torch.equal(back[k], m[k]), k
