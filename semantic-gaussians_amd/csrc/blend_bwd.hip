@@ -192,228 +192,4 @@ hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const ui
 	return hipGetLastError();
 }
 
-// -------------------------------------------------------------------------------------
-// Per-Gaussian backward: conic -> cov2D -> cov3D & mean; mean2D -> mean3D; SH; scale/rot.
-__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
-	int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
-	const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
-	const float* __restrict__ scales, const float* __restrict__ rotations, float mod,
-	const float* __restrict__ cov3Ds, const float* __restrict__ view,
-	const float* __restrict__ proj, float fx, float fy, float tanx, float tany,
-	const float* __restrict__ campos, const float* __restrict__ dL_dmean2D,
-	const float* __restrict__ dL_dconic, float* __restrict__ dL_dmeans,
-	const float* __restrict__ dL_dcolor, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-	float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
-{
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= P || !(radii[i] > 0)) return;
-	const float mx = means3D[3 * (size_t)i], my = means3D[3 * (size_t)i + 1],
-		    mz = means3D[3 * (size_t)i + 2];
-	float cov3D[6];
-#pragma unroll
-	for (int k = 0; k < 6; k++) cov3D[k] = cov3Ds[6 * (size_t)i + k];
-
-	float dmean[3];
-	float dcov[6];
-	// ---- computeCov2DCUDA (backward.cu:141-271)
-	{
-		const float dcx = dL_dconic[4 * (size_t)i], dcy = dL_dconic[4 * (size_t)i + 1],
-			    dcz = dL_dconic[4 * (size_t)i + 3];
-		const Cov2D c2 = cov2d_parts(mx, my, mz, fx, fy, tanx, tany, cov3D, view);
-		const float limx = 1.3f * tanx, limy = 1.3f * tany;
-		const float x_grad_mul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f;
-		const float y_grad_mul = (c2.tytz < -limy || c2.tytz > limy) ? 0.f : 1.f;
-		const float a = c2.a, b = c2.b, c = c2.c;
-		const float denom = a * c - b * b;
-		float dL_da = 0, dL_db = 0, dL_dc = 0;
-		const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-		const float(*T)[3] = c2.T;
-		if (denom2inv != 0) {
-			dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
-			dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
-			dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
-			dcov[0] = (T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc);
-			dcov[3] = (T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc);
-			dcov[5] = (T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc);
-			dcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][1] * dL_dc;
-			dcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][2] * dL_dc;
-			dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
-		} else {
-#pragma unroll
-			for (int k = 0; k < 6; k++) dcov[k] = 0;
-		}
-#pragma unroll
-		for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
-		const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]},
-				       {cov3D[1], cov3D[3], cov3D[4]},
-				       {cov3D[2], cov3D[4], cov3D[5]}};
-		float dT[2][3];
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			dT[0][k] = 2 * (T[0][0] * V[k][0] + T[0][1] * V[k][1] + T[0][2] * V[k][2]) * dL_da +
-				   (T[1][0] * V[k][0] + T[1][1] * V[k][1] + T[1][2] * V[k][2]) * dL_db;
-			dT[1][k] = 2 * (T[1][0] * V[k][0] + T[1][1] * V[k][1] + T[1][2] * V[k][2]) * dL_dc +
-				   (T[0][0] * V[k][0] + T[0][1] * V[k][1] + T[0][2] * V[k][2]) * dL_db;
-		}
-#define SGS_WG(i_, j_) view[4 * (j_) + (i_)]   // glm W[i][j]: column i, row j
-		const float dJ00 = SGS_WG(0, 0) * dT[0][0] + SGS_WG(0, 1) * dT[0][1] + SGS_WG(0, 2) * dT[0][2];
-		const float dJ02 = SGS_WG(2, 0) * dT[0][0] + SGS_WG(2, 1) * dT[0][1] + SGS_WG(2, 2) * dT[0][2];
-		const float dJ11 = SGS_WG(1, 0) * dT[1][0] + SGS_WG(1, 1) * dT[1][1] + SGS_WG(1, 2) * dT[1][2];
-		const float dJ12 = SGS_WG(2, 0) * dT[1][0] + SGS_WG(2, 1) * dT[1][1] + SGS_WG(2, 2) * dT[1][2];
-#undef SGS_WG
-		const float tz = 1.f / c2.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-		const float dtx = x_grad_mul * -fx * tz2 * dJ02;
-		const float dty = y_grad_mul * -fy * tz2 * dJ12;
-		const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * c2.t[0]) * tz3 * dJ02 +
-				  (2 * fy * c2.t[1]) * tz3 * dJ12;
-		dmean[0] = view[0] * dtx + view[1] * dty + view[2] * dtz;
-		dmean[1] = view[4] * dtx + view[5] * dty + view[6] * dtz;
-		dmean[2] = view[8] * dtx + view[9] * dty + view[10] * dtz;
-	}
-	// ---- preprocessCUDA backward (backward.cu:365-382)
-	{
-		const f4 mh = xf4x4(proj, mx, my, mz);
-		const float m_w = 1.0f / (mh.w + 0.0000001f);
-		const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
-		const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-		const float gx_ = dL_dmean2D[3 * (size_t)i], gy_ = dL_dmean2D[3 * (size_t)i + 1];
-		dmean[0] += (proj[0] * m_w - proj[3] * mul1) * gx_ + (proj[1] * m_w - proj[3] * mul2) * gy_;
-		dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gx_ + (proj[5] * m_w - proj[7] * mul2) * gy_;
-		dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gx_ + (proj[9] * m_w - proj[11] * mul2) * gy_;
-	}
-	if (shs) {
-		// ---- computeColorFromSH backward (backward.cu:20-136)
-		const float* __restrict__ sh = shs + (size_t)i * M * 3;
-		float* __restrict__ dsh = dL_dsh + (size_t)i * M * 3;
-		const float dox = mx - campos[0], doy = my - campos[1], doz = mz - campos[2];
-		const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-		const float x = dox / len, y = doy / len, z = doz / len;
-		float dRGB[3];
-#pragma unroll
-		for (int c = 0; c < 3; c++)
-			dRGB[c] = dL_dcolor[3 * (size_t)i + c] * (clamped[3 * (size_t)i + c] ? 0.f : 1.f);
-		float dRdx[3] = {0, 0, 0}, dRdy[3] = {0, 0, 0}, dRdz[3] = {0, 0, 0};
-#define SGS_S(k, c) sh[3 * (k) + (c)]
-#define SGS_DS(k, v)                                       \
-	{                                                  \
-		const float v_ = (v);                      \
-		for (int c = 0; c < 3; c++) dsh[3 * (k) + c] = v_ * dRGB[c]; \
-	}
-		SGS_DS(0, SH_C0);
-		if (D > 0) {
-			SGS_DS(1, -SH_C1 * y);
-			SGS_DS(2, SH_C1 * z);
-			SGS_DS(3, -SH_C1 * x);
-#pragma unroll
-			for (int c = 0; c < 3; c++) {
-				dRdx[c] = -SH_C1 * SGS_S(3, c);
-				dRdy[c] = -SH_C1 * SGS_S(1, c);
-				dRdz[c] = SH_C1 * SGS_S(2, c);
-			}
-			if (D > 1) {
-				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-				SGS_DS(4, SH_C2[0] * xy);
-				SGS_DS(5, SH_C2[1] * yz);
-				SGS_DS(6, SH_C2[2] * (2.f * zz - xx - yy));
-				SGS_DS(7, SH_C2[3] * xz);
-				SGS_DS(8, SH_C2[4] * (xx - yy));
-#pragma unroll
-				for (int c = 0; c < 3; c++) {
-					dRdx[c] += SH_C2[0] * y * SGS_S(4, c) + SH_C2[2] * 2.f * -x * SGS_S(6, c) + SH_C2[3] * z * SGS_S(7, c) + SH_C2[4] * 2.f * x * SGS_S(8, c);
-					dRdy[c] += SH_C2[0] * x * SGS_S(4, c) + SH_C2[1] * z * SGS_S(5, c) + SH_C2[2] * 2.f * -y * SGS_S(6, c) + SH_C2[4] * 2.f * -y * SGS_S(8, c);
-					dRdz[c] += SH_C2[1] * y * SGS_S(5, c) + SH_C2[2] * 2.f * 2.f * z * SGS_S(6, c) + SH_C2[3] * x * SGS_S(7, c);
-				}
-				if (D > 2) {
-					SGS_DS(9, SH_C3[0] * y * (3.f * xx - yy));
-					SGS_DS(10, SH_C3[1] * xy * z);
-					SGS_DS(11, SH_C3[2] * y * (4.f * zz - xx - yy));
-					SGS_DS(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-					SGS_DS(13, SH_C3[4] * x * (4.f * zz - xx - yy));
-					SGS_DS(14, SH_C3[5] * z * (xx - yy));
-					SGS_DS(15, SH_C3[6] * x * (xx - 3.f * yy));
-#pragma unroll
-					for (int c = 0; c < 3; c++) {
-						dRdx[c] += (SH_C3[0] * SGS_S(9, c) * 3.f * 2.f * xy + SH_C3[1] * SGS_S(10, c) * yz +
-							    SH_C3[2] * SGS_S(11, c) * -2.f * xy + SH_C3[3] * SGS_S(12, c) * -3.f * 2.f * xz +
-							    SH_C3[4] * SGS_S(13, c) * (-3.f * xx + 4.f * zz - yy) +
-							    SH_C3[5] * SGS_S(14, c) * 2.f * xz + SH_C3[6] * SGS_S(15, c) * 3.f * (xx - yy));
-						dRdy[c] += (SH_C3[0] * SGS_S(9, c) * 3.f * (xx - yy) + SH_C3[1] * SGS_S(10, c) * xz +
-							    SH_C3[2] * SGS_S(11, c) * (-3.f * yy + 4.f * zz - xx) +
-							    SH_C3[3] * SGS_S(12, c) * -3.f * 2.f * yz + SH_C3[4] * SGS_S(13, c) * -2.f * xy +
-							    SH_C3[5] * SGS_S(14, c) * -2.f * yz + SH_C3[6] * SGS_S(15, c) * -3.f * 2.f * xy);
-						dRdz[c] += (SH_C3[1] * SGS_S(10, c) * xy + SH_C3[2] * SGS_S(11, c) * 4.f * 2.f * yz +
-							    SH_C3[3] * SGS_S(12, c) * 3.f * (2.f * zz - xx - yy) +
-							    SH_C3[4] * SGS_S(13, c) * 4.f * 2.f * xz + SH_C3[5] * SGS_S(14, c) * (xx - yy));
-					}
-				}
-			}
-		}
-#undef SGS_S
-#undef SGS_DS
-		const float ddx = dRdx[0] * dRGB[0] + dRdx[1] * dRGB[1] + dRdx[2] * dRGB[2];
-		const float ddy = dRdy[0] * dRGB[0] + dRdy[1] * dRGB[1] + dRdy[2] * dRGB[2];
-		const float ddz = dRdz[0] * dRGB[0] + dRdz[1] * dRGB[1] + dRdz[2] * dRGB[2];
-		// dnormvdv (auxiliary.h:107-117)
-		const float sum2 = dox * dox + doy * doy + doz * doz;
-		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-		dmean[0] += ((+sum2 - dox * dox) * ddx - doy * dox * ddy - doz * dox * ddz) * invsum32;
-		dmean[1] += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
-		dmean[2] += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
-	}
-#pragma unroll
-	for (int k = 0; k < 3; k++) dL_dmeans[3 * (size_t)i + k] = dmean[k];
-
-	if (scales) {
-		// ---- computeCov3D backward (backward.cu:275-336)
-		const float qr = rotations[4 * (size_t)i], qx = rotations[4 * (size_t)i + 1],
-			    qy = rotations[4 * (size_t)i + 2], qz = rotations[4 * (size_t)i + 3];
-		float R[3][3];
-		rot_matrix(qr, qx, qy, qz, R);
-		const float s[3] = {mod * scales[3 * (size_t)i], mod * scales[3 * (size_t)i + 1],
-				    mod * scales[3 * (size_t)i + 2]};
-		float Mm[3][3];
-#pragma unroll
-		for (int r = 0; r < 3; r++)
-#pragma unroll
-			for (int c = 0; c < 3; c++) Mm[r][c] = s[r] * R[c][r];
-		const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
-					{0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
-					{0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-		float dM[3][3];
-#pragma unroll
-		for (int r = 0; r < 3; r++)
-#pragma unroll
-			for (int c = 0; c < 3; c++)
-				dM[r][c] = (2.0f * Mm[r][0]) * dS[0][c] + (2.0f * Mm[r][1]) * dS[1][c] + (2.0f * Mm[r][2]) * dS[2][c];
-#pragma unroll
-		for (int k = 0; k < 3; k++)
-			dL_dscale[3 * (size_t)i + k] = R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2];
-		float dMt[3][3];
-#pragma unroll
-		for (int a = 0; a < 3; a++)
-#pragma unroll
-			for (int b = 0; b < 3; b++) dMt[a][b] = dM[a][b] * s[a];
-		const float r = qr, x = qx, y = qy, z = qz;
-		dL_drot[4 * (size_t)i + 0] = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
-		dL_drot[4 * (size_t)i + 1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
-		dL_drot[4 * (size_t)i + 2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
-		dL_drot[4 * (size_t)i + 3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
-	}
-}
-
-void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
-			   const int* radii, const float* shs, const uint8_t* clamped,
-			   const float* scales, const float* rotations, float mod,
-			   const float* cov3Ds, const float* view, const float* proj, float fx,
-			   float fy, float tanx, float tany, const float* campos,
-			   const float* dL_dmean2D, const float* dL_dconic, float* dL_dmeans,
-			   const float* dL_dcolor, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-			   float* dL_drot)
-{
-	hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, D, M,
-			   means3D, radii, shs, clamped, scales, rotations, mod, cov3Ds, view, proj, fx,
-			   fy, tanx, tany, campos, dL_dmean2D, dL_dconic, dL_dmeans, dL_dcolor, dL_dcov3D,
-			   dL_dsh, dL_dscale, dL_drot);
-}
-
 } // namespace sgs
