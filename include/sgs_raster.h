@@ -51,8 +51,11 @@ const char *sgs_last_error(void);
  * Replaces CudaRasterizer::Rasterizer::forward
  *   (CR/cuda_rasterizer/rasterizer_impl.cu:198-341, declared rasterizer.h:30-53;
  *    RR/cuda_rasterizer/rasterizer_impl.cu:198-339 when out_depth != NULL).
- * Pipeline: preprocess -> inclusive scan -> (4-byte D2H) -> duplicateWithKeys ->
- * stable 64-bit radix sort on bits [0, 32+msb(tiles)) -> tile ranges -> blend.
+ * Pipeline (default, binning mode 0): preprocess -> depth presort of the P Gaussians -> span counts + 64-bit
+ * scan -> (8-byte D2H: row instances | num_rendered) -> two span partitions that write every tile's
+ * depth-ordered list and `ranges` with no sort of the tile instances -> blend.  Binning mode 1 keeps the
+ * reference's order of operations (inclusive scan -> 4-byte D2H -> duplicateWithKeys -> stable 64-bit radix sort
+ * on bits [0, 32+msb(tiles)) -> tile ranges); lists, ranges and (reconstructed) keys are bit-identical in all modes.
  *   P,D,M          #Gaussians, active SH degree, SH coeffs per Gaussian (0 if no shs)
  *   background     (C) floats
  *   means3D (P,3) shs (P,M,3)|NULL colors_precomp (P,C)|NULL opacities (P)
@@ -201,7 +204,30 @@ int sgs_debug_sorted_keys(int P, int num_rendered, int width, int height,
  * (DESIGN.md "exp contract"): out[i] = sgs_expf(in[i]). */
 int sgs_debug_expf(int n, const float *in, float *out, void *stream);
 
-/* Tuning / measurement hooks (not part of the reference's interface). */
+/* Tuning / measurement hooks (not part of the reference's interface).
+ *
+ * State model.  The library keeps NO process-global mutable state on the data path: the adaptive work-list
+ * capacities, their pinned feedback words and the counters below live in a context keyed by (device, stream),
+ * created on first use and freed by sgs_stream_release().  The sgs_set_* functions set process-wide DEFAULTS of
+ * the tuning options; sgs_stream_set_option() overrides one option for one stream, so two callers in one
+ * process (different streams or devices) can run different arithmetic / binning / backward modes concurrently. */
+#define SGS_OPT_BLEND_VARIANT 0
+#define SGS_OPT_BINNING_MODE 1
+#define SGS_OPT_BACKWARD_MODE 2
+#define SGS_OPT_STAGE_TIMING 3
+#define SGS_OPT_COUNT 4
+/* value < 0 removes the override (the stream follows the process default again).  Returns the previous override,
+ * or 0x7fffffff if there was none. */
+int sgs_stream_set_option(void *stream, int option, int value);
+#define SGS_STAT_ARENA_SLOTS 0     /* current work-list capacity of the split forward (slots of 1 KB) */
+#define SGS_STAT_FWD_OVERFLOWS 1   /* split forwards whose work list overflowed (frame rendered by the gated fallback) */
+#define SGS_STAT_BWD_OVERFLOWS 2   /* work-list backwards that overflowed (gradients by the per-chunk fallback) */
+#define SGS_STAT_FORWARDS 3        /* forwards issued on this stream */
+#define SGS_STAT_COUNT 4
+int sgs_stream_get_stat(void *stream, int stat, uint64_t *out);
+/* Frees the context of (current device, stream); returns 1 if there was one. */
+int sgs_stream_release(void *stream);
+
 /* Selects the forward blend kernels (tuning / A-B measurements).
  *   0 (default) = for num_channels >= 128: weights pre-pass + row-sweep split-bf16 MFMA accumulate for the
  *                 128-channel-aligned part (feature map within 5e-5 of the absolute composite, every

@@ -16,6 +16,8 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,11 +25,104 @@
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_blend_variant{0};
-std::atomic<int> g_stage_timing{0};
-std::atomic<int> g_backward_mode{0};   // 0 = work-list MFMA backward where eligible, 1 = per-chunk VALU kernel only
-std::atomic<int> g_binning_mode{0};   // 0 = depth-presorted emission (default), 1 = reference order
-float g_stage_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+// Process-wide DEFAULTS of the tuning options (sgs_set_*): what a stream gets when it has no override of its
+// own.  Every other piece of mutable state lives in a StreamCtx (below).
+std::atomic<int> g_default_opt[SGS_OPT_COUNT] = {};
+float g_stage_ms[7] = {0, 0, 0, 0, 0, 0, 0};   // last resolved stage times (guarded by g_ev_mu)
+
+// State of one (device, stream): option overrides, the adaptive work-list capacity of the split blend with its
+// pinned feedback words, the backward's own capacity feedback, counters.  A forward / backward only ever touches
+// the context of the stream it was called with, so concurrent callers on different streams (or devices) share
+// nothing; two calls on the SAME stream from different host threads are serialised by the context's mutex.
+struct StreamCtx {
+	std::mutex mu;
+	int opt[SGS_OPT_COUNT];
+	// forward (split blend work list)
+	uint32_t arena_hint = 0;
+	uint32_t* usage_host = nullptr;   // pinned {slots requested, overflow flag} of this stream's last split forward
+	hipEvent_t usage_ev = nullptr;    // recorded behind the copy into usage_host
+	bool usage_pending = false;
+	// backward (work-list MFMA path)
+	uint32_t bwd_hint = 0;
+	uint32_t* bwd_usage_host = nullptr;
+	hipEvent_t bwd_ev = nullptr;
+	bool bwd_pending = false;
+	uint64_t stat[SGS_STAT_COUNT];
+	StreamCtx()
+	{
+		for (int& o : opt) o = -1;
+		for (uint64_t& v : stat) v = 0;
+	}
+	~StreamCtx()
+	{
+		if (usage_host) (void)hipHostFree(usage_host);
+		if (bwd_usage_host) (void)hipHostFree(bwd_usage_host);
+		if (usage_ev) (void)hipEventDestroy(usage_ev);
+		if (bwd_ev) (void)hipEventDestroy(bwd_ev);
+	}
+	int option(int which) const { return opt[which] >= 0 ? opt[which] : g_default_opt[which].load(); }
+	// pinned word pair + event, created on first use (under `mu`)
+	bool ensure(uint32_t*& words, hipEvent_t& ev)
+	{
+		if (!words) {
+			if (hipHostMalloc((void**)&words, 8, hipHostMallocDefault) != hipSuccess) {
+				words = nullptr;
+				(void)hipGetLastError();
+				return false;
+			}
+			words[0] = words[1] = 0;
+		}
+		if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+			ev = nullptr;
+			(void)hipGetLastError();
+			return false;
+		}
+		return true;
+	}
+};
+
+std::mutex g_ctx_mu;
+std::map<std::pair<int, void*>, std::unique_ptr<StreamCtx>> g_ctx;
+
+StreamCtx* ctx_of(void* stream)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+	std::lock_guard<std::mutex> lk(g_ctx_mu);
+	auto& slot = g_ctx[std::make_pair(dev, stream)];
+	if (!slot) slot.reset(new StreamCtx());
+	return slot.get();
+}
+
+// The backward's work-list scratch: a PRIVATE stream-ordered pool per device.  The default pool is left alone
+// (other libraries in the host process use it); this one keeps up to 4 GiB resident across synchronisations so
+// that the scratch of iteration n + 1 is a pool hit instead of a driver allocation.
+std::mutex g_pool_mu;
+std::map<int, hipMemPool_t> g_pool;
+hipMemPool_t scratch_pool()
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+	std::lock_guard<std::mutex> lk(g_pool_mu);
+	auto it = g_pool.find(dev);
+	if (it != g_pool.end()) return it->second;
+	hipMemPoolProps props;
+	memset(&props, 0, sizeof(props));
+	props.allocType = hipMemAllocationTypePinned;
+	props.handleTypes = hipMemHandleTypeNone;
+	props.location.type = hipMemLocationTypeDevice;
+	props.location.id = dev;
+	hipMemPool_t pool = nullptr;
+	if (hipMemPoolCreate(&pool, &props) != hipSuccess) {
+		(void)hipGetLastError();
+		pool = nullptr;
+	} else {
+		uint64_t threshold = 4ull << 30;
+		(void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+	}
+	g_pool[dev] = pool;
+	return pool;
+}
 
 int fail(int code, const std::string& msg)
 {
@@ -105,10 +200,6 @@ struct BinLayout {
 	size_t rowtab, cmat, gtot, tilelen;
 };
 
-// Work-list capacity of the split blend (slots of 1 KB): adaptive, grown after an overflow.
-std::atomic<uint32_t> g_arena_hint{0};
-uint32_t* g_usage_host = nullptr;   // pinned: {slots used, overflow flag} of the last split forward
-
 BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int ntiles = 0, uint32_t R = 0,
 		     int gx = 0, int gy = 0, int P = 0)
 {
@@ -181,7 +272,7 @@ struct EventSet {
 	hipEvent_t ev[8];
 	int n;
 };
-std::mutex g_ev_mu;
+std::mutex g_ev_mu, g_ms_mu;
 std::vector<EventSet> g_parked;
 
 struct StageTimer {
@@ -214,6 +305,7 @@ struct StageTimer {
 			std::lock_guard<std::mutex> lk(g_ev_mu);
 			g_parked.push_back(es);
 		} else {
+			std::lock_guard<std::mutex> lk(g_ms_mu);
 			resolve(es, g_stage_ms);
 		}
 		mode = 0;
@@ -239,10 +331,38 @@ extern "C" {
 int sgs_abi_version(void) { return SGS_ABI_VERSION; }
 const char* sgs_last_error(void) { return g_err.c_str(); }
 
-int sgs_set_blend_variant(int variant) { return g_blend_variant.exchange(variant); }
-int sgs_set_stage_timing(int enable) { return g_stage_timing.exchange(enable); }
-int sgs_set_binning_mode(int mode) { return g_binning_mode.exchange(mode); }
-int sgs_set_backward_mode(int mode) { return g_backward_mode.exchange(mode); }
+int sgs_set_blend_variant(int variant) { return g_default_opt[SGS_OPT_BLEND_VARIANT].exchange(variant); }
+int sgs_set_stage_timing(int enable) { return g_default_opt[SGS_OPT_STAGE_TIMING].exchange(enable); }
+int sgs_set_binning_mode(int mode) { return g_default_opt[SGS_OPT_BINNING_MODE].exchange(mode); }
+int sgs_set_backward_mode(int mode) { return g_default_opt[SGS_OPT_BACKWARD_MODE].exchange(mode); }
+
+int sgs_stream_set_option(void* stream, int option, int value)
+{
+	if (option < 0 || option >= SGS_OPT_COUNT) return fail(SGS_EINVAL, "unknown option");
+	StreamCtx* c = ctx_of(stream);
+	std::lock_guard<std::mutex> lk(c->mu);
+	const int prev = c->opt[option];
+	c->opt[option] = value < 0 ? -1 : value;
+	return prev < 0 ? 0x7fffffff : prev;   // (0x7fffffff: there was no override)
+}
+
+int sgs_stream_get_stat(void* stream, int stat, uint64_t* out)
+{
+	if (stat < 0 || stat >= SGS_STAT_COUNT || !out) return fail(SGS_EINVAL, "unknown statistic");
+	StreamCtx* c = ctx_of(stream);
+	std::lock_guard<std::mutex> lk(c->mu);
+	*out = c->stat[stat];
+	return 0;
+}
+
+int sgs_stream_release(void* stream)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+	std::lock_guard<std::mutex> lk(g_ctx_mu);
+	return (int)g_ctx.erase(std::make_pair(dev, stream));
+}
+
 int sgs_get_stage_ms(float* ms7)
 {
 	std::vector<EventSet> parked;
@@ -250,6 +370,7 @@ int sgs_get_stage_ms(float* ms7)
 		std::lock_guard<std::mutex> lk(g_ev_mu);
 		parked.swap(g_parked);
 	}
+	std::lock_guard<std::mutex> lk2(g_ms_mu);
 	if (!parked.empty()) {   // deferred mode: mean over the parked forward calls
 		double acc[7] = {0, 0, 0, 0, 0, 0, 0};
 		for (auto& s : parked) {
@@ -320,7 +441,10 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	const int gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
 	const int ntiles = gx * gy;
 
-	StageTimer tm(g_stage_timing.load(), st);
+	StreamCtx* const cx = ctx_of(stream);
+	std::lock_guard<std::mutex> ctx_lock(cx->mu);
+	cx->stat[SGS_STAT_FORWARDS]++;
+	StageTimer tm(cx->option(SGS_OPT_STAGE_TIMING), st);
 
 	const GeomLayout gl = geom_layout(P);
 	char* gchunk = (char*)geometry_buffer(geometry_user, gl.total);
@@ -356,7 +480,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	tm.mark();
 	// binning mode 0: sort the P Gaussians by depth bits and emit instances in that order, so
 	// that the big instance sort only has to be stable on the tile bits (binning.hip)
-	const int bmode = g_binning_mode.load();
+	const int bmode = cx->option(SGS_OPT_BINNING_MODE);
 	const bool presort = bmode == 0 || bmode == 2;
 	// mode 0: per-tile lists from span partitions (binning_rows.hip); its per-wave bin tables live in LDS,
 	// so absurdly long grid axes (> 32k pixels) take the mode-2 path
@@ -403,25 +527,29 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 
 	const int sort_bits = 32 + (int)higher_msb((uint32_t)ntiles);
 	// split blend (weights pre-pass + streaming accumulate) for the 128-channel-aligned part
-	const int variant = g_blend_variant.load();
+	const int variant = cx->option(SGS_OPT_BLEND_VARIANT);
 	const bool use_split = (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
 	if (use_split) {
-		if (!g_usage_host) {
-			if (hipHostMalloc((void**)&g_usage_host, 8, hipHostMallocDefault) != hipSuccess)
-				g_usage_host = nullptr;
-			else g_usage_host[0] = g_usage_host[1] = 0;
+		// feedback from THIS stream's previous split forward: the copy into the pinned words was enqueued on this
+		// stream before the synchronisation a few lines up, so it has completed (the event says so)
+		uint32_t hint = cx->arena_hint;
+		if (cx->usage_pending && cx->usage_ev && hipEventQuery(cx->usage_ev) == hipSuccess) {
+			const uint32_t used = cx->usage_host[0], ovf = cx->usage_host[1];
+			if (ovf) {
+				hint = used + used / 2;            // `used` counts every request, also the refused ones
+				cx->stat[SGS_STAT_FWD_OVERFLOWS]++;
+			} else if (used) {
+				hint = hint > used + used / 4 ? hint : used + used / 4;
+			}
+			cx->usage_pending = false;
 		}
-		uint32_t hint = g_arena_hint.load();
-		if (g_usage_host) {   // feedback from the previous split forward (complete: we just synced)
-			const uint32_t used = g_usage_host[0], ovf = g_usage_host[1];
-			if (ovf) hint = used + used / 2;            // `used` counts every request, also the refused ones
-			else if (used) hint = hint > used + used / 4 ? hint : used + used / 4;
-		}
+		(void)hipGetLastError();
 		if (hint < (uint32_t)ntiles * 192u) hint = (uint32_t)ntiles * 192u;   // chunks of 128 slots
 		hint = (hint + 0xffffu) & ~0xffffu;   // 64k-slot granularity keeps the buffer size stable
-		g_arena_hint.store(hint);
+		cx->arena_hint = hint;
+		cx->stat[SGS_STAT_ARENA_SLOTS] = hint;
 		// a tile can never need more than its list length rounded up to whole chunks
 		arena_max = (uint64_t)L + 128ull * (uint64_t)ntiles;
 		arena_cap = (uint64_t)hint < arena_max ? hint : (uint32_t)arena_max;
@@ -511,8 +639,11 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 			e = sgs::launch_blend_forward(st, a, 0, counter, 0);
 		if (e == hipSuccess && c_split < num_channels)
 			e = sgs::launch_blend_forward(st, a, 0, nullptr, c_split);
-		if (e == hipSuccess && g_usage_host)
-			e = hipMemcpyAsync(g_usage_host, counter, 8, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess && cx->ensure(cx->usage_host, cx->usage_ev)) {
+			e = hipMemcpyAsync(cx->usage_host, counter, 8, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess) e = hipEventRecord(cx->usage_ev, st);
+			cx->usage_pending = e == hipSuccess;
+		}
 	} else {
 		tm.mark();   // (no weights pre-pass on this path)
 		e = sgs::launch_blend_forward(st, a, variant == 6 ? 0 : variant);   // 6 = px4 without the split
@@ -522,25 +653,6 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	tm.mark();
 	tm.finish();
 	return (int)L;
-}
-
-// The stream-ordered allocator returns unused memory to the driver at every synchronisation unless told
-// otherwise -- and every forward synchronises once (num_rendered).  Keep the default pool's memory resident so
-// that the backward's scratch is a pool hit, not a driver allocation, from the second iteration on.
-static void keep_async_pool_resident()
-{
-	static std::atomic<uint64_t> done_mask{0};
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-	const uint64_t bit = 1ull << dev;
-	if (done_mask.load() & bit) return;
-	hipMemPool_t pool = nullptr;
-	if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-		uint64_t threshold = ~0ull;
-		(void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
-	}
-	(void)hipGetLastError();
-	done_mask.fetch_or(bit);
 }
 
 int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, int width,
@@ -564,6 +676,8 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 		return fail(SGS_EINVAL, "null gradient buffer");
 	if (shs && num_channels != 3) return fail(SGS_EINVAL, "SH colours imply 3 channels");
 
+	StreamCtx* const cx = ctx_of(stream);
+	std::lock_guard<std::mutex> ctx_lock(cx->mu);
 	const int gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
 	const GeomLayout gl = geom_layout(P);
 	const sgs_image_layout il = img_layout(width, height);
@@ -598,22 +712,44 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 	if (R > 0) {
 		hipError_t e = hipSuccess;
 		bool done = false;
-		const int bw_mode = g_backward_mode.load();
+		const int bw_mode = cx->option(SGS_OPT_BACKWARD_MODE);
 		if (bw_mode != 1 && sgs::blend_backward_mfma_eligible(a)) {
-			// the forward's work list again, in stream-ordered scratch sized like the forward's arena
+			// the forward's work list again, in stream-ordered scratch.  Its capacity adapts to what THIS
+			// stream's previous backward used (the forward's hint is only the starting point: below 128
+			// channels the forward never builds a work list).
 			const int ntiles = gx * gy;
-			uint32_t hint = g_arena_hint.load();
+			uint32_t hint = cx->bwd_hint > cx->arena_hint ? cx->bwd_hint : cx->arena_hint;
+			if (cx->bwd_pending && cx->bwd_ev && hipEventQuery(cx->bwd_ev) == hipSuccess) {
+				const uint32_t used = cx->bwd_usage_host[0], ovf = cx->bwd_usage_host[1];
+				if (ovf) {
+					hint = used + used / 2;
+					cx->stat[SGS_STAT_BWD_OVERFLOWS]++;   // that backward ran on the per-chunk fallback
+				} else if (used && hint < used + used / 4) {
+					hint = used + used / 4;
+				}
+				cx->bwd_pending = false;
+			}
+			(void)hipGetLastError();
 			if (hint < (uint32_t)ntiles * 192u) hint = (uint32_t)ntiles * 192u;
 			hint = (hint + 0xffffu) & ~0xffffu;
+			cx->bwd_hint = hint;
 			const uint64_t cap_max = (uint64_t)R + 128ull * (uint64_t)ntiles;
 			uint32_t cap = (uint64_t)hint < cap_max ? hint : (uint32_t)cap_max;
 			if (bw_mode == 2) cap = 128u * (uint32_t)((ntiles + 1) / 2);   // (tests: guaranteed overflow -> gated fallback)
 			sgs::SplitArena lay;
 			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay);
 			void* scratch = nullptr;
-			keep_async_pool_resident();
-			if (hipMallocAsync(&scratch, bytes + 128, st) == hipSuccess && scratch) {
-				e = sgs::launch_blend_backward_mfma(st, a, align_ptr((char*)scratch), lay);
+			hipMemPool_t pool = scratch_pool();
+			hipError_t ea = pool ? hipMallocFromPoolAsync(&scratch, bytes + 128, pool, st)
+					     : hipMallocAsync(&scratch, bytes + 128, st);
+			if (ea == hipSuccess && scratch) {
+				char* arena = align_ptr((char*)scratch);
+				e = sgs::launch_blend_backward_mfma(st, a, arena, lay);
+				if (e == hipSuccess && cx->ensure(cx->bwd_usage_host, cx->bwd_ev)) {
+					if (hipMemcpyAsync(cx->bwd_usage_host, arena + lay.counter, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+					    hipEventRecord(cx->bwd_ev, st) == hipSuccess)
+						cx->bwd_pending = true;
+				}
 				const hipError_t e2 = hipFreeAsync(scratch, st);
 				if (e == hipSuccess) e = e2;
 				done = true;

@@ -38,7 +38,12 @@ EXPORTS = (
     "sgs_mark_visible", "sgs_knn_mean_dist2", "sgs_geometry_layout_of", "sgs_binning_layout_of",
     "sgs_image_layout_of", "sgs_sort_bits", "sgs_debug_expf", "sgs_debug_sorted_keys", "sgs_set_blend_variant",
     "sgs_set_stage_timing", "sgs_get_stage_ms", "sgs_set_binning_mode", "sgs_set_backward_mode", "sgs_fusion_compute_mapping", "sgs_fusion_accumulate",
+    "sgs_stream_set_option", "sgs_stream_get_stat", "sgs_stream_release",
 )
+
+# sgs_stream_set_option / sgs_stream_get_stat selectors (include/sgs_raster.h)
+OPT_BLEND_VARIANT, OPT_BINNING_MODE, OPT_BACKWARD_MODE, OPT_STAGE_TIMING = 0, 1, 2, 3
+STAT_ARENA_SLOTS, STAT_FWD_OVERFLOWS, STAT_BWD_OVERFLOWS, STAT_FORWARDS = 0, 1, 2, 3
 
 _lib = None
 
@@ -108,6 +113,12 @@ def load():
     lib.sgs_fusion_accumulate.argtypes = [i, i, p, i, i, p, p, p, p]
     lib.sgs_get_stage_ms.restype = i
     lib.sgs_get_stage_ms.argtypes = [C.POINTER(C.c_float)]
+    lib.sgs_stream_set_option.restype = i
+    lib.sgs_stream_set_option.argtypes = [p, i, i]
+    lib.sgs_stream_get_stat.restype = i
+    lib.sgs_stream_get_stat.argtypes = [p, i, C.POINTER(C.c_uint64)]
+    lib.sgs_stream_release.restype = i
+    lib.sgs_stream_release.argtypes = [p]
     _lib = lib
     return lib
 

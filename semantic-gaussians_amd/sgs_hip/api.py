@@ -57,8 +57,14 @@ class RgbdRasterizationSettings(NamedTuple):
 
 
 def _snapshot(args, path):
-    host = tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
-    torch.save(host, path)
+    """Input snapshot for a failed call (the reference writes one BEFORE every debug call).  After a real
+    device fault the copies to the host fail too: never let that mask the original exception."""
+    try:
+        host = tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+        torch.save(host, path)
+        return True
+    except Exception:   # noqa: BLE001
+        return False
 
 
 def _make_function(with_depth):
@@ -67,22 +73,23 @@ def _make_function(with_depth):
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                    cov3Ds_precomp, raster_settings):
+                    cov3Ds_precomp, raster_settings, track=True):
             s = raster_settings
             channels = 3 if with_depth else s.num_channels
             call = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier,
                     cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
                     s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
                     s.debug, channels)
-            # nothing to backpropagate (torch.no_grad / no input requires grad): the state buffers
-            # need not outlive the call, keep them in the resident inference pool
-            pool = None if any(ctx.needs_input_grad) else raster.INFERENCE_POOL
+            # nothing to backpropagate (torch.no_grad, or no input requires grad): the state buffers need
+            # not outlive the call, keep them in the resident inference pool.  `track` is decided by the
+            # caller of .apply(): ctx.needs_input_grad mirrors the inputs' requires_grad even under no_grad
+            # (fusion.py / eval_segmentation.py pass nn.Parameters under torch.no_grad()).
+            pool = None if track else raster.INFERENCE_POOL
             try:
                 (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer,
                  depth) = raster.rasterize_forward(*call, want_depth=with_depth, pool=pool)
             except Exception:
-                if s.debug:
-                    _snapshot(call, "snapshot_fw.dump")
+                if s.debug and _snapshot(call, "snapshot_fw.dump"):
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
             ctx.raster_settings = s
@@ -109,13 +116,12 @@ def _make_function(with_depth):
                  grad_cov3Ds_precomp, grad_sh, grad_scales,
                  grad_rotations) = raster.rasterize_backward(*call)
             except Exception:
-                if s.debug:
-                    _snapshot(call, "snapshot_bw.dump")
+                if s.debug and _snapshot(call, "snapshot_bw.dump"):
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
             # one gradient per forward input, in input order; None for the settings
             return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities,
-                    grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
+                    grad_scales, grad_rotations, grad_cov3Ds_precomp, None, None)
 
     return _RasterizeGaussians
 
@@ -124,16 +130,24 @@ _ChnFunction = _make_function(with_depth=False)
 _RgbdFunction = _make_function(with_depth=True)
 
 
+def _tracks_grad(*tensors):
+    """Will autograd record this call?  (Decided before .apply(): inside forward() grad mode is off.)"""
+    return torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
 def rasterize_gaussians_chn(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                             cov3Ds_precomp, raster_settings):
+    track = _tracks_grad(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     return _ChnFunction.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                              cov3Ds_precomp, raster_settings)
+                              cov3Ds_precomp, raster_settings, track)
 
 
 def rasterize_gaussians_rgbd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                              cov3Ds_precomp, raster_settings):
+    track = _tracks_grad(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     return _RgbdFunction.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                               cov3Ds_precomp, raster_settings)
+                               cov3Ds_precomp, raster_settings, track)
 
 
 class _RasterizerBase(nn.Module):

@@ -6,8 +6,8 @@ buffers are torch tensors (caching allocator, current stream), everything else h
 inside libsgs_hip.so.
 """
 import ctypes as C
-
 import os
+import warnings
 
 import torch
 
@@ -94,6 +94,31 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+STRICT_BG = os.environ.get("SGS_STRICT_BG", "0") not in ("", "0")
+_bg_warned = False
+
+
+def _check_bg(bg, Cn):
+    """A background shorter than num_channels: the reference reads past its end
+    (CR/cuda_rasterizer/forward.cu:373; view_viser.py:82-83,303-313 passes a 3-vector with C ~ 20).
+    Here the missing channels are defined as 0 -- the script keeps running and nothing is read out of
+    bounds -- with one warning per process; SGS_STRICT_BG=1 makes it an error instead."""
+    global _bg_warned
+    if bg is None or bg.numel() >= Cn:
+        return bg
+    if STRICT_BG:
+        raise RuntimeError(
+            f"bg has {bg.numel()} entries but num_channels={Cn} (the reference reads out of "
+            "bounds here, CR/cuda_rasterizer/forward.cu:373)")
+    if not _bg_warned:
+        warnings.warn(f"bg has {bg.numel()} entries but num_channels={Cn}: missing channels are taken as 0 "
+                      "(the reference reads out of bounds here; set SGS_STRICT_BG=1 to make this an error)")
+        _bg_warned = True
+    pad = torch.zeros(Cn, dtype=bg.dtype, device=bg.device)
+    pad[: bg.numel()] = bg.reshape(-1)
+    return pad
+
+
 def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                       image_width, sh, degree, campos, prefiltered, debug, num_channels,
@@ -128,11 +153,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
             keep.append(kept)
             return ptr
 
-        bg = background
-        if bg is not None and bg.numel() < Cn:
-            raise RuntimeError(
-                f"bg has {bg.numel()} entries but num_channels={Cn} (the reference reads out of "
-                "bounds here, CR/cuda_rasterizer/forward.cu:373)")
+        bg = _check_bg(background, Cn)
         M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
         rc = lib.sgs_rasterize_forward(
             bufs.callback("g"), None, bufs.callback("b"), None, bufs.callback("i"), None,
@@ -306,6 +327,30 @@ def debug_expf(x):
         _lib.check(lib.sgs_debug_expf(x.numel(), x.data_ptr(), out.data_ptr(),
                                       _stream_ptr(x.device)), "debug_expf")
     return out
+
+
+def set_stream_option(option, value, device=None):
+    """Override one tuning option (_lib.OPT_*) for the CURRENT stream of `device` only; value < 0 removes the
+    override.  The set_* functions below set the process-wide defaults."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(device):
+        return int(_lib.load().sgs_stream_set_option(_stream_ptr(device), int(option), int(value)))
+
+
+def stream_stat(stat, device=None):
+    """Counter (_lib.STAT_*) of the current stream's context: work-list capacity, overflow counts, forwards."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = C.c_uint64(0)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().sgs_stream_get_stat(_stream_ptr(device), int(stat), C.byref(out)), "stat")
+    return int(out.value)
+
+
+def release_stream(device=None):
+    """Free the library's context of the current stream (pinned feedback words, events)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(device):
+        return int(_lib.load().sgs_stream_release(_stream_ptr(device)))
 
 
 def set_blend_exact(exact):

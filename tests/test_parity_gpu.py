@@ -212,10 +212,22 @@ def test_debug_flag_and_errors():
                                  c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy,
                                  48, 64, torch.zeros(500, 16, 3, device=DEV), 3, c.camera_center,
                                  False, False, 8, False)
-    with pytest.raises(RuntimeError, match="bg has 3 entries"):
-        raster.rasterize_forward(s.bg[:3], s.means3D, s.features, s.opacities, s.scales, s.rotations,
-                                 1.0, e, c.world_view_transform, c.full_proj_transform, c.tanfovx,
-                                 c.tanfovy, 48, 64, e, 0, c.camera_center, False, False, 8, False)
+    # a background shorter than C (view_viser.py passes a 3-vector with C ~ 20; the reference reads out of
+    # bounds): missing channels are 0, with a warning -- or an error under SGS_STRICT_BG=1
+    short_bg = torch.tensor([0.25, -0.5, 1.0], device=DEV)
+    full_bg = torch.cat([short_bg, torch.zeros(5, device=DEV)])
+    args = (s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e, c.world_view_transform,
+            c.full_proj_transform, c.tanfovx, c.tanfovy, 48, 64, e, 0, c.camera_center, False, False, 8, False)
+    raster._bg_warned = False
+    with pytest.warns(UserWarning, match="bg has 3 entries"):
+        padded = raster.rasterize_forward(short_bg, *args)[1]
+    assert torch.equal(padded, raster.rasterize_forward(full_bg, *args)[1])
+    raster.STRICT_BG = True
+    try:
+        with pytest.raises(RuntimeError, match="bg has 3 entries"):
+            raster.rasterize_forward(short_bg, *args)
+    finally:
+        raster.STRICT_BG = False
     with pytest.raises(RuntimeError, match="prefiltered"):
         far = s.means3D.clone()
         far[0, 2] = -1.0
@@ -437,3 +449,112 @@ def test_views_pipelined_on_two_streams_match_serial():
         for (n0, r0), (n1, r1) in zip(light, sdist.render_views_pipelined(render_light, cams, in_flight=4)):
             bad += int(n0 != n1 or not torch.equal(r0, r1))
     assert bad == 0, f"{bad} of {300 * len(cams)} pipelined forwards differ from the serial result"
+
+
+def test_no_grad_with_parameters_uses_the_resident_pool():
+    """fusion.py / eval_segmentation.py pass nn.Parameters under torch.no_grad(): the state buffers must come
+    from the resident inference pool (same storage on the next frame), not from fresh allocations."""
+    import channel_rasterization as chn
+    from sgs_hip import raster
+    scene, cam = small_scene(P=1500, C=8, W=64, H=48, fx=60.0)
+    s, c = scene.to(DEV), cam.to(DEV)
+    settings = chn.GaussianRasterizationSettings(
+        image_height=48, image_width=64, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=s.bg, scale_modifier=1.0,
+        viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+        prefiltered=False, debug=False, num_channels=8)
+    xyz = torch.nn.Parameter(s.means3D.clone())
+    feats = torch.nn.Parameter(s.features.clone())
+    rast = chn.GaussianRasterizer(settings)
+    raster.INFERENCE_POOL.clear()
+    ptrs = []
+    for _ in range(3):
+        with torch.no_grad():
+            color, radii = rast(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=s.opacities,
+                                colors_precomp=feats, scales=s.scales, rotations=s.rotations)
+        assert not color.requires_grad
+        ptrs.append(sorted(t.data_ptr() for t in raster.INFERENCE_POOL._t.values()))
+    assert len(ptrs[0]) == 3 and ptrs[0] == ptrs[1] == ptrs[2]
+    # with grad enabled the buffers belong to the autograd graph instead
+    raster.INFERENCE_POOL.clear()
+    color, _ = rast(means3D=xyz, means2D=torch.zeros_like(xyz, requires_grad=True), opacities=s.opacities,
+                    colors_precomp=feats, scales=s.scales, rotations=s.rotations)
+    assert color.requires_grad and len(raster.INFERENCE_POOL._t) == 0
+    color.sum().backward()
+    assert feats.grad is not None
+
+
+def test_options_and_state_are_per_stream(orc):
+    """Two callers in one process: stream A renders with the exact fp32 arithmetic and binning mode 1, stream B
+    with the defaults, interleaved.  Each gets its own result and its own work-list state."""
+    from sgs_hip import raster, _lib
+    scene, cam = small_scene(P=2500, C=128, W=96, H=80, fx=85.0)
+    want = oracle_forward(orc, scene, cam)["out"]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        assert raster.set_stream_option(_lib.OPT_BLEND_VARIANT, 15) == 0x7fffffff
+        raster.set_stream_option(_lib.OPT_BINNING_MODE, 1)
+    outs = {"a": [], "b": []}
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            outs["a"].append(_hip_forward(scene, cam)[1])
+        with torch.cuda.stream(sb):
+            outs["b"].append(_hip_forward(scene, cam)[1])
+    torch.cuda.synchronize()
+    for o in outs["a"]:
+        assert np.array_equal(o.cpu().numpy(), want)                      # exact arithmetic: the oracle's bits
+    for o in outs["b"]:
+        got = o.cpu().numpy()
+        assert not np.array_equal(got, want)                              # default (split-bf16) arithmetic
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    with torch.cuda.stream(sa):
+        assert raster.stream_stat(_lib.STAT_FORWARDS) == 3
+        assert raster.set_stream_option(_lib.OPT_BLEND_VARIANT, -1) == 15  # back to the process default
+        assert raster.release_stream() == 1
+    with torch.cuda.stream(sb):
+        assert raster.stream_stat(_lib.STAT_FORWARDS) == 3 and raster.stream_stat(_lib.STAT_ARENA_SLOTS) > 0
+        raster.release_stream()
+
+
+def test_backward_worklist_feedback_is_per_stream(orc):
+    """C = 64: the forward never builds a work list (below 128 channels), so the backward learns its capacity
+    from its own feedback.  A backward whose work list overflowed (forced here with backward mode 2) is counted
+    on ITS stream when the next backward reads the feedback, the per-chunk fallback and the MFMA path give the
+    same gradients, and another stream's counters stay untouched."""
+    from sgs_hip import raster, _lib
+    scene, cam = small_scene(P=3000, C=64, W=64, H=48, fx=60.0)
+    s, c = scene.to(DEV), cam.to(DEV)
+    e = torch.Tensor([])
+    st, other = torch.cuda.Stream(), torch.cuda.Stream()
+    dL = torch.randn(64, 48, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    torch.cuda.synchronize()
+
+    def fwd_bwd():
+        n, color, radii, geom, binn, img, _ = raster.rasterize_forward(
+            s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e, c.world_view_transform,
+            c.full_proj_transform, c.tanfovx, c.tanfovy, 48, 64, e, 0, c.camera_center, False, False, 64, False)
+        g = raster.rasterize_backward(s.bg, s.means3D, radii, s.features, s.scales, s.rotations, 1.0, e,
+                                      c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy,
+                                      dL, e, 0, c.camera_center, geom, n, binn, img, False)
+        torch.cuda.current_stream().synchronize()
+        return [t.clone() for t in g]
+
+    with torch.cuda.stream(st):
+        raster.set_stream_option(_lib.OPT_BACKWARD_MODE, 2)     # undersized work list: overflow -> fallback
+        g_fallback = fwd_bwd()
+        raster.set_stream_option(_lib.OPT_BACKWARD_MODE, -1)
+        assert raster.stream_stat(_lib.STAT_BWD_OVERFLOWS) == 0   # not read back yet
+        g_mfma = fwd_bwd()
+        assert raster.stream_stat(_lib.STAT_BWD_OVERFLOWS) == 1
+        g_again = fwd_bwd()
+        assert raster.stream_stat(_lib.STAT_BWD_OVERFLOWS) == 1   # the default-capacity backward did not overflow
+        raster.release_stream()
+    with torch.cuda.stream(other):
+        fwd_bwd()
+        fwd_bwd()
+        assert raster.stream_stat(_lib.STAT_BWD_OVERFLOWS) == 0
+        raster.release_stream()
+    for a, b, c2 in zip(g_fallback, g_mfma, g_again):
+        scale = b.abs().max().item() + 1e-20
+        assert (a - b).abs().max().item() <= 2e-4 * scale
+        assert (c2 - b).abs().max().item() <= 2e-4 * scale
