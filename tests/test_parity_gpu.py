@@ -555,6 +555,8 @@ def test_backward_worklist_feedback_is_per_stream(orc):
         assert raster.stream_stat(_lib.STAT_BWD_OVERFLOWS) == 0
         raster.release_stream()
     for a, b, c2 in zip(g_fallback, g_mfma, g_again):
+        if b.numel() == 0:   # (dL_dsh: no SH coefficients in this call)
+            continue
         scale = b.abs().max().item() + 1e-20
         assert (a - b).abs().max().item() <= 2e-4 * scale
         assert (c2 - b).abs().max().item() <= 2e-4 * scale
