@@ -92,62 +92,73 @@ def binning(pre, W, H):
     return dict(point_list=point_list, ranges=torch.stack([lo, hi], 1), num_rendered=L)
 
 
-def blend_tiles(pre, binn, features, bg, W, H, tile_ids=None, chunk=256):
-    """Renders the listed tiles (default all).  -> out (C,H,W), final_T (H,W), n_contrib (H,W) int64, entries walked"""
+def blend_tiles(pre, binn, features, bg, W, H, tile_ids=None, chunk=128, group=64):
+    """Renders the listed tiles (default all), `group` tiles at a time: every op works on [G, 256 px, n] arrays
+    (lists padded to the longest of the group with masked entries), so the host threads get ops worth
+    splitting.  -> out (C,H,W), final_T (H,W), n_contrib (H,W) int64, list entries walked"""
     C = features.shape[1]
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
-    out = torch.zeros(C, H, W)
-    final_T = torch.ones(H, W)
-    n_contrib = torch.zeros(H, W, dtype=torch.int64)
+    out = torch.zeros(C, gy * TILE, gx * TILE)
+    final_T = torch.ones(gy * TILE, gx * TILE)
+    n_contrib = torch.zeros(gy * TILE, gx * TILE, dtype=torch.int64)
     pix, conic, opac = pre["pix"], pre["conic"], pre["opacity"]
+    plist = binn["point_list"]
+    if plist.numel() == 0:
+        plist = torch.zeros(1, dtype=torch.int64)
     walked = 0
     yy, xx = torch.meshgrid(torch.arange(TILE, dtype=torch.float32), torch.arange(TILE, dtype=torch.float32),
                             indexing="ij")
-    yy, xx = yy.reshape(-1, 1), xx.reshape(-1, 1)
-    tiles = range(gx * gy) if tile_ids is None else tile_ids
-    for t in tiles:
-        tx, ty = t % gx, t // gx
-        px, py = xx + tx * TILE, yy + ty * TILE                                # (256,1)
-        inside = ((px < W) & (py < H)).reshape(-1)
-        r0, r1 = int(binn["ranges"][t, 0]), int(binn["ranges"][t, 1])
-        T = torch.ones(256)
+    yy, xx = yy.reshape(1, -1, 1), xx.reshape(1, -1, 1)
+    tiles = torch.arange(gx * gy) if tile_ids is None else torch.as_tensor(list(tile_ids), dtype=torch.int64)
+    ar = torch.arange(chunk)
+    for g0 in range(0, tiles.numel(), group):
+        tg = tiles[g0:g0 + group]
+        G = tg.numel()
+        tx, ty = (tg % gx).float().reshape(G, 1, 1), (tg // gx).float().reshape(G, 1, 1)
+        px, py = xx + tx * TILE, yy + ty * TILE                                  # (G,256,1)
+        inside = ((px < W) & (py < H)).reshape(G, 256)
+        r0, r1 = binn["ranges"][tg, 0], binn["ranges"][tg, 1]                     # (G,)
+        T = torch.ones(G, 256)
         done = ~inside
-        acc = torch.zeros(256, C)
-        last = torch.zeros(256, dtype=torch.int64)
-        pos = r0
-        while pos < r1 and not bool(done.all()):
-            ids = binn["point_list"][pos:min(pos + chunk, r1)]
-            n = ids.numel()
-            dx = pix[ids, 0][None, :] - px
-            dy = pix[ids, 1][None, :] - py
-            k = conic[ids]
-            power = -0.5 * (k[:, 0] * dx * dx + k[:, 2] * dy * dy) - k[:, 1] * dx * dy
-            alpha = torch.clamp(opac[ids][None, :] * torch.exp(power), max=0.99)
-            ok = (power <= 0) & (alpha >= 1.0 / 255.0) & ~done[:, None]
+        acc = torch.zeros(G, 256, C)
+        last = torch.zeros(G, 256, dtype=torch.int64)
+        off = 0
+        nmax = int((r1 - r0).max()) if G else 0
+        while off < nmax and not bool(done.all()):
+            pos = r0[:, None] + off + ar[None, :]                                 # (G,n)
+            valid = pos < r1[:, None]
+            # list entries a tile's block walks: until all of its pixels are done (as the reference's block does)
+            walked += int((valid & ~done.all(1)[:, None]).sum())
+            ids = plist[torch.where(valid, pos, torch.zeros_like(pos))]          # (G,n)
+            dx = pix[ids, 0][:, None, :] - px                                     # (G,256,n)
+            dy = pix[ids, 1][:, None, :] - py
+            k = conic[ids]                                                        # (G,n,3)
+            power = -0.5 * (k[:, None, :, 0] * dx * dx + k[:, None, :, 2] * dy * dy) - k[:, None, :, 1] * dx * dy
+            alpha = torch.clamp(opac[ids][:, None, :] * torch.exp(power), max=0.99)
+            ok = valid[:, None, :] & (power <= 0) & (alpha >= 1.0 / 255.0) & ~done[:, :, None]
             a_eff = torch.where(ok, alpha, torch.zeros_like(alpha))
             one_m = 1.0 - a_eff
-            T_excl = T[:, None] * torch.cumprod(torch.cat([torch.ones(256, 1), one_m[:, :-1]], 1), 1)
-            stop = ok & (T_excl * one_m < 1e-4)                               # the entry that would cross 1e-4 ...
-            dead = torch.cumsum(stop.to(torch.int32), 1) > 0                  # ... and everything after it
+            ones = torch.ones(G, 256, 1)
+            T_excl = T[:, :, None] * torch.cumprod(torch.cat([ones, one_m[:, :, :-1]], 2), 2)
+            stop = ok & (T_excl * one_m < 1e-4)                                   # the entry that would cross 1e-4 ...
+            dead = torch.cumsum(stop.to(torch.int32), 2) > 0                      # ... and everything after it
             a_eff = torch.where(dead, torch.zeros_like(a_eff), a_eff)
             one_m = 1.0 - a_eff
-            T_excl = T[:, None] * torch.cumprod(torch.cat([torch.ones(256, 1), one_m[:, :-1]], 1), 1)
+            T_excl = T[:, :, None] * torch.cumprod(torch.cat([ones, one_m[:, :, :-1]], 2), 2)
             wgt = a_eff * T_excl
-            acc += wgt @ features[ids]
-            T = T_excl[:, -1] * one_m[:, -1]
-            took = wgt > 0
-            idx = torch.arange(1, n + 1)[None, :] + (pos - r0)
-            last = torch.maximum(last, (took * idx).amax(1))
-            done = done | dead[:, -1]
-            walked += n
-            pos += n
-        res = acc + T[:, None] * bg[None, :C]
-        ys, xs = ty * TILE, tx * TILE
-        hh, ww = min(TILE, H - ys), min(TILE, W - xs)
-        out[:, ys:ys + hh, xs:xs + ww] = res.t().reshape(C, TILE, TILE)[:, :hh, :ww]
-        final_T[ys:ys + hh, xs:xs + ww] = T.reshape(TILE, TILE)[:hh, :ww]
-        n_contrib[ys:ys + hh, xs:xs + ww] = last.reshape(TILE, TILE)[:hh, :ww]
-    return out, final_T, n_contrib, walked
+            acc += torch.bmm(wgt, features[ids])                                  # [G,256,n] x [G,n,C]
+            T = T_excl[:, :, -1] * one_m[:, :, -1]
+            idx = (ar[None, None, :] + (off + 1)) * (wgt > 0)
+            last = torch.maximum(last, idx.amax(2))
+            done = done | dead[:, :, -1]
+            off += chunk
+        res = acc + T[:, :, None] * bg[None, None, :C]                            # (G,256,C)
+        for i in range(G):
+            ys, xs = int(ty[i]) * TILE, int(tx[i]) * TILE
+            out[:, ys:ys + TILE, xs:xs + TILE] = res[i].t().reshape(C, TILE, TILE)
+            final_T[ys:ys + TILE, xs:xs + TILE] = T[i].reshape(TILE, TILE)
+            n_contrib[ys:ys + TILE, xs:xs + TILE] = last[i].reshape(TILE, TILE)
+    return out[:, :H, :W].contiguous(), final_T[:H, :W].contiguous(), n_contrib[:H, :W].contiguous(), walked
 
 
 def render(scene, cam, W, H, tile_ids=None, timings=None):

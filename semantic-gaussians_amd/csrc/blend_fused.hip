@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void blend_fused_kernel(const FusedArgs a)
 		has_pending = false;
 	};
 
-	for (uint32_t step = 0; step < 0x4000000u; step++) {
+	for (uint32_t step = 0; step < 400000u; step++) {   // (bounded: a logic error must not hang the GPU)
 		const bool producing = !p_fin;
 		const bool consuming = step >= (uint32_t)F_LA;
 		if (consuming && step - (uint32_t)F_LA >= nprod) break;

@@ -528,7 +528,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	const int sort_bits = 32 + (int)higher_msb((uint32_t)ntiles);
 	// split blend (weights pre-pass + streaming accumulate) for the 128-channel-aligned part
 	const int variant = cx->option(SGS_OPT_BLEND_VARIANT);
-	const bool use_split = (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
+	// variants 32 / 33: the fused single-kernel blend (split-bf16 / exact fp32), bits [11:8] = segment length / 2
+	const bool want_fused = (variant & 0xff) == 32 || (variant & 0xff) == 33;
+	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
 	if (use_split) {
@@ -628,7 +630,10 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.n_contrib = (uint32_t*)(ichunk + il.n_contrib);
 	a.out = out_color;
 	a.out_depth = out_depth;
-	if (use_split) {
+	if (want_fused && sgs::blend_forward_fused_eligible(a) && (size_t)128 * width * height * 4 < (1ull << 32)) {
+		tm.mark();
+		e = sgs::launch_blend_forward_fused(st, a, (variant & 0xff) == 33, ((variant >> 8) & 15) * 2);
+	} else if (use_split) {
 		char* arena = bchunk + bl.arena;
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
 		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 15 ? 9 : 8));

@@ -89,6 +89,10 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
 				      int split_mode);
 
+// ---- blend_fused.hip: the C % 128 == 0 forward blend as one kernel (weights never leave the CU)
+bool blend_forward_fused_eligible(const BlendFwdArgs& a);
+hipError_t launch_blend_forward_fused(hipStream_t st, const BlendFwdArgs& a, bool exact, int seg_tiles);
+
 hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
 				     const float2* means2D, const float4* conic_opacity, float* final_T,
 				     uint32_t* n_contrib, char* arena, const SplitArena& lay, int W, int H, int gx,

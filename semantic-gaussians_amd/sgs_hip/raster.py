@@ -60,34 +60,58 @@ INFERENCE_POOL = ScratchPool()
 
 class _Buffers:
     """Growable byte buffers handed to the library through the sgs_alloc_fn callback
-    (the reference's resizeFunctional, CR/rasterize_points.cu:28-36)."""
+    (the reference's resizeFunctional, CR/rasterize_points.cu:28-36).
+
+    The C callback itself is ONE process-wide ctypes trampoline; which _Buffers / which buffer it serves travels
+    in the callback's `user` word.  (A fresh CFUNCTYPE closure per buffer per frame makes libffi map and unmap
+    executable pages all the time: a ~10 ms host stall every few dozen frames on a 256-thread host.)"""
+
+    _live = {}
+    _next = 1
+    KEYS = ("g", "b", "i", "s")
 
     def __init__(self, device, pool=None):
         self.device = device
         self.pool = pool
         self.tensors = {}
-        self._cbs = {}
+        self.handle = _Buffers._next
+        _Buffers._next += 1
+        _Buffers._live[self.handle] = self
+
+    def release(self):
+        _Buffers._live.pop(self.handle, None)
+
+    def _alloc(self, key, nbytes):
+        try:
+            if self.pool is not None:
+                t = self.pool.get(self.device, key, int(nbytes))
+            else:
+                t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self.tensors[key] = t
+            return t.data_ptr()
+        except Exception:   # noqa: BLE001 - reported as SGS_EALLOC by the library
+            return None
 
     def callback(self, key):
-        def alloc(_user, nbytes):
-            try:
-                if self.pool is not None:
-                    t = self.pool.get(self.device, key, int(nbytes))
-                else:
-                    t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-                self.tensors[key] = t
-                return t.data_ptr()
-            except Exception:   # noqa: BLE001 - reported as SGS_EALLOC by the library
-                return None
-        cb = _lib.ALLOC_FN(alloc)
-        self._cbs[key] = cb
-        return cb
+        """(function pointer, user word) pair for buffer `key`."""
+        return _TRAMPOLINE, C.c_void_p(self.handle * 4 + _Buffers.KEYS.index(key))
 
     def get(self, key):
         t = self.tensors.get(key)
         if t is None:
             t = torch.empty(0, dtype=torch.uint8, device=self.device)
         return t
+
+
+def _trampoline(user, nbytes):
+    user = int(user or 0)
+    bufs = _Buffers._live.get(user >> 2)
+    if bufs is None:
+        return None
+    return bufs._alloc(_Buffers.KEYS[user & 3], nbytes)
+
+
+_TRAMPOLINE = _lib.ALLOC_FN(_trampoline)
 
 
 def _stream_ptr(device):
@@ -143,6 +167,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
             color = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
             if want_depth:
                 depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
+            bufs.release()
             return 0, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
         color = torch.empty(Cn, H, W, dtype=torch.float32, device=dev)   # fully overwritten
         if want_depth:
@@ -156,7 +181,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         bg = _check_bg(background, Cn)
         M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
         rc = lib.sgs_rasterize_forward(
-            bufs.callback("g"), None, bufs.callback("b"), None, bufs.callback("i"), None,
+            *bufs.callback("g"), *bufs.callback("b"), *bufs.callback("i"),
             P, int(degree), int(M), p(bg, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
             p(colors, "colors_precomp"), p(opacity, "opacities"), p(scales, "scales"),
             float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
@@ -164,6 +189,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
             float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), Cn, color.data_ptr(),
             depth.data_ptr() if depth is not None else None, radii.data_ptr(), int(bool(debug)),
             _stream_ptr(dev))
+        bufs.release()
         num_rendered = _lib.check(rc, "rasterize_gaussians failed")
     return num_rendered, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
 
@@ -246,8 +272,8 @@ def dist2(points):
         if P != 0:
             ptr, pts = _ptr(points, "points", dev)
             bufs = _Buffers(dev)
-            rc = lib.sgs_knn_mean_dist2(P, ptr, means.data_ptr(), bufs.callback("s"), None,
-                                        _stream_ptr(dev))
+            rc = lib.sgs_knn_mean_dist2(P, ptr, means.data_ptr(), *bufs.callback("s"), _stream_ptr(dev))
+            bufs.release()
             _lib.check(rc, "distCUDA2 failed")
     return means
 
