@@ -242,6 +242,25 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
             dL_drotations)
 
 
+def render_partial(means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                   image_height, image_width, campos, scale_modifier=1.0, pool=None):
+    """One Gaussian SHARD of a view as a compositing partial (A, T): A = the (C,H,W) feature map rendered with a
+    ZERO background, T = the (H,W) transmittance left behind the shard.  Partials of depth-ordered shards combine
+    with the "over" operator (sgs_hip.dist.composite_over / render_gaussian_sharded, BASELINE config 5):
+    (A1, T1) o (A2, T2) = (A1 + T1 A2, T1 T2).  -> (A, T, radii)"""
+    Cn = colors.size(1)
+    bg = torch.zeros(Cn, dtype=torch.float32, device=means3D.device)
+    e = torch.Tensor([])
+    _, color, radii, _, _, img, _ = rasterize_forward(
+        bg, means3D, colors, opacity, scales, rotations, scale_modifier, e, viewmatrix, projmatrix, tan_fovx,
+        tan_fovy, image_height, image_width, e, 0, campos, False, False, Cn, False, pool=pool)
+    if means3D.size(0) == 0:
+        T = torch.ones(image_height, image_width, dtype=torch.float32, device=means3D.device)
+    else:
+        T = image_views(img, image_width, image_height)["final_T"].clone()
+    return color, T, radii
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible (CR/rasterize_points.cu:204-223)."""
     lib = _lib.load()
