@@ -487,6 +487,7 @@ __device__ __forceinline__ void sweep_zero(SweepSets& S)
 // may alias an LDS-DMA destination and drain the bundles in flight (cdna_hip_programming.md
 // 5.7: early-clobber outputs, nothing consumes an output before the explicit lgkmcnt(0), that
 // wait takes the values as "+v").
+template <bool X16>
 __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_t n, int cg, int half, int l31)
 {
 	const uint32_t fa = st + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;   // + kk * 512
@@ -545,12 +546,19 @@ __device__ __forceinline__ void sweep_compute(SweepSets& S, uint32_t st, uint32_
 		const s16x8 h = __builtin_bit_cast(s16x8, bh), l = __builtin_bit_cast(s16x8, bl);
 		const s16x4 h0 = {h[0], h[1], h[2], h[3]}, h1 = {h[4], h[5], h[6], h[7]};
 		const s16x4 l0 = {l[0], l[1], l[2], l[3]}, l1 = {l[4], l[5], l[6], l[7]};
+		if (X16) {   // reproducer only (tools/repro_x16_neighbour_corruption.py): the gfx950 double-rate form
+			const bf16x8 hb = __builtin_bit_cast(bf16x8, bh), lb = __builtin_bit_cast(bf16x8, bl);
+			S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, hb, S[1][pb], 0, 0, 0);
+			S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, lb, S[1][pb], 0, 0, 0);
+			S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hb, S[1][pb], 0, 0, 0);
+		} else {
 		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(al0, h0, S[1][pb], 0, 0, 0);
 		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(al1, h1, S[1][pb], 0, 0, 0);
 		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah0, l0, S[1][pb], 0, 0, 0);
 		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah1, l1, S[1][pb], 0, 0, 0);
 		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah0, h0, S[1][pb], 0, 0, 0);
 		S[1][pb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah1, h1, S[1][pb], 0, 0, 0);
+		}
 		if (pb < 3) {
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nh), "+v"(nl) : : "memory");
 			__builtin_amdgcn_sched_barrier(0);
@@ -781,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 		const bool is_left = ((tx + g * stagger) & 1) == 0;   // even rows: even tiles are left halves; odd rows (staggered): odd tiles
 		if (!(DBG & 2)) {   // always into S[1]
 			if (EXACT) sweep_compute_exact(S, st0, cg, half, l31);
-			else sweep_compute(S, st0, n, cg, half, l31);
+			else sweep_compute<(DBG & 8) != 0>(S, st0, n, cg, half, l31);
 		}
 		if ((e0y >> 16) != 0u && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
 			const int hi = (l31 >> 4) & 1;
@@ -895,6 +903,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			case 2: SGS_LAUNCH_SWEEP(2, false); break;
 			case 3: SGS_LAUNCH_SWEEP(3, false); break;
 			case 4: SGS_LAUNCH_SWEEP(4, false); break;
+			case 8: SGS_LAUNCH_SWEEP(8, false); break;   // v_mfma_f32_32x32x16_bf16 products (reproducer only)
 			default: SGS_LAUNCH_SWEEP(0, false); break;
 			}
 #undef SGS_LAUNCH_SWEEP
