@@ -456,6 +456,59 @@ __device__ __forceinline__ void sweep_store_paired_fast(const SweepSets& S, cons
 	}
 }
 
+// EXPERIMENT (variant 0x408), not the default: the same pair as 16-byte stores.  Measured at cfg3: sweep 1.09 ms against
+// 0.93 ms for the dword form -- eight channel planes per store instruction and 512 extra VALU per pair cost more than
+// the shorter store queue gains.  After the permlane16 swap lane l31 of register r holds pixel xp + l31 of channel
+// plane(r); a 4 x 4 transpose inside every quad of lanes (two rounds of v_mov_dpp quad_perm + select) turns four
+// consecutive registers (four channels) x four lanes (four pixels) into: lane qi of the quad holds four CONSECUTIVE
+// pixels of channel plane(4 q + qi).  One global_store_dwordx4 then writes eight complete 128-B lines (8 lanes x 16 B
+// per channel and row), and a tile pair is 32 store instructions instead of 128.
+// loff4 = byte offset of [4*half + (lane & 3)][ty*16 + g][xl0 + 4 * ((lane & 31) >> 2)]
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void sweep_store_paired_wide(const SweepSets& S, const float* ubase, uint32_t loff4,
+							 size_t HW, int W, int lane)
+{
+	const uint64_t plane8 = (uint64_t)HW * 32u;   // 8 channel planes
+	// lane masks for the selects.  They are bit merges (v_bfi_b32) on purpose: written as ?: the compiler turns them
+	// into exec-masked branches, and a DPP move executed under a partial exec mask cannot read the disabled lanes.
+	const uint32_t m1 = (lane & 1) ? 0xFFFFFFFFu : 0u, m2 = (lane & 2) ? 0xFFFFFFFFu : 0u;
+	auto sel = [](uint32_t m, uint32_t a, uint32_t b) __attribute__((always_inline)) { return (a & m) | (b & ~m); };
+#pragma unroll
+	for (int pb = 0; pb < 4; pb++) {
+		const uint32_t o0 = loff4 + (uint32_t)(4 * pb * W) * 4u, o1 = o0 + (uint32_t)(2 * W) * 4u;
+		uint64_t sb = (uint64_t)ubase;
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			uint32_t a[4], b[4];   // row 2 pb (a) and row 2 pb + 1 (b) of registers 4 q .. 4 q + 3
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(S[0][pb][4 * q + j]),
+										 __float_as_uint(S[1][pb][4 * q + j]), false, false);
+				a[j] = sw[0];
+				b[j] = sw[1];
+			}
+#pragma unroll
+			for (int w = 0; w < 2; w++) {
+				uint32_t* v = w ? b : a;
+				// 2 x 2 blocks inside lane pairs, then the off-diagonal blocks across lane pairs
+				const uint32_t x0 = sel(m1, quad_xor1(v[1]), v[0]), x1 = sel(m1, v[1], quad_xor1(v[0]));
+				const uint32_t x2 = sel(m1, quad_xor1(v[3]), v[2]), x3 = sel(m1, v[3], quad_xor1(v[2]));
+				const uint32_t y0 = sel(m2, quad_xor2(x2), x0), y2 = sel(m2, x2, quad_xor2(x0));
+				const uint32_t y1 = sel(m2, quad_xor2(x3), x1), y3 = sel(m2, x3, quad_xor2(x1));
+				const u32x4 d = {y0, y1, y2, y3};
+				const uint32_t off = w ? o1 : o0;
+				// (s_nop: a store of more than 64 bits is still reading its data registers when the next VALU may
+				// overwrite them -- the hazard the compiler pads for its own stores but cannot see inside an asm)
+				asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(sb) : "memory");
+			}
+			sb += plane8;
+		}
+	}
+}
+
 // the half rows in S[1] on their own (segment ends): 64-B pieces;
 // base = &out[c0 + 4*half][ty*16 + g + 2*((lane>>4)&1)][x0 + (lane & 15)]
 template <bool GUARD>
@@ -742,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	}
 	uint32_t st0 = ring, stI = ring + LA * STAGE_BYTES;   // stages of batch j and of bundle j + LA
 	bool has_pending = false;   // S[0] holds left half rows waiting for their right-hand tile
-	bool after_stores = false;
+	int skip_wait = 0;   // steps whose bundle is already known to have landed (see the tile-complete branch)
 	for (uint32_t j = 0; j < J; j++) {
 		if (j + 2 * LA >= wbase + SW_JMAX) {   // (uniform, long segments only) slide the table window
 			__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
@@ -772,9 +825,12 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 		}
 		// bundle j landed; the LA - 1 younger bundles -- and after an epilogue part of its stores --
 		// may still be in flight (vmcnt is 6 bits: <= 63)
-		if (after_stores) __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (15 << 8));   // vmcnt(63)
+		// vmcnt counts loads and stores in one counter but only orders them within their kind: a counted wait is safe
+		// only up to the number of YOUNGER LOADS, so stores behind a bundle always have to retire before the wait for it
+		// returns.  The tile-complete branch therefore waits for the next LA - 1 bundles BEFORE it issues its stores;
+		// the steps that consume those bundles skip the wait and the stores get that long to drain.
+		if (skip_wait > 0) skip_wait--;
 		else __builtin_amdgcn_s_waitcnt(((LA - 1) * SW_NDMA) | (7 << 4) | (15 << 8));
-		after_stores = false;
 		__builtin_amdgcn_s_barrier();
 		{
 			uint32_t id0, id1;   // this lane's feature-row ids for bundle j + LA, from the id area of bundle j
@@ -793,20 +849,28 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 		}
 		if ((e0y >> 16) != 0u && !((DBG & 1) && S[1][0][0] != 123.f)) {   // tile complete
 			const int hi = (l31 >> 4) & 1;
+			const bool will_store = !is_left || tx == tx0 + nt - 1;   // (uniform)
+			if (will_store) {   // bundles j + 1 .. j + LA - 1 first (issued one and two steps ago), then the stores
+				__builtin_amdgcn_s_waitcnt(SW_NDMA | (7 << 4) | (15 << 8));
+				skip_wait = LA - 1;
+			}
 			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * W;
 			const int xs = tx * SGS_TILE + (l31 & 15), xp = (tx - 1) * SGS_TILE + l31;
 			const int y0 = ty * SGS_TILE + g;
 			if (!is_left && has_pending) {   // S[0] | S[1] are whole lines
 				const bool inside = (tx + 1) * SGS_TILE <= W && y0 + 14 < H;   // uniform: the whole 32 x 8 block
-				if (inside && (DBG & 4)) sweep_store_paired<false>(S, cbp + xp, HW, W, true, y0, H);
-				else if (inside)
+				if (inside && (DBG & 4)) {   // (A/B: 16-byte stores after a quad transpose -- measured 17 % SLOWER, see the helper)
+					sweep_store_paired_wide(S, out + (size_t)c0 * HW,
+								((uint32_t)(4 * half + (lane & 3)) * (uint32_t)HW +
+								 (uint32_t)(y0 * W + (tx - 1) * SGS_TILE + 4 * (l31 >> 2))) * 4u, HW, W, lane);
+				} else if (inside) {
 					sweep_store_paired_fast(S, out + (size_t)c0 * HW,
 								((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)(y0 * W + xp)) * 4u, HW, W);
-				else sweep_store_paired<true>(S, cbp + xp, HW, W, xp < W, y0, H);
-				after_stores = true;
+				} else {
+					sweep_store_paired<true>(S, cbp + xp, HW, W, xp < W, y0, H);
+				}
 			} else if (!is_left || tx == tx0 + nt - 1) {   // a half with no partner in this segment
 				sweep_store_single<true>(S, cbp + (size_t)(2 * hi) * W + xs, HW, W, xs < W, y0 + 2 * hi, H);
-				after_stores = true;
 			}
 			if (is_left) {   // becomes the pending left half
 #pragma unroll
