@@ -92,6 +92,9 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 // ---- blend_fused.hip: the C % 128 == 0 forward blend as one kernel (weights never leave the CU)
 bool blend_forward_fused_eligible(const BlendFwdArgs& a);
 hipError_t launch_blend_forward_fused(hipStream_t st, const BlendFwdArgs& a, bool exact, int seg_tiles);
+// ---- blend_fused_pc.hip: one kernel, one producer wave (weights, once per strip) + C / 64 consumer waves per workgroup
+bool blend_forward_fused_pc_eligible(const BlendFwdArgs& a);
+hipError_t launch_blend_forward_fused_pc(hipStream_t st, const BlendFwdArgs& a, bool exact, int seg_tiles, int dbg = 0);
 
 hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
 				     const float2* means2D, const float4* conic_opacity, float* final_T,

@@ -560,3 +560,15 @@ def test_backward_worklist_feedback_is_per_stream(orc):
         scale = b.abs().max().item() + 1e-20
         assert (a - b).abs().max().item() <= 2e-4 * scale
         assert (c2 - b).abs().max().item() <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("variant", [33, 35, 32, 34])
+@pytest.mark.parametrize("C,W,H,P", [(128, 208, 160, 2500), (256, 200, 120, 2500), (512, 192, 100, 2500), (384, 100, 70, 2000)])
+def test_fused_single_kernel_variants(orc, variant, C, W, H, P):
+    """The experimental single-kernel forward blends (blend_fused.hip: every wave autonomous, variants 32 / 33;
+    blend_fused_pc.hip: one producer wave + C / 64 consumer waves per workgroup, 34 / 35).  Not the default -- both are
+    slower than the two-kernel path (DESIGN.md 5.6) -- but they are complete renderers and must stay exact: the
+    odd variants use fp32 MFMA and return the oracle's bits, the even ones the split-bf16 products."""
+    scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=90.0, seed=C)
+    scene = scene._replace(bg=torch.linspace(-1.0, 1.0, C))
+    _check_forward(orc, scene, cam, variant=variant, exact=bool(variant & 1))
