@@ -87,3 +87,47 @@ def test_feature_training_loop_converges(C):
     import channel_rasterization
     losses = _fit(channel_rasterization, C, steps=80, with_depth=False)
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+def test_densification_statistics_match_the_oracle(orc):
+    """Parity, not property: ONE optimisation step's densification inputs -- what train.py:156-160 and
+    add_densification_stats (model/gaussian_model.py:608-612) read -- against the oracle's backward of the same
+    loss: viewspace_points.grad[:, :2] (hence xyz_gradient_accum), radii (max_radii2D), visibility_filter
+    (denom); and the densify mask `grads >= densify_grad_threshold` derived from them."""
+    import numpy as np
+    import rgbd_rasterization
+    from helpers import small_scene, oracle_forward
+    scene, cam = small_scene(P=2500, C=3, W=96, H=64, fx=85.0, seed=34)
+    s, c = scene.to(DEV), cam.to(DEV)
+    g = torch.Generator().manual_seed(7)
+    target = torch.rand(3, 64, 96, generator=g)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    kw = dict(image_height=64, image_width=96, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=bg.to(DEV), scale_modifier=1.0,
+              viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+              prefiltered=False, debug=False)
+    rast = rgbd_rasterization.GaussianRasterizer(raster_settings=rgbd_rasterization.GaussianRasterizationSettings(**kw))
+    xyz = s.means3D.clone().requires_grad_(True)
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
+    screenspace_points.retain_grad()
+    image, radii, depth = rast(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=s.features,
+                               opacities=s.opacities, scales=s.scales, rotations=s.rotations, cov3D_precomp=None)
+    loss = ((image - target.to(DEV)) ** 2).mean()   # (smooth: an L1 residual near 0 could flip sign between renders)
+    loss.backward()
+    visibility_filter = radii > 0
+    accum = torch.norm(screenspace_points.grad[visibility_filter, :2], dim=-1)
+
+    fw = oracle_forward(orc, scene, cam, bg=bg.numpy())
+    dL = (2.0 * (fw["out"] - target.numpy()) / fw["out"].size).astype(np.float32)    # d mean (x - t)^2 / dx
+    gb = orc.backward(fw, dL, scene.means3D.numpy(), cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(),
+                      cam.camera_center.numpy(), 96, 64, cam.tanfovx, cam.tanfovy, bg.numpy(),
+                      scales=scene.scales.numpy(), rotations=scene.rotations.numpy())
+    vis_o = fw["radii"] > 0
+    assert np.array_equal(radii.cpu().numpy(), fw["radii"]) and np.array_equal(visibility_filter.cpu().numpy(), vis_o)
+    want = np.linalg.norm(gb["dL_dmean2D"][vis_o, :2], axis=-1)
+    got = accum.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-4 * want.max()
+    assert np.abs(xyz.grad.cpu().numpy() - gb["dL_dmeans3D"]).max() <= 1e-4 * np.abs(gb["dL_dmeans3D"]).max()
+    # the densification decision (densify_and_prune: grads >= threshold) is the same set, away from the threshold
+    thr = float(np.median(want))
+    away = np.abs(want - thr) > 1e-3 * thr
+    assert np.array_equal((got >= thr)[away], (want >= thr)[away])
