@@ -215,7 +215,13 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
 #define SGS_OPT_BINNING_MODE 1
 #define SGS_OPT_BACKWARD_MODE 2
 #define SGS_OPT_STAGE_TIMING 3
-#define SGS_OPT_COUNT 4
+/* Row pitch, in pixels, of the out_color planes the NEXT forwards on this stream write: out_color is then
+ * (C, H, pitch) floats and pixel (c, y, x) lives at out_color[(c * H + y) * pitch + x].  0 (default) = width
+ * (contiguous (C,H,W), the reference's layout).  A pitch that is a multiple of 32 pixels makes every 16-pixel tile
+ * pair a whole number of 128-byte lines whatever the image width is (BASELINE config 4: width 1297); the padding
+ * columns hold unspecified values.  Must be >= width; ignored by the RGB-D variant's depth plane. */
+#define SGS_OPT_OUT_PITCH 4
+#define SGS_OPT_COUNT 5
 /* value < 0 removes the override (the stream follows the process default again).  Returns the previous override,
  * or 0x7fffffff if there was none. */
 int sgs_stream_set_option(void *stream, int option, int value);

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px1_kernel(
 	const float4* __restrict__ conic_opacity, const float* __restrict__ depths,
 	const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
 	float* __restrict__ out, float* __restrict__ out_depth, int W, int H, int C, int gx,
-	int c_begin, int nchunks, int write_aux, int per_xcd, int total)
+	int c_begin, int nchunks, int write_aux, int per_xcd, int total, int pitch)
 {
 	const int b = blockIdx.x;
 	const int v = (b & 7) * per_xcd + (b >> 3);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px1_kernel(
 	const int py = ty * SGS_TILE + wave * 4 + (lane >> 4);
 	const bool inside = px < W && py < H;
 	const float pxf = (float)px, pyf = (float)py;
-	const size_t HW = (size_t)H * W;
+	const size_t HW = (size_t)H * pitch;   // channel plane stride of the (possibly row-padded) output
 
 	const uint2 range = ranges[tile];
 	const int n_total = (int)(range.y - range.x);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px1_kernel(
 		}
 #pragma unroll
 		for (int c = 0; c < CC; c++)
-			if (FULL || c < cn) out[(size_t)(c0 + c) * HW + pix] = __builtin_fmaf(T, bg[c0 + c], acc[c]);
+			if (FULL || c < cn) out[(size_t)(c0 + c) * HW + (size_t)py * pitch + px] = __builtin_fmaf(T, bg[c0 + c], acc[c]);
 	}
 }
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 	const float2* __restrict__ means2D, const float* __restrict__ features,
 	const float4* __restrict__ conic_opacity, const float* __restrict__ bg,
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out, int W,
-	int H, int C, int gx, int nchunks, int per_xcd, int total, const uint32_t* __restrict__ gate)
+	int H, int C, int gx, int nchunks, int per_xcd, int total, const uint32_t* __restrict__ gate, int pitch)
 {
 	if (gate && gate[1] == 0u) return;   // fallback instance: runs only if the split path overflowed
 	const int b = blockIdx.x;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
 	const int c0 = (chunk * 4 + wave) * CW;   // this wave's channel slice
 	const int tx = tile % gx, ty = tile / gx;
-	const size_t HW = (size_t)H * W;
+	const size_t HW = (size_t)H * pitch;   // channel plane stride of the (possibly row-padded) output
 
 	// weight-phase pixel (strip = wave)
 	const int px = tx * SGS_TILE + (lane & 15);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 		const int qy = ty * SGS_TILE + p * 4 + (lane >> 4);
 		if (qx < W && qy < H) {
 			const float Tp = s_T[p * 64 + lane];
-			const size_t pix = (size_t)qy * W + qx;
+			const size_t pix = (size_t)qy * pitch + qx;
 #pragma unroll
 			for (int c = 0; c < CW; c++)
 				out[(size_t)(c0 + c) * HW + pix] = __builtin_fmaf(Tp, bg[c0 + c], acc[p][c >> 1][c & 1]);
@@ -303,7 +303,7 @@ static void launch_px1(hipStream_t st, const BlendFwdArgs& a, int c_begin, int n
 	hipLaunchKernelGGL((blend_fwd_px1_kernel<CC, DEPTH, FULL>), dim3(per_xcd * 8), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.depths,
 			   a.bg, a.final_T, a.n_contrib, a.out, a.out_depth, a.W, a.H, a.C, a.gx, c_begin,
-			   nchunks, write_aux, per_xcd, total);
+			   nchunks, write_aux, per_xcd, total, a.pitch);
 }
 
 template <int CW, int BATCH>
@@ -313,7 +313,7 @@ static void launch_px4(hipStream_t st, const BlendFwdArgs& a, int nchunks, const
 	const int per_xcd = (total + 7) / 8;
 	hipLaunchKernelGGL((blend_fwd_px4_kernel<CW, BATCH>), dim3(per_xcd * 8), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.bg,
-			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate);
+			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate, a.pitch);
 }
 
 // variant: 0 = default (px4 CW=32 for the 128-channel-aligned part, px1 for the rest)

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const char* __restrict__ wgt, const float* __restrict__ features,
 	const float* __restrict__ bg, float* __restrict__ out, const uint32_t* __restrict__ counter,
-	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items)
+	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int PW)
 {
 	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
 	const int b = blockIdx.x;
@@ -687,7 +687,8 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const int chunk = v % nchunks_c;
 	const int g = (v / nchunks_c) & 1;   // row parity of this workgroup
 	const int rest = v / (2 * nchunks_c);
-	const int stagger = (W & 31) == 16 ? 1 : 0;   // odd rows start 64 B into a line (else every row is aligned alike)
+	// PW = output row pitch in pixels (>= W; the image width itself unless the caller asked for padded rows)
+	const int stagger = (PW & 31) == 16 ? 1 : 0;   // odd rows start 64 B into a line (else every row is aligned alike)
 	const int sg = rest % nseg, ty = rest / nseg;
 	const int tx0 = sg * seg;   // even (seg is even)
 	const int nt = (gx - tx0) < seg ? (gx - tx0) : seg;
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const int half = lane >> 5, l31 = lane & 31;
 	const int cbase = chunk * 128;
 	const int c0 = cbase + cg * 32;
-	const size_t HW = (size_t)H * W;
+	const size_t HW = (size_t)H * PW;   // channel plane stride
 
 	__shared__ float4 s_ring[NST * STAGE_BYTES / 16];
 	// the segment's batches as one flat stream: .x = first arena slot of the batch,
@@ -854,23 +855,24 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 				__builtin_amdgcn_s_waitcnt(SW_NDMA | (7 << 4) | (15 << 8));
 				skip_wait = LA - 1;
 			}
-			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * W;
+			float* cbp = out + (size_t)(c0 + 4 * half) * HW + (size_t)(ty * SGS_TILE + g) * PW;
 			const int xs = tx * SGS_TILE + (l31 & 15), xp = (tx - 1) * SGS_TILE + l31;
 			const int y0 = ty * SGS_TILE + g;
 			if (!is_left && has_pending) {   // S[0] | S[1] are whole lines
-				const bool inside = (tx + 1) * SGS_TILE <= W && y0 + 14 < H;   // uniform: the whole 32 x 8 block
+				// uniform: the whole 32 x 8 block lies inside the (row-padded) plane -- padding columns may be written
+				const bool inside = (tx + 1) * SGS_TILE <= W && y0 + 14 < H;
 				if (inside && (DBG & 4)) {   // (A/B: 16-byte stores after a quad transpose -- measured 17 % SLOWER, see the helper)
 					sweep_store_paired_wide(S, out + (size_t)c0 * HW,
 								((uint32_t)(4 * half + (lane & 3)) * (uint32_t)HW +
-								 (uint32_t)(y0 * W + (tx - 1) * SGS_TILE + 4 * (l31 >> 2))) * 4u, HW, W, lane);
+								 (uint32_t)(y0 * PW + (tx - 1) * SGS_TILE + 4 * (l31 >> 2))) * 4u, HW, PW, lane);
 				} else if (inside) {
 					sweep_store_paired_fast(S, out + (size_t)c0 * HW,
-								((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)(y0 * W + xp)) * 4u, HW, W);
+								((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)(y0 * PW + xp)) * 4u, HW, PW);
 				} else {
-					sweep_store_paired<true>(S, cbp + xp, HW, W, xp < W, y0, H);
+					sweep_store_paired<true>(S, cbp + xp, HW, PW, xp < W, y0, H);
 				}
 			} else if (!is_left || tx == tx0 + nt - 1) {   // a half with no partner in this segment
-				sweep_store_single<true>(S, cbp + (size_t)(2 * hi) * W + xs, HW, W, xs < W, y0 + 2 * hi, H);
+				sweep_store_single<true>(S, cbp + (size_t)(2 * hi) * PW + xs, HW, PW, xs < W, y0 + 2 * hi, H);
 			}
 			if (is_left) {   // becomes the pending left half
 #pragma unroll
@@ -959,7 +961,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 #define SGS_LAUNCH_SWEEP(D_, E_)                                                                     \
 	hipLaunchKernelGGL((blend_accum_sweep_kernel<D_, E_>), dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
-			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items)
+			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch)
 		if (exact) SGS_LAUNCH_SWEEP(0, true);
 		else
 			switch ((split_mode >> 8) & 15) {

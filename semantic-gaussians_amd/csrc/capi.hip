@@ -529,7 +529,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// split blend (weights pre-pass + streaming accumulate) for the 128-channel-aligned part
 	const int variant = cx->option(SGS_OPT_BLEND_VARIANT);
 	// variants 32 / 33: the fused single-kernel blend (split-bf16 / exact fp32), bits [11:8] = segment length / 2
-	const bool want_fused = (variant & 0xff) >= 32 && (variant & 0xff) <= 35;   // 34 / 35: producer + consumer waves
+	// 32-35: the experimental single-kernel blends (contiguous output only)
+	const bool want_fused = (variant & 0xff) >= 32 && (variant & 0xff) <= 35 &&
+				(cx->option(SGS_OPT_OUT_PITCH) <= 0 || cx->option(SGS_OPT_OUT_PITCH) == width);
 	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
@@ -630,6 +632,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.n_contrib = (uint32_t*)(ichunk + il.n_contrib);
 	a.out = out_color;
 	a.out_depth = out_depth;
+	a.pitch = cx->option(SGS_OPT_OUT_PITCH) > 0 ? cx->option(SGS_OPT_OUT_PITCH) : width;
+	if (a.pitch < width) return fail(SGS_EINVAL, "output pitch smaller than the image width");
 	if (want_fused && (variant & 0xff) >= 34 && sgs::blend_forward_fused_pc_eligible(a)) {
 		tm.mark();
 		e = sgs::launch_blend_forward_fused_pc(st, a, (variant & 0xff) == 35, ((variant >> 8) & 15) * 2, (variant >> 12) & 15);

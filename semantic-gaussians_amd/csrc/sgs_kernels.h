@@ -69,8 +69,9 @@ struct BlendFwdArgs {
 	const float* bg;             // (C)
 	float* final_T;              // (H*W)
 	uint32_t* n_contrib;         // (H*W)
-	float* out;                  // (C,H,W)
+	float* out;                  // (C,H,W), rows `pitch` floats apart (pitch >= W; pitch == W: contiguous)
 	float* out_depth;            // (H*W) or null
+	int pitch;                   // output row pitch in pixels
 };
 // gate: optional device word; when non-null the 128-channel-aligned kernels exit unless
 // *gate != 0 (used as the arena-overflow fallback of the split path).

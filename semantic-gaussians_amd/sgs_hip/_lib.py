@@ -42,7 +42,7 @@ EXPORTS = (
 )
 
 # sgs_stream_set_option / sgs_stream_get_stat selectors (include/sgs_raster.h)
-OPT_BLEND_VARIANT, OPT_BINNING_MODE, OPT_BACKWARD_MODE, OPT_STAGE_TIMING = 0, 1, 2, 3
+OPT_BLEND_VARIANT, OPT_BINNING_MODE, OPT_BACKWARD_MODE, OPT_STAGE_TIMING, OPT_OUT_PITCH = 0, 1, 2, 3, 4
 STAT_ARENA_SLOTS, STAT_FWD_OVERFLOWS, STAT_BWD_OVERFLOWS, STAT_FORWARDS = 0, 1, 2, 3
 
 _lib = None

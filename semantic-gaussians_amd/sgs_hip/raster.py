@@ -118,6 +118,10 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+# Opt-in: allocate the output planes with rows padded to a multiple of this many pixels and return the (C,H,W) VIEW of
+# them (non-contiguous when W is not a multiple).  32 makes every tile pair whole 128-byte lines for any width
+# (cfg4's 1297: the accumulate kernel's stores run at the full-line rate instead of the partial-line rate).
+OUTPUT_PITCH_ALIGN = int(os.environ.get("SGS_OUTPUT_PITCH_ALIGN", "0") or 0)
 STRICT_BG = os.environ.get("SGS_STRICT_BG", "0") not in ("", "0")
 _bg_warned = False
 
@@ -169,7 +173,12 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
                 depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
             bufs.release()
             return 0, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
-        color = torch.empty(Cn, H, W, dtype=torch.float32, device=dev)   # fully overwritten
+        pitch = W
+        if OUTPUT_PITCH_ALIGN > 1 and W % OUTPUT_PITCH_ALIGN and Cn >= 128 and not want_depth:
+            pitch = -(-W // OUTPUT_PITCH_ALIGN) * OUTPUT_PITCH_ALIGN
+        color = torch.empty(Cn, H, pitch, dtype=torch.float32, device=dev)   # fully overwritten
+        if pitch != W:
+            lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, pitch)
         if want_depth:
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
 
@@ -190,6 +199,9 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
             depth.data_ptr() if depth is not None else None, radii.data_ptr(), int(bool(debug)),
             _stream_ptr(dev))
         bufs.release()
+        if pitch != W:
+            lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, -1)
+            color = color[:, :, :W]
         num_rendered = _lib.check(rc, "rasterize_gaussians failed")
     return num_rendered, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
 

@@ -572,3 +572,27 @@ def test_fused_single_kernel_variants(orc, variant, C, W, H, P):
     scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=90.0, seed=C)
     scene = scene._replace(bg=torch.linspace(-1.0, 1.0, C))
     _check_forward(orc, scene, cam, variant=variant, exact=bool(variant & 1))
+
+
+@pytest.mark.parametrize("C,W,H", [(128, 205, 70), (256, 100, 52), (160, 49, 40), (128, 208, 64)])
+def test_output_pitch_option(orc, C, W, H):
+    """Opt-in row-padded output planes (sgs_hip.raster.OUTPUT_PITCH_ALIGN / SGS_OPT_OUT_PITCH): the (C,H,W) view of
+    the padded tensor holds exactly the contiguous render's bits -- only the store addresses change -- in both
+    arithmetic modes, for widths that are and are not multiples of 16."""
+    from sgs_hip import raster
+    scene, cam = small_scene(P=2500, C=C, W=W, H=H, fx=90.0, seed=W)
+    scene = scene._replace(bg=torch.linspace(-1.0, 1.0, C))
+    want = {v: _hip_forward(scene, cam, variant=v)[1].clone() for v in (0, 15)}
+    raster.OUTPUT_PITCH_ALIGN = 32
+    try:
+        for v in (0, 15):
+            out = _hip_forward(scene, cam, variant=v)[1]
+            padded = W % 32 != 0
+            assert out.shape == (C, H, W) and out.is_contiguous() == (not padded)
+            if padded:
+                assert out.stride() == (H * (-(-W // 32) * 32), -(-W // 32) * 32, 1)
+            assert torch.equal(out, want[v])
+    finally:
+        raster.OUTPUT_PITCH_ALIGN = 0
+    fw = oracle_forward(orc, scene, cam)
+    assert np.array_equal(want[15].cpu().numpy(), fw["out"])
