@@ -94,9 +94,19 @@ __global__ __launch_bounds__(256) void fusion_mapping_kernel(int N, const float*
 		vis = vis && p.z > 0.0;
 	} else if (vis) {
 		const size_t pix = (size_t)p.vi * W + (size_t)p.ui;
-		const double d = DEPTH == 1 ? (double)static_cast<const float*>(depth)[pix]
-					    : static_cast<const double*>(depth)[pix];
-		vis = fabs(d - p.z) <= vis_thres * d;
+		// fusion_utils.py:65-67: `self.vis_thres * depth_cur` is evaluated in the depth map's OWN precision -- a
+		// Python float times a float32 array is a float32 product (the rendered depth is float32), times the
+		// float64 z-buffer of "surface" mode a float64 one -- and only then compared with the float64 |d - z|.
+		double d, thr;
+		if (DEPTH == 1) {
+			const float df = static_cast<const float*>(depth)[pix];
+			d = (double)df;
+			thr = (double)((float)vis_thres * df);
+		} else {
+			d = static_cast<const double*>(depth)[pix];
+			thr = vis_thres * d;
+		}
+		vis = fabs(d - p.z) <= thr;
 	}
 	mapping[3 * (size_t)i] = vis ? p.vi : 0;
 	mapping[3 * (size_t)i + 1] = vis ? p.ui : 0;
