@@ -278,8 +278,11 @@ def main():
 
     def in_flight(variant, steps, warmup, stage_timing=False):
         raster.set_blend_variant(variant)
+        out = None
         for _ in range(warmup):
-            step()
+            out = step()   # bound like the timed loop: step n's outputs live while step n + 1 allocates, so the
+            #                caching allocator reaches its steady-state footprint here, not in the timed region
+            #                (a 10 GB hipMalloc in timed step 2 was a 240 ms stall, profiles/r02h_bench_default.json)
         if stage_timing:   # deferred per-stage hipEvents for the timed steps only (no extra synchronisation)
             raster.get_stage_ms()
             raster.set_stage_timing(2)
