@@ -308,6 +308,297 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	}
 }
 
+// ================= split-bf16 forms of the two products (the default) =================
+// x = hi + lo + O(2^-16 x) with hi, lo bf16 (round to nearest even), and  F.G ~ Fl.Gh + Fh.Gl + Fh.Gh  on
+// v_mfma_f32_32x32x8_bf16_1k with fp32 accumulation: every product is exact in fp32, what is dropped is
+// <= 3 * 2^-16 of sum |F||G| -- the forward's default arithmetic (5.2) applied to the backward's two products.
+// 3 x 32 cycles per 8 k instead of 4 x 64: the matrix work drops 2.7x and both kernels become staging bound.
+// Operand slabs in LDS: one row per M / N index, 36 dwords: [16 dwords: 32 k as bf16 hi][16 dwords: lo][4 pad];
+// a lane of half h reads its 16 k (positions 16 h .. 16 h + 15) as ds_read_b128 pairs (conflict free at this pitch).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int LDQ = 36;   // row pitch (dwords) of the split slabs
+
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo)
+{
+	const bf16x2 hv = {(__bf16)a, (__bf16)b};
+	hi = __builtin_bit_cast(uint32_t, hv);
+	const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+	const bf16x2 lv = {(__bf16)(a - ha), (__bf16)(b - hb)};
+	lo = __builtin_bit_cast(uint32_t, lv);
+}
+__device__ __forceinline__ void split_px4(float4 v, bool ok, uint2& hi, uint2& lo)
+{
+	split_pair(v.x, v.y, hi.x, lo.x);
+	split_pair(v.z, v.w, hi.y, lo.y);
+	hi.x = ok ? hi.x : 0u;
+	hi.y = ok ? hi.y : 0u;
+	lo.x = ok ? lo.x : 0u;
+	lo.y = ok ? lo.y : 0u;
+}
+struct Op2 {   // two k-steps (2 x 4 bf16) of one operand row
+	s16x4 k0, k1;
+};
+__device__ __forceinline__ Op2 lds_op2(const uint32_t* p)
+{
+	const uint4 v = *reinterpret_cast<const uint4*>(p);
+	Op2 r;
+	r.k0 = __builtin_bit_cast(s16x4, uint2{v.x, v.y});
+	r.k1 = __builtin_bit_cast(s16x4, uint2{v.z, v.w});
+	return r;
+}
+#define SGS_MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(A_, B_, C_, 0, 0, 0)
+
+// ---- 3'. D = F G.  The gradient slab has to be transposed on its way into LDS (k = channel is the slow
+// dimension of dL_dpix): a thread owns ONE pixel and 16 channels of the slab (16 dword loads, lanes along px':
+// four 64-byte row pieces per wave instruction) and writes its 16 k as two 16-byte pieces per half.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_dot_split_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float* __restrict__ features, const float* __restrict__ bg,
+	const float* __restrict__ dL_dpix, float* __restrict__ Drows,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int per_xcd, int ntiles)
+{
+	if (counter[1] != 0u) return;
+	const int b = blockIdx.x;
+	const int tile = (b & 7) * per_xcd + (b >> 3);
+	if (tile >= ntiles) return;
+	const int t = threadIdx.x;
+	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int l31 = lane & 31, h = lane >> 5;
+	const int tx = tile % gx, ty = tile / gx;
+	const uint32_t HW = (uint32_t)H * (uint32_t)W;
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const int total = (int)nact[tile];
+
+	__shared__ __attribute__((aligned(16))) uint32_t sF[CHUNK * LDQ];
+	__shared__ __attribute__((aligned(16))) uint32_t sG[256 * LDQ];
+	__shared__ uint32_t s_id[CHUNK];
+
+	// this thread's pixel px' = t & 255 and channel half (t >> 8) of every slab
+	const int gp = t & 255, gh = t >> 8;
+	const int g_y = ty * SGS_TILE + 2 * ((gp & 127) >> 4) + (gp >> 7), g_x = tx * SGS_TILE + (gp & 15);
+	const bool g_ok = g_y < H && g_x < W;
+	const uint32_t g_off = (uint32_t)(16 * gh) * HW + (uint32_t)(g_y < H ? g_y : H - 1) * (uint32_t)W +
+			       (uint32_t)(g_x < W ? g_x : W - 1);
+	const uint32_t g_offb = 4u * g_off;   // (eligibility: 128 planes * 4 B < 2^32)
+
+	for (int ci = 0; ci * CHUNK < total; ci++) {
+		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
+		const int mb = (cnt + 31) >> 5;
+		const uint32_t cstart = table[chunk_base + ci];
+		__syncthreads();
+		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
+		f32x16 acc[4];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+		__syncthreads();   // s_id visible
+		const float* frow[2];
+		bool fvalid[2];
+#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			const int q = t + 512 * i, e = q >> 3, f = q & 7;
+			const uint32_t id = s_id[e];
+			fvalid[i] = id != NO_ID;
+			frow[i] = ((id == BG_ID || id == NO_ID) ? bg : features + (size_t)id * C) + 4 * f;
+		}
+		float pg[16];
+		float4 pf[2];
+		auto fetch = [&](int c0) __attribute__((always_inline)) {
+			// buffer loads: SGPR descriptor over this slab + scalar plane offset + ONE 32-bit lane offset (as plain
+			// pointer arithmetic the compiler tabulates 16 64-bit lane addresses and spills them)
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+				const_cast<float*>(dL_dpix + (size_t)c0 * HW), 0, 0xFFFFFFFF, 0x00020000);
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				pg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, g_offb, (uint32_t)j * HW * 4u, 0));
+#pragma unroll
+			for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
+		};
+		fetch(0);
+		for (int c0 = 0; c0 < C; c0 += 32) {
+			__syncthreads();   // the previous slab's readers are done
+			{
+				uint32_t hi[8], lo[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					split_pair(pg[2 * j], pg[2 * j + 1], hi[j], lo[j]);
+					hi[j] = g_ok ? hi[j] : 0u;
+					lo[j] = g_ok ? lo[j] : 0u;
+				}
+				uint32_t* row = &sG[gp * LDQ + 8 * gh];
+				*reinterpret_cast<uint4*>(row) = uint4{hi[0], hi[1], hi[2], hi[3]};
+				*reinterpret_cast<uint4*>(row + 4) = uint4{hi[4], hi[5], hi[6], hi[7]};
+				*reinterpret_cast<uint4*>(row + 16) = uint4{lo[0], lo[1], lo[2], lo[3]};
+				*reinterpret_cast<uint4*>(row + 20) = uint4{lo[4], lo[5], lo[6], lo[7]};
+			}
+#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				const int q = t + 512 * i, e = q >> 3, f = q & 7;
+				uint2 hi, lo;
+				split_px4(pf[i], fvalid[i], hi, lo);
+				*reinterpret_cast<uint2*>(&sF[e * LDQ + 2 * f]) = hi;
+				*reinterpret_cast<uint2*>(&sF[e * LDQ + 16 + 2 * f]) = lo;
+			}
+			__syncthreads();
+			if (c0 + 32 < C) fetch(c0 + 32);
+			// k = position 16 h + 4 s + j of the slab (= channel c0 + that) for both operands
+#pragma unroll
+			for (int sp = 0; sp < 2; sp++) {
+				const uint32_t* gb_ = &sG[(32 * wave + l31) * LDQ + 8 * h + 4 * sp];
+				const Op2 bh = lds_op2(gb_), bl = lds_op2(gb_ + 16);
+#pragma unroll
+				for (int m = 0; m < 4; m++)
+					if (m < mb) {
+						const uint32_t* fa = &sF[(32 * m + l31) * LDQ + 8 * h + 4 * sp];
+						const Op2 ah = lds_op2(fa), al = lds_op2(fa + 16);
+						acc[m] = SGS_MFMA_BF16(al.k0, bh.k0, acc[m]);
+						acc[m] = SGS_MFMA_BF16(ah.k0, bl.k0, acc[m]);
+						acc[m] = SGS_MFMA_BF16(ah.k0, bh.k0, acc[m]);
+						acc[m] = SGS_MFMA_BF16(al.k1, bh.k1, acc[m]);
+						acc[m] = SGS_MFMA_BF16(ah.k1, bl.k1, acc[m]);
+						acc[m] = SGS_MFMA_BF16(ah.k1, bh.k1, acc[m]);
+					}
+			}
+		}
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			if (m < mb)
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					const int e = 32 * m + mfma_row(r, h);
+					if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 32 * wave + l31] = acc[m][r];
+				}
+	}
+}
+
+// ---- 2'. dL/dF = W G^T: k = px' is the fast dimension of both operands, so staging is convert + pack.
+template <bool VEC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_dcolor_split_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float* __restrict__ Wrows, const float* __restrict__ dL_dpix,
+	float* __restrict__ dL_dcolors, const uint32_t* __restrict__ counter, int W, int H, int C, int gx,
+	int nch, int per_xcd, int items)
+{
+	if (counter[1] != 0u) return;
+	const int b = blockIdx.x;
+	const int item = (b & 7) * per_xcd + (b >> 3);
+	if (item >= items) return;
+	const int tile = item / nch, cc = item - tile * nch;
+	const int t = threadIdx.x;
+	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int nb = wave & 3, mh = wave >> 2;
+	const int l31 = lane & 31, h = lane >> 5;
+	const int tx = tile % gx, ty = tile / gx;
+	const uint32_t HW = (uint32_t)H * (uint32_t)W;
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const int total = (int)nact[tile];
+	const int cbase = cc * 128;
+
+	__shared__ __attribute__((aligned(16))) uint32_t sW[CHUNK * LDQ];
+	__shared__ __attribute__((aligned(16))) uint32_t sG[128 * LDQ];
+	__shared__ uint32_t s_id[CHUNK];
+
+	const float* gch[2];
+	bool cvalid[2];
+	int gy0[2], gxx[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		const int q = t + 512 * i, e = q >> 3, f = q & 7;
+		cvalid[i] = cbase + e < C;
+		gch[i] = dL_dpix + (size_t)(cvalid[i] ? cbase + e : cbase) * HW;
+		gy0[i] = ty * SGS_TILE + 2 * (f >> 2);
+		gxx[i] = tx * SGS_TILE + (f & 3) * 4;
+	}
+
+	for (int ci = 0; ci * CHUNK < total; ci++) {
+		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
+		const int cnt16 = (cnt + 15) & ~15;
+		const int mb = ((cnt + 31) >> 5) - 2 * mh;
+		const bool wave_on = cbase + 32 * nb < C && mb > 0;
+		const uint32_t cstart = table[chunk_base + ci];
+		__syncthreads();
+		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
+		f32x16 acc[2];
+#pragma unroll
+		for (int m = 0; m < 2; m++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+		const float* wrow[2];
+		bool wvalid[2];
+#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			const int q = t + 512 * i, e = q >> 3, f = q & 7;
+			wvalid[i] = e < cnt16;
+			wrow[i] = Wrows + (size_t)(cstart + (wvalid[i] ? e : 0)) * 256 + 4 * f;
+		}
+		float4 pw[2], pg[2];
+		bool pok[2];
+		auto fetch = [&](int j) __attribute__((always_inline)) {
+			const int yo = 4 * (j & 3) + (j >> 2);
+#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				pw[i] = *reinterpret_cast<const float4*>(wrow[i] + 32 * j);
+				const int y = gy0[i] + yo;
+				pok[i] = cvalid[i] && y < H;
+				pg[i] = load_px4<VEC>(gch[i] + (uint32_t)(y < H ? y : H - 1) * (uint32_t)W, gxx[i], W);
+			}
+		};
+		fetch(0);
+		for (int j = 0; j < 8; j++) {
+			__syncthreads();
+#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				const int q = t + 512 * i, e = q >> 3, f = q & 7;
+				uint2 hi, lo;
+				split_px4(pw[i], wvalid[i], hi, lo);
+				*reinterpret_cast<uint2*>(&sW[e * LDQ + 2 * f]) = hi;
+				*reinterpret_cast<uint2*>(&sW[e * LDQ + 16 + 2 * f]) = lo;
+				split_px4(mask_px4(pg[i], gxx[i], W, pok[i]), true, hi, lo);
+				*reinterpret_cast<uint2*>(&sG[e * LDQ + 2 * f]) = hi;
+				*reinterpret_cast<uint2*>(&sG[e * LDQ + 16 + 2 * f]) = lo;
+			}
+			__syncthreads();
+			if (j + 1 < 8) fetch(j + 1);
+			if (wave_on) {
+				// k = position 16 h + 4 s + jj of the slab (= px' 32 j + that) for both operands
+#pragma unroll
+				for (int sp = 0; sp < 2; sp++) {
+					const uint32_t* gb_ = &sG[(32 * nb + l31) * LDQ + 8 * h + 4 * sp];
+					const Op2 bh = lds_op2(gb_), bl = lds_op2(gb_ + 16);
+#pragma unroll
+					for (int m = 0; m < 2; m++)
+						if (m < mb) {
+							const uint32_t* wa = &sW[(64 * mh + 32 * m + l31) * LDQ + 8 * h + 4 * sp];
+							const Op2 ah = lds_op2(wa), al = lds_op2(wa + 16);
+							acc[m] = SGS_MFMA_BF16(al.k0, bh.k0, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k0, bl.k0, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k0, bh.k0, acc[m]);
+							acc[m] = SGS_MFMA_BF16(al.k1, bh.k1, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k1, bl.k1, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k1, bh.k1, acc[m]);
+						}
+				}
+			}
+		}
+		if (wave_on) {
+#pragma unroll
+			for (int m = 0; m < 2; m++)
+				if (m < mb)
+#pragma unroll
+					for (int r = 0; r < 16; r++) {
+						const int e = 64 * mh + 32 * m + mfma_row(r, h);
+						const uint32_t id = s_id[e];
+						if (id < NO_ID) atomicAdd(&dL_dcolors[(size_t)id * C + cbase + 32 * nb + l31], acc[m][r]);
+					}
+		}
+	}
+}
+#undef SGS_MFMA_BF16
+
 struct StagedEntryG {
 	float a2, b2, c2, o;
 	float x, y;
@@ -438,7 +729,8 @@ bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 	       ((uintptr_t)a.dL_dpix & 15u) == 0 && (size_t)a.H * a.W * 128 * 4 < ((size_t)1 << 32);   // 32-bit slab offsets
 }
 
-hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay)
+hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
+				      bool fp32_products)
 {
 	const int ntiles = a.gx * a.gy;
 	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
@@ -455,12 +747,18 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const int items = ntiles * nch;
 	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
 	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows
-#define SGS_LAUNCH_BWD(V_, DOT_)                                                                                 \
-	hipLaunchKernelGGL(bwd_dcolor_kernel<V_>, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, \
+#define SGS_LAUNCH_BWD(DCOL_, DOT_)                                                                              \
+	hipLaunchKernelGGL(DCOL_, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id,                 \
 			   rows, a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);        \
 	hipLaunchKernelGGL(DOT_, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, a.colors, a.bg,  \
 			   a.dL_dpix, rows, counter, a.W, a.H, a.C, a.gx, txcd, ntiles)
-	if (vec) { SGS_LAUNCH_BWD(true, bwd_dot_kernel<true>); } else { SGS_LAUNCH_BWD(false, bwd_dot_kernel<false>); }
+	if (fp32_products) {
+		if (vec) { SGS_LAUNCH_BWD(bwd_dcolor_kernel<true>, bwd_dot_kernel<true>); }
+		else { SGS_LAUNCH_BWD(bwd_dcolor_kernel<false>, bwd_dot_kernel<false>); }
+	} else {
+		if (vec) { SGS_LAUNCH_BWD(bwd_dcolor_split_kernel<true>, bwd_dot_split_kernel); }
+		else { SGS_LAUNCH_BWD(bwd_dcolor_split_kernel<false>, bwd_dot_split_kernel); }
+	}
 #undef SGS_LAUNCH_BWD
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
 			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,

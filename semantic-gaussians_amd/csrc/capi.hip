@@ -756,7 +756,7 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 					     : hipMallocAsync(&scratch, bytes + 128, st);
 			if (ea == hipSuccess && scratch) {
 				char* arena = align_ptr((char*)scratch);
-				e = sgs::launch_blend_backward_mfma(st, a, arena, lay);
+				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3);
 				if (e == hipSuccess && cx->ensure(cx->bwd_usage_host, cx->bwd_ev)) {
 					if (hipMemcpyAsync(cx->bwd_usage_host, arena + lay.counter, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
 					    hipEventRecord(cx->bwd_ev, st) == hipSuccess)

@@ -126,7 +126,9 @@ hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const ui
 // forward's work list + a scalar recurrence (see the file header).  `arena` is scratch of
 // split_arena_bytes(capacity, ...) bytes.
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a);
-hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay);
+// fp32_products: the two channel products on v_mfma_f32_32x32x2_f32 (exact fp32 products) instead of split bf16
+hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
+				      bool fp32_products);
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
 			   const int* radii, const float* shs, const uint8_t* clamped,
 			   const float* scales, const float* rotations, float mod,
