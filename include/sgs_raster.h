@@ -271,6 +271,10 @@ int sgs_set_binning_mode(int mode);
  * gradient entry of the float64 oracle (tests).  Returns the previous mode. */
 int sgs_set_backward_mode(int mode);
 int sgs_get_stage_ms(float *ms7);
+/* Debug (tools/sweep_trace.py): device buffer of 4 x uint64 per workgroup of the accumulate sweep, filled by the
+ * next forwards with (begin, end) on the 100 MHz steady counter, HW_ID | XCC_ID << 32, batches | tiles << 32;
+ * NULL switches the trace off.  Process-wide, not for production use. */
+void sgs_debug_set_sweep_trace(void *device_words);
 
 /* ---- 2-D -> 3-D fusion step (the callers either side of the depth render) ----
  *

@@ -392,6 +392,55 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Workgroup = 4 waves = 4 channel groups of 32; wave tile 32 channels x the 128 pixels of the parity
 // (4 MFMA blocks of 32 px = two rows each); batch = 16 entries; ring of NST stages of 8 KB fp32
 // features + 8 KB weights (this parity's half) + the ids of the batch LA bundles on.
+// ---- sweep plan: the order in which the accumulate sweep's workgroups take the segments.
+// A sweep workgroup's duration is ~ a * (batches of its segment) + b (tools/sweep_trace.py: 1.46 us per batch + 36 us
+// at cfg3) and the hardware hands workgroup b to XCD b % 8 in blockIdx order, 64 at a time per XCD.  In row-major
+// order the last workgroups of every XCD are full-size ones, and an XCD whose band of rows is lighter idles while the
+// others finish: 433 of 512 slots busy on average.  This kernel (one workgroup, a few us between the weights pre-pass
+// and the sweep) sorts the segments by their batch count, heaviest first; the sweep deals them to the XCDs in
+// serpentine order (rank k -> XCD k % 16 < 8 ? k % 8 : 7 - k % 8), all 2 * C / 128 workgroups of a segment on one XCD
+// (they share its weights and feature rows through that XCD's L2).  Longest-processing-time-first: every XCD gets
+// the same work to within one small segment and its last workgroups are its shortest.
+constexpr int PLAN_MAX = 4096;   // segments (beyond: row-major order)
+__global__ __launch_bounds__(1024) void sweep_plan_kernel(const uint32_t* __restrict__ nact, uint32_t* __restrict__ order,
+							   const uint32_t* __restrict__ counter, int gx, int gy, int seg, int nseg)
+{
+	if (counter[1] != 0u) return;
+	__shared__ uint32_t key[PLAN_MAX];
+	const int n = gy * nseg;
+	int np2 = 1;
+	while (np2 < n) np2 <<= 1;
+	for (int s = threadIdx.x; s < np2; s += 1024) {
+		uint32_t k = 0;   // padding sorts last
+		if (s < n) {
+			const int ty = s / nseg, tx0 = (s % nseg) * seg;
+			const int nt = (gx - tx0) < seg ? (gx - tx0) : seg;
+			uint32_t J = 0;
+			for (int i = 0; i < nt; i++) J += (nact[ty * gx + tx0 + i] + 15u) >> 4;
+			J = J < 0xFFFFEu ? J : 0xFFFFEu;
+			k = ((J + 1u) << 12) | (uint32_t)(PLAN_MAX - 1 - s);   // ties: lower segment first
+		}
+		key[s] = k;
+	}
+	__syncthreads();
+	for (int k2 = 2; k2 <= np2; k2 <<= 1)   // bitonic sort, descending
+		for (int j = k2 >> 1; j > 0; j >>= 1) {
+			for (int i = threadIdx.x; i < np2; i += 1024) {
+				const int ixj = i ^ j;
+				if (ixj > i) {
+					const uint32_t a = key[i], b = key[ixj];
+					const bool desc = (i & k2) == 0;
+					if (desc ? a < b : a > b) {
+						key[i] = b;
+						key[ixj] = a;
+					}
+				}
+			}
+			__syncthreads();
+		}
+	for (int s = threadIdx.x; s < n; s += 1024) order[s] = (uint32_t)(PLAN_MAX - 1) - (key[s] & 4095u);
+}
+
 constexpr int SEGMAX = 96;   // tiles per sweep (upper bound, the launcher picks the length)
 constexpr int SW_JMAX = 1024; // batch-table window (batches of a segment kept in LDS)
 constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
@@ -678,15 +727,29 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const char* __restrict__ wgt, const float* __restrict__ features,
 	const float* __restrict__ bg, float* __restrict__ out, const uint32_t* __restrict__ counter,
-	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int PW)
+	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int PW,
+	unsigned long long* __restrict__ trace, const uint32_t* __restrict__ order, int dealt)
 {
 	if (counter[1] != 0u) return;   // arena overflowed: the single-kernel path renders this frame
 	const int b = blockIdx.x;
-	const int v = (b & 7) * per_xcd + (b >> 3);
-	if (v >= total_items) return;
-	const int chunk = v % nchunks_c;
-	const int g = (v / nchunks_c) & 1;   // row parity of this workgroup
-	const int rest = v / (2 * nchunks_c);
+	int chunk, g, rest;   // 128-channel chunk, row parity, segment (= ty * nseg + sg) of this workgroup
+	if (dealt) {   // segments dealt to the XCDs in serpentine order of their rank (sweep_plan_kernel); per_xcd = ranks per XCD
+		const int x = b & 7, pos = b >> 3, sib = 2 * nchunks_c;
+		const int m = pos / sib, w = pos - m * sib;
+		const int k = 16 * (m >> 1) + ((m & 1) ? 15 - x : x);
+		if (k >= total_items) return;   // (total_items = segments)
+		chunk = w % nchunks_c;
+		g = w / nchunks_c;
+		rest = order ? (int)order[k] : k;
+	} else {   // row-major: XCD x takes the band [x * per_xcd, (x + 1) * per_xcd) of (segment, parity, chunk) items
+		const int v = (b & 7) * per_xcd + (b >> 3);
+		if (v >= total_items) return;
+		chunk = v % nchunks_c;
+		g = (v / nchunks_c) & 1;
+		rest = v / (2 * nchunks_c);
+	}
+	// (debug, tools/sweep_trace.py) per-workgroup timeline: begin / end on the 100 MHz steady counter + where it ran
+	const unsigned long long t_begin = trace ? wall_clock64() : 0ull;
 	// PW = output row pitch in pixels (>= W; the image width itself unless the caller asked for padded rows)
 	const int stagger = (PW & 31) == 16 ? 1 : 0;   // odd rows start 64 B into a line (else every row is aligned alike)
 	const int sg = rest % nseg, ty = rest / nseg;
@@ -885,6 +948,13 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 		stI = stI + STAGE_BYTES == ring + NST * STAGE_BYTES ? ring : stI + STAGE_BYTES;
 	}
 	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the dummy tail bundles before LDS is released
+	if (trace && threadIdx.x == 0) {
+		trace[4 * (size_t)b] = t_begin;
+		trace[4 * (size_t)b + 1] = wall_clock64();
+		trace[4 * (size_t)b + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |          // HW_ID
+					   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // XCC_ID
+		trace[4 * (size_t)b + 3] = (unsigned long long)J | ((unsigned long long)nt << 32);
+	}
 }
 
 // The exact-format work list alone (fp32 weight rows + ids + list positions): the backward's first step.
@@ -917,11 +987,15 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	a.table = take(((L >> 7) + (size_t)ntiles + 1) * 4);           // chunk starts
 	a.act_id = take((size_t)capacity * 4);
 	a.act_idx = take((size_t)capacity * 4);
+	a.order = take((size_t)PLAN_MAX * 4);
 	a.wgt = take((size_t)capacity * 1024);
 	a.total = (off + 127) & ~(size_t)127;
 	if (lay) *lay = a;
 	return a.total;
 }
+
+static unsigned long long* g_sweep_trace = nullptr;   // debug only (sgs_debug_set_sweep_trace)
+void set_sweep_trace(void* device_words) { g_sweep_trace = (unsigned long long*)device_words; }
 
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
@@ -956,12 +1030,23 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		if (exact) SGS_LAUNCH_W(3, st, 0, ntiles);
 		else SGS_LAUNCH_W(2, st, 0, ntiles);
 		if (mark) mark(mark_user);
-		const int items = a.gy * nseg * nc * 2;   // x 2 row parities
-		const int pxcd = (items + 7) / 8;
+		// workgroup order (bits [13:12] of the variant): 0 / 3 = segments sorted by work and dealt to the XCDs
+		// (sweep_plan_kernel), 1 = row-major bands per XCD (the previous order), 2 = dealt, unsorted
+		const int nsegs = a.gy * nseg;
+		int plan = (split_mode >> 12) & 3;
+		if (plan == 0) plan = 3;
+		if (nsegs > PLAN_MAX && plan == 3) plan = 2;
+		uint32_t* order = (uint32_t*)(arena + lay.order);
+		if (plan == 3)
+			hipLaunchKernelGGL(sweep_plan_kernel, dim3(1), dim3(1024), 0, st, nbatches, order, counter, a.gx, a.gy, seg, nseg);
+		const int dealt = plan >= 2;
+		const int items = dealt ? nsegs : nsegs * nc * 2;   // x 2 row parities
+		const int pxcd = dealt ? 2 * ((nsegs + 15) / 16) * nc * 2 : (items + 7) / 8;   // workgroups per XCD
+		const uint32_t* order_arg = plan == 3 ? order : nullptr;
 #define SGS_LAUNCH_SWEEP(D_, E_)                                                                     \
 	hipLaunchKernelGGL((blend_accum_sweep_kernel<D_, E_>), dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
-			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch)
+			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
 		if (exact) SGS_LAUNCH_SWEEP(0, true);
 		else
 			switch ((split_mode >> 8) & 15) {

@@ -334,6 +334,7 @@ const char* sgs_last_error(void) { return g_err.c_str(); }
 int sgs_set_blend_variant(int variant) { return g_default_opt[SGS_OPT_BLEND_VARIANT].exchange(variant); }
 int sgs_set_stage_timing(int enable) { return g_default_opt[SGS_OPT_STAGE_TIMING].exchange(enable); }
 int sgs_set_binning_mode(int mode) { return g_default_opt[SGS_OPT_BINNING_MODE].exchange(mode); }
+void sgs_debug_set_sweep_trace(void* device_words) { sgs::set_sweep_trace(device_words); }
 int sgs_set_backward_mode(int mode) { return g_default_opt[SGS_OPT_BACKWARD_MODE].exchange(mode); }
 
 int sgs_stream_set_option(void* stream, int option, int value)

@@ -80,7 +80,7 @@ hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int varia
 
 // ---- blend_fwd_split.hip (weights pre-pass + streaming accumulate)
 struct SplitArena {   // byte offsets inside the arena chunk
-	size_t counter, nbatches, table, act_id, act_idx, wgt, total;
+	size_t counter, nbatches, table, act_id, act_idx, order, wgt, total;
 	uint32_t capacity;   // work-list slots (1 KB of weights + 4 B id each)
 };
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay);
@@ -89,6 +89,9 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
 				      int split_mode);
+
+// debug: 4 x uint64 per sweep workgroup (begin, end on the 100 MHz steady counter, HW_ID | XCC_ID << 32, batches | tiles << 32)
+void set_sweep_trace(void* device_words);
 
 // ---- blend_fused.hip: the C % 128 == 0 forward blend as one kernel (weights never leave the CU)
 bool blend_forward_fused_eligible(const BlendFwdArgs& a);
