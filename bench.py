@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--views", type=int, default=4,
                     help="views in flight per GPU: a step renders this many views of the scene, one per HIP "
                          "stream, so one view's front-end and host round trip overlap another view's blend")
+    ap.add_argument("--blocking-count", action="store_true",
+                    help="headline with the reference's blocking num_rendered read-back in every forward "
+                         "(default: deferred counts, SGS_OPT_DEFER_COUNT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-arithmetic / backward legs")
     args = ap.parse_args()
@@ -237,16 +240,23 @@ def main():
     pools = [raster.ScratchPool() for _ in range(V)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(V - 1)]
 
-    def render(i):
+    def render(i, deferred=False):
         c = cams[i]
+        fn = raster.rasterize_forward_deferred if deferred else raster.rasterize_forward
         with torch.cuda.stream(streams[i]):
-            return raster.rasterize_forward(
-                s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, empty,
-                c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, empty, 0,
-                c.camera_center, False, False, C, False, pool=pools[i])
+            return fn(s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, empty,
+                      c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, empty, 0,
+                      c.camera_center, False, False, C, False, pool=pools[i])
+
+    DEFER = not args.blocking_count
 
     def step():   # one batch: V views of the scene, all in flight together
-        return [render(i) for i in range(V)]
+        if not DEFER:   # the reference's host pattern: every forward blocks on its num_rendered read-back
+            return [render(i) for i in range(V)]
+        # deferred counts (SGS_OPT_DEFER_COUNT): all V forwards are enqueued without the host waiting for the GPU,
+        # then every frame's counts are checked (a frame that outgrew its capacity guess is rendered again there)
+        pending = [render(i, True) for i in range(V)]
+        return [h.result() for h in pending]
 
     def barrier():
         if world > 1:
@@ -426,6 +436,10 @@ def main():
                        "parallelism": f"views x{world * V}: {V} in flight per GPU on {V} HIP streams, {world} GPU(s), "
                                       f"scene replicated, no collective",
                        "rccl": rccl,
+                       "num_rendered": ("blocking read-back in every forward (the reference's host pattern)" if not DEFER else
+                                        "deferred (SGS_OPT_DEFER_COUNT): buffers sized from the stream's previous frame, counts "
+                                        "checked on the device and on the host once per step; every step's num_rendered is "
+                                        "compared with the serial render (integrity)"),
                        "blend_variant": args.variant,
                        "blend_arithmetic": ("fp32 MFMA, bit-exact" if not split else
                                             "every weight, decision and integer output in contract fp32; the C >= 128 "

@@ -37,6 +37,8 @@ extern "C" {
 #define SGS_EALLOC (-3)   /* allocator callback returned NULL */
 #define SGS_ETRAP (-4)    /* prefiltered=1 but a point was culled (reference: __trap(),
                              CR/cuda_rasterizer/auxiliary.h:156-160) */
+#define SGS_ERETRY (-5)   /* sgs_forward_result: the deferred-count frame did not fit its capacity guess */
+#define SGS_ENOTREADY (-6) /* sgs_forward_result(wait = 0): the counts have not arrived yet */
 
 /* Resizable scratch buffer callback.  Replaces std::function<char*(size_t)>
  * (CR/cuda_rasterizer/rasterizer.h:31-33, built by resizeFunctional,
@@ -221,7 +223,18 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * pair a whole number of 128-byte lines whatever the image width is (BASELINE config 4: width 1297); the padding
  * columns hold unspecified values.  Must be >= width; ignored by the RGB-D variant's depth plane. */
 #define SGS_OPT_OUT_PITCH 4
-#define SGS_OPT_COUNT 5
+/* 1: deferred-count forwards on this stream (inference).  The reference's forward -- and this one by default --
+ * blocks the host once per frame on a device-to-host copy of num_rendered (rasterizer_impl.cu:283), because the
+ * binning buffer is sized from it.  With this option the buffers are sized from the stream's capacity guesses
+ * (1.25 x what its previous frame needed; the first frame of a stream still blocks), the true counts stay on the
+ * device, and a frame that does not fit aborts itself on the device.  sgs_rasterize_forward then returns at once
+ * with the CAPACITY the binning buffer was laid out for; the caller MUST call sgs_forward_result() before it uses
+ * the outputs: 0 = valid (and the true num_rendered), SGS_ERETRY = render that frame again (the guess has grown).
+ * One host thread can so keep several streams full: 1M Gaussians x 512 channels, 4 views in flight:
+ * see DESIGN.md 7.  Binning mode 0 only; ignored under debug; not for frames that will be differentiated (the
+ * backward locates the lists from num_rendered).  2: as 1 with a capacity no frame fits (tests). */
+#define SGS_OPT_DEFER_COUNT 5
+#define SGS_OPT_COUNT 6
 /* value < 0 removes the override (the stream follows the process default again).  Returns the previous override,
  * or 0x7fffffff if there was none. */
 int sgs_stream_set_option(void *stream, int option, int value);
@@ -229,8 +242,14 @@ int sgs_stream_set_option(void *stream, int option, int value);
 #define SGS_STAT_FWD_OVERFLOWS 1   /* split forwards whose work list overflowed (frame rendered by the gated fallback) */
 #define SGS_STAT_BWD_OVERFLOWS 2   /* work-list backwards that overflowed (gradients by the per-chunk fallback) */
 #define SGS_STAT_FORWARDS 3        /* forwards issued on this stream */
-#define SGS_STAT_COUNT 4
+#define SGS_STAT_DEFERRED_FORWARDS 4   /* of those, deferred-count ones */
+#define SGS_STAT_DEFERRED_RETRIES 5    /* deferred-count frames that did not fit (sgs_forward_result: SGS_ERETRY) */
+#define SGS_STAT_COUNT 6
 int sgs_stream_get_stat(void *stream, int stat, uint64_t *out);
+/* The counts of the last forward on `stream` (see SGS_OPT_DEFER_COUNT).  wait != 0: blocks until they have arrived
+ * (that is after the frame's scan, long before its blend); wait == 0: SGS_ENOTREADY if they have not.  After an
+ * ordinary forward: 0 and its num_rendered, immediately. */
+int sgs_forward_result(void *stream, int wait, int *num_rendered);
 /* Frees the context of (current device, stream); returns 1 if there was one. */
 int sgs_stream_release(void *stream);
 

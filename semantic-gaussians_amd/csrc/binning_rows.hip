@@ -124,9 +124,10 @@ hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes,
 // Stage A passes segstart == nullptr: one segment of `total` items.  One workgroup.
 __global__ __launch_bounds__(64) void seg_tables_kernel(int nseg, uint32_t total, uint32_t* __restrict__ segstart,
 							 bool single, uint32_t* __restrict__ chunk0,
-							 uint32_t* __restrict__ grp0)
+							 uint32_t* __restrict__ grp0, const uint32_t* __restrict__ abort)
 {
 	if (threadIdx.x != 0) return;
+	if (abort && *abort != 0u) return;
 	if (single) {
 		segstart[0] = 0u;
 		segstart[1] = total;
@@ -148,8 +149,10 @@ __global__ __launch_bounds__(64) void seg_tables_kernel(int nseg, uint32_t total
 template <bool FROM_RANKS>
 __global__ __launch_bounds__(256) void span_hist_kernel(
 	int nb, int nseg, const uint32_t* __restrict__ segstart, const uint32_t* __restrict__ chunk0,
-	const uint2* __restrict__ items, const uint4* __restrict__ rrec, uint32_t* __restrict__ cmat)
+	const uint2* __restrict__ items, const uint4* __restrict__ rrec, uint32_t* __restrict__ cmat,
+	const uint32_t* __restrict__ abort)
 {
+	if (abort && *abort != 0u) return;
 	extern __shared__ int s_diff[];   // [4 waves][nb + 1]
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -193,8 +196,10 @@ __global__ __launch_bounds__(256) void span_hist_kernel(
 // in-group exclusive prefix over the chunks of a scan group (in place), group total to gtot
 __global__ __launch_bounds__(256) void span_scan_groups_kernel(int nb, int nseg, const uint32_t* __restrict__ chunk0,
 								const uint32_t* __restrict__ grp0,
-								uint32_t* __restrict__ cmat, uint32_t* __restrict__ gtot)
+								uint32_t* __restrict__ cmat, uint32_t* __restrict__ gtot,
+								const uint32_t* __restrict__ abort)
 {
+	if (abort && *abort != 0u) return;
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	const uint32_t G = t / (uint32_t)nb;
 	const int b = (int)(t - G * (uint32_t)nb);
@@ -225,8 +230,9 @@ __global__ __launch_bounds__(256) void span_scan_groups_kernel(int nb, int nseg,
 // 64 contiguous runs, run sums are wave-scanned (stage A has one segment with hundreds of groups).
 __global__ __launch_bounds__(256) void span_scan_lists_kernel(int nb, int nseg, const uint32_t* __restrict__ grp0,
 							       uint32_t* __restrict__ gtot, int seg_stride, int bin_stride,
-							       uint32_t* __restrict__ listlen)
+							       uint32_t* __restrict__ listlen, const uint32_t* __restrict__ abort)
 {
+	if (abort && *abort != 0u) return;
 	const int lane = threadIdx.x & 63;
 	const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (t >= nb * nseg) return;
@@ -257,8 +263,10 @@ __global__ __launch_bounds__(256) void span_scan_lists_kernel(int nb, int nseg, 
 // rasterizer_impl.cu:116-138,313); else starts[t] = start, starts[n] = total.  One workgroup.
 template <bool RANGES>
 __global__ __launch_bounds__(1024) void list_scan_kernel(int n, const uint32_t* __restrict__ len,
-							  uint2* __restrict__ ranges, uint32_t* __restrict__ starts)
+							  uint2* __restrict__ ranges, uint32_t* __restrict__ starts,
+							  const uint32_t* __restrict__ abort)
 {
+	if (abort && *abort != 0u) return;
 	__shared__ uint32_t s_part[1024];
 	const int per = (n + 1023) / 1024;
 	const int t0 = threadIdx.x * per < n ? threadIdx.x * per : n, t1 = (t0 + per < n) ? t0 + per : n;
@@ -290,8 +298,9 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 	const uint32_t* __restrict__ grp0, const uint2* __restrict__ items, const uint4* __restrict__ rrec,
 	const uint32_t* __restrict__ cmat, const uint32_t* __restrict__ gtot, const uint32_t* __restrict__ starts,
 	const uint2* __restrict__ ranges, int seg_stride, int bin_stride, uint2* __restrict__ out_items,
-	uint32_t* __restrict__ point_list)
+	uint32_t* __restrict__ point_list, const uint32_t* __restrict__ abort)
 {
+	if (abort && *abort != 0u) return;
 	extern __shared__ uint32_t s_base[];   // [4 waves][nb]: first position of this chunk in each list
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -357,7 +366,7 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 }
 
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
-			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list)
+			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort)
 {
 	const int ntiles = gx * gy;
 	if (R == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st);
@@ -375,32 +384,32 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	const size_t ldsA = (size_t)4 * (nbA + 1) * 4, ldsB = (size_t)4 * (nbB + 1) * 4;
 
 	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
-	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A);
+	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
 	hipLaunchKernelGGL(span_hist_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A,
-			   (const uint2*)nullptr, rrec, cmat);
+			   (const uint2*)nullptr, rrec, cmat, abort);
 	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grA * nbA + 255) / 256)), dim3(256), 0, st,
-			   nbA, 1, chunk0A, grp0A, cmat, gtot);
+			   nbA, 1, chunk0A, grp0A, cmat, gtot, abort);
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
-			   binlen);
-	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB);
+			   binlen, abort);
+	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort);
 	hipLaunchKernelGGL(span_scatter_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A, grp0A,
 			   (const uint2*)nullptr, rrec, cmat, gtot, segB, (const uint2*)nullptr, 0, 1, items,
-			   (uint32_t*)nullptr);
+			   (uint32_t*)nullptr, abort);
 
 	// ---- stage B: the major instances of each major bin -> per-tile lists
 	const uint32_t chB = R / RCH + (uint32_t)nbA, grB = chB / RGRP + (uint32_t)nbA;   // upper bounds
 	const int seg_stride = major_x ? 1 : gx, bin_stride = major_x ? gx : 1;          // tile = y * gx + x
-	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, nbA, R, segB, false, chunk0B, grp0B);
+	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, nbA, R, segB, false, chunk0B, grp0B, abort);
 	hipLaunchKernelGGL(span_hist_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B, items,
-			   rrec, cmat);
+			   rrec, cmat, abort);
 	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grB * nbB + 255) / 256)), dim3(256), 0, st,
-			   nbB, nbA, chunk0B, grp0B, cmat, gtot);
+			   nbB, nbA, chunk0B, grp0B, cmat, gtot, abort);
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
-			   seg_stride, bin_stride, lens);
-	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, (uint32_t*)nullptr);
+			   seg_stride, bin_stride, lens, abort);
+	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, (uint32_t*)nullptr, abort);
 	hipLaunchKernelGGL(span_scatter_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B,
 			   grp0B, items, rrec, cmat, gtot, (const uint32_t*)nullptr, ranges, seg_stride, bin_stride,
-			   (uint2*)nullptr, point_list);
+			   (uint2*)nullptr, point_list, abort);
 	return hipGetLastError();
 }
 

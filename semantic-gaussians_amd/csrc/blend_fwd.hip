@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void blend_fwd_px1_kernel(
 	const float4* __restrict__ conic_opacity, const float* __restrict__ depths,
 	const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
 	float* __restrict__ out, float* __restrict__ out_depth, int W, int H, int C, int gx,
-	int c_begin, int nchunks, int write_aux, int per_xcd, int total, int pitch)
+	int c_begin, int nchunks, int write_aux, int per_xcd, int total, int pitch, const uint32_t* __restrict__ abort)
 {
+	if (abort && *abort != 0u) return;   // deferred-count forward whose capacity guess was too small (capi.hip)
 	const int b = blockIdx.x;
 	const int v = (b & 7) * per_xcd + (b >> 3);
 	if (v >= total) return;
@@ -183,9 +184,11 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 	const float2* __restrict__ means2D, const float* __restrict__ features,
 	const float4* __restrict__ conic_opacity, const float* __restrict__ bg,
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out, int W,
-	int H, int C, int gx, int nchunks, int per_xcd, int total, const uint32_t* __restrict__ gate, int pitch)
+	int H, int C, int gx, int nchunks, int per_xcd, int total, const uint32_t* __restrict__ gate, int pitch,
+	const uint32_t* __restrict__ abort)
 {
-	if (gate && gate[1] == 0u) return;   // fallback instance: runs only if the split path overflowed
+	if (gate && gate[1] != 1u) return;   // fallback instance: runs only if the split path's work list overflowed (1; 2 = aborted frame)
+	if (abort && *abort != 0u) return;
 	const int b = blockIdx.x;
 	const int v = (b & 7) * per_xcd + (b >> 3);
 	if (v >= total) return;
@@ -303,7 +306,7 @@ static void launch_px1(hipStream_t st, const BlendFwdArgs& a, int c_begin, int n
 	hipLaunchKernelGGL((blend_fwd_px1_kernel<CC, DEPTH, FULL>), dim3(per_xcd * 8), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.depths,
 			   a.bg, a.final_T, a.n_contrib, a.out, a.out_depth, a.W, a.H, a.C, a.gx, c_begin,
-			   nchunks, write_aux, per_xcd, total, a.pitch);
+			   nchunks, write_aux, per_xcd, total, a.pitch, a.abort);
 }
 
 template <int CW, int BATCH>
@@ -313,7 +316,7 @@ static void launch_px4(hipStream_t st, const BlendFwdArgs& a, int nchunks, const
 	const int per_xcd = (total + 7) / 8;
 	hipLaunchKernelGGL((blend_fwd_px4_kernel<CW, BATCH>), dim3(per_xcd * 8), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.bg,
-			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate, a.pitch);
+			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate, a.pitch, a.abort);
 }
 
 // variant: 0 = default (px4 CW=32 for the 128-channel-aligned part, px1 for the rest)

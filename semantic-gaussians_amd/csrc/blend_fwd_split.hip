@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	constexpr bool SWEEP = true;     // parity-major pixel order, closing T * bg pseudo entry, zero padding to 16
 	const int tile = (b & 7) * per_xcd + (b >> 3);
 	if (tile >= ntiles) return;
+	if (counter[1] == 2u) return;   // aborted frame (arena_reset_kernel): the lists do not exist
 	const int tx = tile % gx, ty = tile / gx;
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -441,9 +442,14 @@ __global__ __launch_bounds__(1024) void sweep_plan_kernel(const uint32_t* __rest
 	for (int s = threadIdx.x; s < n; s += 1024) order[s] = (uint32_t)(PLAN_MAX - 1) - (key[s] & 4095u);
 }
 
-constexpr int SEGMAX = 96;   // tiles per sweep (upper bound, the launcher picks the length)
-constexpr int SW_JMAX = 1024; // batch-table window (batches of a segment kept in LDS)
-constexpr int NST = 4;       // ring stages (bundles of NST - 1 batches in flight)
+#ifndef SGS_SEGMAX   // (overridable for A/B builds: LDS per workgroup decides what can share a CU with the sweep)
+#define SGS_SEGMAX 96
+#define SGS_SW_JMAX 1024
+#define SGS_NST 4
+#endif
+constexpr int SEGMAX = SGS_SEGMAX;   // tiles per sweep (upper bound, the launcher picks the length)
+constexpr int SW_JMAX = SGS_SW_JMAX; // batch-table window (batches of a segment kept in LDS)
+constexpr int NST = SGS_NST;         // ring stages (bundles of NST - 1 batches in flight)
 constexpr int LA = NST - 1;
 constexpr int STAGE_BYTES = 8192 + 8192 + 1024;   // features | this parity's weights | ids of the batch LA bundles on
 constexpr int SW_NDMA = 5;   // LDS-DMA instructions per wave per bundle: 2 feature + 2 weight + 1 id
@@ -994,6 +1000,15 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	return a.total;
 }
 
+// counter[0] = work-list slots handed out, counter[1] = 0 ok / 1 the work list overflowed (the gated single-kernel
+// fallback renders the frame) / 2 the frame was aborted before the blend (deferred-count forward whose capacity
+// guess was too small: every blend kernel exits).  Replaces a memset so that the abort word is folded in.
+__global__ void arena_reset_kernel(uint32_t* __restrict__ counter, const uint32_t* __restrict__ abort)
+{
+	counter[0] = 0u;
+	counter[1] = (abort && *abort != 0u) ? 2u : 0u;
+}
+
 static unsigned long long* g_sweep_trace = nullptr;   // debug only (sgs_debug_set_sweep_trace)
 void set_sweep_trace(void* device_words) { g_sweep_trace = (unsigned long long*)device_words; }
 
@@ -1007,7 +1022,8 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	uint32_t* table = (uint32_t*)(arena + lay.table);
 	uint32_t* act_id = (uint32_t*)(arena + lay.act_id);
 	float* wgt = (float*)(arena + lay.wgt);
-	hipError_t e = hipMemsetAsync(counter, 0, 8, st);
+	hipLaunchKernelGGL(arena_reset_kernel, dim3(1), dim3(1), 0, st, counter, a.abort);
+	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 #define SGS_LAUNCH_W(M_, ST_, T0_, NT_)                                                             \
 	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3((((NT_) + 7) / 8) * 8), dim3(256), 0, ST_,    \

@@ -47,6 +47,13 @@ struct StreamCtx {
 	uint32_t* bwd_usage_host = nullptr;
 	hipEvent_t bwd_ev = nullptr;
 	bool bwd_pending = false;
+	// deferred-count forward (SGS_OPT_DEFER_COUNT): capacity guesses for num_rendered / the major-instance count,
+	// the pinned record {num_rendered, major instances, trap flag, abort flag} of the last deferred forward
+	uint32_t L_hint = 0, R_hint = 0;
+	uint32_t* count_host = nullptr;
+	hipEvent_t count_ev = nullptr;
+	bool count_pending = false;
+	int last_num_rendered = 0;
 	uint64_t stat[SGS_STAT_COUNT];
 	StreamCtx()
 	{
@@ -57,6 +64,8 @@ struct StreamCtx {
 	{
 		if (usage_host) (void)hipHostFree(usage_host);
 		if (bwd_usage_host) (void)hipHostFree(bwd_usage_host);
+		if (count_host) (void)hipHostFree(count_host);
+		if (count_ev) (void)hipEventDestroy(count_ev);
 		if (usage_ev) (void)hipEventDestroy(usage_ev);
 		if (bwd_ev) (void)hipEventDestroy(bwd_ev);
 	}
@@ -65,12 +74,12 @@ struct StreamCtx {
 	bool ensure(uint32_t*& words, hipEvent_t& ev)
 	{
 		if (!words) {
-			if (hipHostMalloc((void**)&words, 8, hipHostMallocDefault) != hipSuccess) {
+			if (hipHostMalloc((void**)&words, 16, hipHostMallocDefault) != hipSuccess) {
 				words = nullptr;
 				(void)hipGetLastError();
 				return false;
 			}
-			words[0] = words[1] = 0;
+			words[0] = words[1] = words[2] = words[3] = 0;
 		}
 		if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
 			ev = nullptr;
@@ -153,7 +162,7 @@ struct Carver {
 
 struct GeomLayout {
 	sgs_geometry_layout pub;
-	size_t scan_temp, scan_temp_bytes, trap_flag, total;
+	size_t scan_temp, scan_temp_bytes, trap_flag, count_rec, total;
 	// depth presort of the Gaussians (binning modes 0 and 2)
 	size_t perm, gkeys, counts_sorted, gsort_temp, gsort_temp_bytes;
 	// mode 0: rows | tiles counts of the ranked Gaussians and their inclusive scan
@@ -177,6 +186,7 @@ GeomLayout geom_layout(int P)
 	g.scan_temp_bytes = sgs::scan_temp_bytes(P);
 	g.scan_temp = c.take(g.scan_temp_bytes);
 	g.trap_flag = c.take(4);
+	g.count_rec = c.take(16);   // deferred-count forward: {num_rendered, major instances, trap, abort}
 	g.perm = c.take(p * 4);
 	g.gkeys = c.take(p * 4);
 	g.counts_sorted = c.take(p * 4);
@@ -317,6 +327,31 @@ struct StageTimer {
 	}
 };
 
+// Deferred-count forward: the instance counts stay on the device.  rec = {num_rendered, major instances, trap flag,
+// abort}; abort != 0 (a count exceeds the capacity the buffers were sized for, or the prefiltered trap fired) makes
+// every later kernel of the frame exit.
+__global__ void count_check_kernel(const uint64_t* __restrict__ offs_last, const int* __restrict__ trap_flag,
+				   uint32_t L_cap, uint32_t R_cap, uint32_t* __restrict__ rec)
+{
+	const uint64_t rl = *offs_last;
+	const uint64_t L = rl & 0xffffffffull, R = rl >> 32;
+	const uint32_t trap = (uint32_t)*trap_flag;
+	rec[0] = (uint32_t)L;
+	rec[1] = (uint32_t)R;
+	rec[2] = trap;
+	rec[3] = (L > (uint64_t)L_cap || R > (uint64_t)R_cap || trap != 0u) ? 1u : 0u;
+}
+
+// capacity guess for a count: 1.25 x what the last frame needed, 64k granularity (stable buffer sizes)
+inline uint32_t grow_hint(uint32_t hint, uint32_t used)
+{
+	uint64_t want = (uint64_t)used + used / 4 + 1;
+	want = (want + 0xffffull) & ~0xffffull;
+	if (want > 0x7fffffffull) want = 0x7fffffffull;
+	if ((uint64_t)hint >= want && (uint64_t)hint <= 2 * want) return hint;   // still fits, not wasteful: keep
+	return (uint32_t)want;
+}
+
 #define SGS_CHECK_STAGE(what)                                                             \
 	do {                                                                              \
 		hipError_t e_ = hipGetLastError();                                        \
@@ -345,6 +380,34 @@ int sgs_stream_set_option(void* stream, int option, int value)
 	const int prev = c->opt[option];
 	c->opt[option] = value < 0 ? -1 : value;
 	return prev < 0 ? 0x7fffffff : prev;   // (0x7fffffff: there was no override)
+}
+
+int sgs_forward_result(void* stream, int wait, int* num_rendered)
+{
+	StreamCtx* c = ctx_of(stream);
+	std::lock_guard<std::mutex> lk(c->mu);
+	if (!c->count_pending) {   // the last forward on this stream was an ordinary (blocking) one
+		if (num_rendered) *num_rendered = c->last_num_rendered;
+		return 0;
+	}
+	hipError_t e = wait ? hipEventSynchronize(c->count_ev) : hipEventQuery(c->count_ev);
+	if (e == hipErrorNotReady) {
+		(void)hipGetLastError();
+		return SGS_ENOTREADY;
+	}
+	if (e != hipSuccess) return fail_hip(e, "deferred count");
+	const uint32_t L = c->count_host[0], R = c->count_host[1], trap = c->count_host[2], abort = c->count_host[3];
+	c->count_pending = false;
+	c->L_hint = grow_hint(c->L_hint, L);
+	c->R_hint = grow_hint(c->R_hint, R);
+	c->last_num_rendered = (int)L;
+	if (num_rendered) *num_rendered = (int)L;
+	if (trap) return fail(SGS_ETRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
+	if (abort) {
+		c->stat[SGS_STAT_DEFERRED_RETRIES]++;
+		return fail(SGS_ERETRY, "deferred-count forward: the frame needs more room than the capacity guess; render it again");
+	}
+	return 0;
 }
 
 int sgs_stream_get_stat(void* stream, int stat, uint64_t* out)
@@ -510,20 +573,57 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	if (e != hipSuccess) return fail_hip(e, "inclusive scan");
 	SGS_CHECK_STAGE("inclusive scan");
 
-	// the one blocking read-back of the forward (rasterizer_impl.cu:283)
-	int host_vals[2] = {0, 0};
-	uint64_t host_rl = 0;   // mode 0: row instances << 32 | num_rendered
-	if (rows) e = hipMemcpyAsync(&host_rl, offs64 + (P - 1), 8, hipMemcpyDeviceToHost, st);
-	else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess) e = hipStreamSynchronize(st);
-	if (e != hipSuccess) return fail_hip(e, "num_rendered read-back");
-	if (host_vals[1] != 0)
-		return fail(SGS_ETRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
-	const uint32_t L = rows ? (uint32_t)(host_rl & 0xffffffffull) : (uint32_t)host_vals[0];
-	const uint32_t Rrows = rows ? (uint32_t)(host_rl >> 32) : 0u;
-	if (rows && (host_rl & 0xffffffffull) > 0x7fffffffull) return fail(SGS_EINVAL, "num_rendered exceeds 2^31-1");
-	if (L > 0x7fffffffu) return fail(SGS_EINVAL, "num_rendered exceeds 2^31-1");
+	// The instance counts.  Default: the one blocking read-back of the forward (rasterizer_impl.cu:283).
+	// SGS_OPT_DEFER_COUNT (binning mode 0, not under debug): nothing is read back.  The buffers and grids are sized
+	// from this stream's capacity guesses (1.25 x what its previous frame needed), the true counts are checked
+	// against them on the device (count_check_kernel: a frame that does not fit aborts itself), copied to a pinned
+	// record and reported by sgs_forward_result().  The host never waits for the GPU inside the call, so one host
+	// thread can keep several streams fed.  The return value is then the CAPACITY the binning buffer was laid out
+	// for, not num_rendered -- such a forward cannot be handed to sgs_rasterize_backward.
+	const int defer_opt = cx->option(SGS_OPT_DEFER_COUNT);
+	if (cx->count_pending && cx->count_ev && hipEventQuery(cx->count_ev) == hipSuccess) {
+		// a deferred frame nobody asked about: still learn from it
+		cx->L_hint = grow_hint(cx->L_hint, cx->count_host[0]);
+		cx->R_hint = grow_hint(cx->R_hint, cx->count_host[1]);
+		cx->count_pending = false;
+	}
+	(void)hipGetLastError();
+	const bool defer = defer_opt > 0 && rows && !debug && (defer_opt == 2 || (cx->L_hint > 0 && cx->R_hint > 0)) &&
+			   cx->ensure(cx->count_host, cx->count_ev);
+	uint32_t L = 0, Rrows = 0;
+	const uint32_t* abort_word = nullptr;
+	if (defer) {
+		L = defer_opt == 2 ? 4096u : cx->L_hint;   // (2: tests -- a capacity no real frame fits, exercises the abort)
+		Rrows = defer_opt == 2 ? 4096u : cx->R_hint;
+		uint32_t* rec = (uint32_t*)(gchunk + gl.count_rec);
+		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, st, offs64 + (P - 1), trap_flag, L, Rrows, rec);
+		e = hipMemcpyAsync(cx->count_host, rec, 16, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipEventRecord(cx->count_ev, st);
+		if (e != hipSuccess) return fail_hip(e, "deferred count record");
+		cx->count_pending = true;
+		cx->stat[SGS_STAT_DEFERRED_FORWARDS]++;
+		abort_word = rec + 3;
+	} else {
+		int host_vals[2] = {0, 0};
+		uint64_t host_rl = 0;   // mode 0: row instances << 32 | num_rendered
+		if (rows) e = hipMemcpyAsync(&host_rl, offs64 + (P - 1), 8, hipMemcpyDeviceToHost, st);
+		else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (e != hipSuccess) return fail_hip(e, "num_rendered read-back");
+		if (host_vals[1] != 0)
+			return fail(SGS_ETRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
+		L = rows ? (uint32_t)(host_rl & 0xffffffffull) : (uint32_t)host_vals[0];
+		Rrows = rows ? (uint32_t)(host_rl >> 32) : 0u;
+		if (rows && (host_rl & 0xffffffffull) > 0x7fffffffull) return fail(SGS_EINVAL, "num_rendered exceeds 2^31-1");
+		if (L > 0x7fffffffu) return fail(SGS_EINVAL, "num_rendered exceeds 2^31-1");
+		if (rows) {
+			cx->L_hint = grow_hint(cx->L_hint, L);
+			cx->R_hint = grow_hint(cx->R_hint, Rrows);
+		}
+		cx->count_pending = false;
+		cx->last_num_rendered = (int)L;
+	}
 	tm.mark();
 
 	const int sort_bits = 32 + (int)higher_msb((uint32_t)ntiles);
@@ -531,7 +631,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	const int variant = cx->option(SGS_OPT_BLEND_VARIANT);
 	// variants 32 / 33: the fused single-kernel blend (split-bf16 / exact fp32), bits [11:8] = segment length / 2
 	// 32-35: the experimental single-kernel blends (contiguous output only)
-	const bool want_fused = (variant & 0xff) >= 32 && (variant & 0xff) <= 35 &&
+	const bool want_fused = !defer && (variant & 0xff) >= 32 && (variant & 0xff) <= 35 &&
 				(cx->option(SGS_OPT_OUT_PITCH) <= 0 || cx->option(SGS_OPT_OUT_PITCH) == width);
 	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
@@ -575,7 +675,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		tm.mark();   // (no separate emission stage)
 		e = sgs::launch_row_binning(st, P, Rrows, gx, gy, (const uint4*)(gchunk + gl.rrec), (uint2*)keys_u,
 					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
-					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list);
+					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list,
+					    abort_word);
 		if (e != hipSuccess) return fail_hip(e, "row binning");
 		SGS_CHECK_STAGE("row binning");
 		tm.mark();
@@ -634,6 +735,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.out = out_color;
 	a.out_depth = out_depth;
 	a.pitch = cx->option(SGS_OPT_OUT_PITCH) > 0 ? cx->option(SGS_OPT_OUT_PITCH) : width;
+	a.abort = abort_word;
 	if (a.pitch < width) return fail(SGS_EINVAL, "output pitch smaller than the image width");
 	if (want_fused && (variant & 0xff) >= 34 && sgs::blend_forward_fused_pc_eligible(a)) {
 		tm.mark();

@@ -46,8 +46,10 @@ hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes,
 				  uint64_t* offs64, uint4* rrec);
 void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, size_t* cmat_words,
 			 size_t* gtot_words, size_t* len_words);
+// R may be an upper bound of the major-instance count (grids and scratch are sized from it, the kernels read the
+// actual counts from device tables); abort: optional device word, != 0 -> every kernel exits
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
-			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list);
+			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort = nullptr);
 void launch_reconstruct_keys_ranges(hipStream_t st, int ntiles, const uint2* ranges, const uint32_t* point_list,
 				    const float* depths, uint64_t* keys_sorted);
 size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit);
@@ -72,6 +74,7 @@ struct BlendFwdArgs {
 	float* out;                  // (C,H,W), rows `pitch` floats apart (pitch >= W; pitch == W: contiguous)
 	float* out_depth;            // (H*W) or null
 	int pitch;                   // output row pitch in pixels
+	const uint32_t* abort;       // optional device word: != 0 -> every blend kernel exits (deferred-count forward, capi.hip)
 };
 // gate: optional device word; when non-null the 128-channel-aligned kernels exit unless
 // *gate != 0 (used as the arena-overflow fallback of the split path).

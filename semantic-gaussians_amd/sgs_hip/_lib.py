@@ -39,11 +39,13 @@ EXPORTS = (
     "sgs_image_layout_of", "sgs_sort_bits", "sgs_debug_expf", "sgs_debug_sorted_keys", "sgs_set_blend_variant",
     "sgs_set_stage_timing", "sgs_get_stage_ms", "sgs_set_binning_mode", "sgs_set_backward_mode", "sgs_fusion_compute_mapping", "sgs_fusion_accumulate",
     "sgs_stream_set_option", "sgs_stream_get_stat", "sgs_stream_release", "sgs_debug_set_sweep_trace",
+    "sgs_forward_result",
 )
 
 # sgs_stream_set_option / sgs_stream_get_stat selectors (include/sgs_raster.h)
-OPT_BLEND_VARIANT, OPT_BINNING_MODE, OPT_BACKWARD_MODE, OPT_STAGE_TIMING, OPT_OUT_PITCH = 0, 1, 2, 3, 4
-STAT_ARENA_SLOTS, STAT_FWD_OVERFLOWS, STAT_BWD_OVERFLOWS, STAT_FORWARDS = 0, 1, 2, 3
+OPT_BLEND_VARIANT, OPT_BINNING_MODE, OPT_BACKWARD_MODE, OPT_STAGE_TIMING, OPT_OUT_PITCH, OPT_DEFER_COUNT = 0, 1, 2, 3, 4, 5
+STAT_ARENA_SLOTS, STAT_FWD_OVERFLOWS, STAT_BWD_OVERFLOWS, STAT_FORWARDS, STAT_DEFERRED_FORWARDS, STAT_DEFERRED_RETRIES = 0, 1, 2, 3, 4, 5
+ERETRY, ENOTREADY = -5, -6
 
 _lib = None
 
@@ -111,6 +113,8 @@ def load():
     lib.sgs_fusion_compute_mapping.argtypes = [i, p, p, C.POINTER(C.c_double), i, i, i, C.c_double, i, p, p, p, p, p]
     lib.sgs_fusion_accumulate.restype = i
     lib.sgs_fusion_accumulate.argtypes = [i, i, p, i, i, p, p, p, p]
+    lib.sgs_forward_result.restype = i
+    lib.sgs_forward_result.argtypes = [p, i, C.POINTER(i)]
     lib.sgs_debug_set_sweep_trace.restype = None
     lib.sgs_debug_set_sweep_trace.argtypes = [p]
     lib.sgs_get_stage_ms.restype = i

@@ -65,7 +65,9 @@ def render_views_pipelined(render_fn, views, in_flight=2, device=None):
     kernels, another view's blend keeps the memory system busy (cfg3 on MI355X: 2.1 -> 1.8 ms per view).
 
     `render_fn(view, slot)` must enqueue on the CURRENT stream (the rasteriser does) and use
-    per-slot resources for anything it keeps across calls (e.g. `ScratchPool` number `slot`).
+    per-slot resources for anything it keeps across calls (e.g. `ScratchPool` number `slot`).  It may return
+    `raster.rasterize_forward_deferred(...)` handles: then the host never waits for the GPU while it enqueues
+    (cfg3: 1.47 -> see DESIGN.md 7 ms per view with four in flight); they are resolved here, one frame per slot behind.
     Results are returned in view order after a device synchronize."""
     if not torch.cuda.is_available():
         return [render_fn(v, 0) for v in views]
@@ -80,9 +82,20 @@ def render_views_pipelined(render_fn, views, in_flight=2, device=None):
     for st in streams[1:]:
         st.wait_stream(streams[0])   # inputs produced on the caller's stream are visible to the others
     out = []
+    pending = [None] * n   # per slot: index of a deferred-count forward (raster.rasterize_forward_deferred) not yet resolved
     for i, v in enumerate(views):
-        with torch.cuda.stream(streams[i % n]):
-            out.append(render_fn(v, i % n))
+        slot = i % n
+        if pending[slot] is not None:   # before the slot's state buffers are handed to the next frame
+            out[pending[slot]] = out[pending[slot]].result()
+            pending[slot] = None
+        with torch.cuda.stream(streams[slot]):
+            r = render_fn(v, slot)
+        out.append(r)
+        if hasattr(r, "result") and hasattr(r, "layout_count"):
+            pending[slot] = i
+    for j in pending:
+        if j is not None:
+            out[j] = out[j].result()
     for st in streams[1:]:
         streams[0].wait_stream(st)
     torch.cuda.synchronize(device)

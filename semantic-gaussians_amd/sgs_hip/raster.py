@@ -147,6 +147,53 @@ def _check_bg(bg, Cn):
     return pad
 
 
+class DeferredForward:
+    """A forward whose instance counts stayed on the device (SGS_OPT_DEFER_COUNT, include/sgs_raster.h): the call
+    that made it did not wait for the GPU.  result() -- call it on the host thread that made the forward, before the
+    outputs are used -- waits for the counts (they arrive after the frame's scan, long before its blend) and returns
+    the same tuple rasterize_forward returns, with the true num_rendered; a frame that did not fit this stream's
+    capacity guess is rendered again the ordinary way (the guess has grown by then).  Inference only: the
+    binning buffer is laid out for `layout_count` (>= num_rendered) entries, which rasterize_backward cannot know."""
+
+    def __init__(self, args, kwargs, stream, out):
+        self._args, self._kwargs, self._stream, self._out = args, kwargs, stream, out
+        self.layout_count = out[0]
+        self.retried = False
+
+    def result(self):
+        if self._args is None:
+            return self._out
+        lib = _lib.load()
+        n = C.c_int(0)
+        rc = lib.sgs_forward_result(C.c_void_p(self._stream.cuda_stream), 1, C.byref(n))
+        if rc == _lib.ERETRY:
+            with torch.cuda.stream(self._stream):
+                self._out = rasterize_forward(*self._args, **self._kwargs)
+            self.retried = True
+            self.layout_count = self._out[0]
+        else:
+            _lib.check(rc, "rasterize_gaussians failed")
+            self._out = (int(n.value),) + tuple(self._out[1:])
+        self._args = self._kwargs = None
+        return self._out
+
+
+def rasterize_forward_deferred(*args, **kwargs):
+    """rasterize_forward without the host waiting for the GPU: -> DeferredForward.  The first frame of a stream is an
+    ordinary (blocking) forward -- it is where the capacity guesses come from."""
+    dev = args[1].device
+    stream = torch.cuda.current_stream(dev)
+    lib = _lib.load()
+    sp = C.c_void_p(stream.cuda_stream)
+    with torch.cuda.device(dev):
+        prev = lib.sgs_stream_set_option(sp, _lib.OPT_DEFER_COUNT, int(kwargs.pop("_defer_mode", 1)))
+        try:
+            out = rasterize_forward(*args, **kwargs)
+        finally:
+            lib.sgs_stream_set_option(sp, _lib.OPT_DEFER_COUNT, -1 if prev == 0x7fffffff else prev)
+    return DeferredForward(args, kwargs, stream, out)
+
+
 def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                       image_width, sh, degree, campos, prefiltered, debug, num_channels,

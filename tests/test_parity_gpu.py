@@ -596,3 +596,85 @@ def test_output_pitch_option(orc, C, W, H):
         raster.OUTPUT_PITCH_ALIGN = 0
     fw = oracle_forward(orc, scene, cam)
     assert np.array_equal(want[15].cpu().numpy(), fw["out"])
+
+
+def _fwd_args(scene, cam, want_depth=False):
+    s, c = scene.to(DEV), cam.to(DEV)
+    e = torch.Tensor([])
+    Cn = s.features.shape[1]
+    return (s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e, c.world_view_transform,
+            c.full_proj_transform, c.tanfovx, c.tanfovy, c.image_height, c.image_width, e, 0, c.camera_center,
+            False, False, Cn, want_depth)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,want_depth", [(128, False), (160, False), (16, False), (3, True)])
+def test_deferred_count_forward_matches_blocking(C, want_depth):
+    """SGS_OPT_DEFER_COUNT: the forward that never reads num_rendered back (buffers sized from the stream's previous
+    frame, counts checked on the device) returns the blocking forward's bits -- feature map, depth, radii, final_T,
+    n_contrib -- and its num_rendered; the first deferred call of a stream is an ordinary one (no guess yet); a frame
+    that outgrows the guess aborts on the device and is rendered again; an all-culled frame works."""
+    from sgs_hip import raster, _lib
+    st = torch.cuda.Stream(DEV)   # a fresh stream: no capacity guess yet
+    scene, cam = small_scene(P=3000, C=C, W=200, H=136, fx=120.0, seed=11 + C)
+    args = _fwd_args(scene, cam, want_depth)
+    H, W = 136, 200
+    with torch.cuda.stream(st):
+        want = raster.rasterize_forward(*args)
+        iv = raster.image_views(want[5], W, H)
+        want_T, want_nc = iv["final_T"].clone(), iv["n_contrib"].clone()
+        want_color, want_depth_map = want[1].clone(), (want[6].clone() if want_depth else None)
+        base = raster.stream_stat(_lib.STAT_DEFERRED_FORWARDS)
+        for k in range(3):
+            h = raster.rasterize_forward_deferred(*args)
+            assert h.layout_count >= want[0]
+            out = h.result()
+            assert not h.retried and out[0] == want[0]
+            assert torch.equal(out[1], want_color) and torch.equal(out[2], want[2])
+            iv = raster.image_views(out[5], W, H)
+            assert torch.equal(iv["final_T"], want_T) and torch.equal(iv["n_contrib"], want_nc)
+            if want_depth:
+                assert torch.equal(out[6], want_depth_map)
+        assert raster.stream_stat(_lib.STAT_DEFERRED_FORWARDS) == base + 3
+        # a capacity no frame fits: aborted on the device, rendered again by result()
+        h = raster.rasterize_forward_deferred(*args, _defer_mode=2)
+        out = h.result()
+        assert h.retried and out[0] == want[0] and torch.equal(out[1], want_color)
+        assert raster.stream_stat(_lib.STAT_DEFERRED_RETRIES) >= 1
+        # a much larger frame on the same stream outgrows the guess learnt above
+        big, bcam = small_scene(P=40000, C=C, W=200, H=136, fx=120.0, seed=5)
+        big = big._replace(scales=big.scales * 1.5)
+        bargs = _fwd_args(big, bcam, want_depth)
+        bwant = raster.rasterize_forward(*_fwd_args(big, bcam, want_depth))
+        bcolor = bwant[1].clone()
+        raster.rasterize_forward(*args)   # (the guess follows the last frame: small again)
+        h = raster.rasterize_forward_deferred(*bargs)
+        out = h.result()
+        assert out[0] == bwant[0] and torch.equal(out[1], bcolor)
+        if bwant[0] > 2 * want[0] + (1 << 17):
+            assert h.retried
+        # nothing visible
+        behind = scene._replace(means3D=scene.means3D * torch.tensor([1.0, 1.0, -1.0]))
+        h = raster.rasterize_forward_deferred(*_fwd_args(behind, cam, want_depth))
+        out = h.result()
+        assert out[0] == 0 and (out[2] == 0).all()
+        assert torch.equal(out[1], scene.bg.to(DEV)[:C, None, None].expand(C, H, W))
+        raster.release_stream()
+
+
+@pytest.mark.gpu
+def test_pipelined_views_with_deferred_counts():
+    """render_views_pipelined with deferred-count forwards: same images as serial blocking rendering."""
+    from sgs_hip import raster, dist as sdist
+    scene, cam = small_scene(P=6000, C=128, W=256, H=160, fx=140.0, seed=3)
+    args = _fwd_args(scene, cam)
+    want = raster.rasterize_forward(*args)[1].clone()
+    pools = [raster.ScratchPool() for _ in range(3)]
+
+    def fn(v, slot):
+        return raster.rasterize_forward_deferred(*args, pool=pools[slot])
+
+    outs = sdist.render_views_pipelined(fn, list(range(10)), in_flight=3)
+    assert len(outs) == 10
+    for o in outs:
+        assert isinstance(o, tuple) and torch.equal(o[1], want)
