@@ -290,6 +290,10 @@ int sgs_set_binning_mode(int mode);
  * gradient entry of the float64 oracle (tests).  Returns the previous mode. */
 int sgs_set_backward_mode(int mode);
 int sgs_get_stage_ms(float *ms7);
+/* The depth presort of the forward (csrc/depth_sort.hip) on a bare array of 32-bit keys: perm[r] = index of the
+ * r-th smallest key, equal keys in index order (tests).  With keys / perm / scratch NULL: returns the scratch
+ * bytes needed for P keys. */
+long long sgs_debug_depth_sort(int P, const unsigned *keys, unsigned *perm, void *scratch, void *stream);
 /* Debug (tools/sweep_trace.py): device buffer of 4 x uint64 per workgroup of the accumulate sweep, filled by the
  * next forwards with (begin, end) on the 100 MHz steady counter, HW_ID | XCC_ID << 32, batches | tiles << 32;
  * NULL switches the trace off.  Process-wide, not for production use. */

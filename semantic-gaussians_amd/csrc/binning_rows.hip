@@ -111,11 +111,12 @@ size_t scan64_temp_bytes(int P)
 
 hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes, int P, const uint32_t* perm,
 				  const int* radii, const float2* means2D, int gx, int gy, uint64_t* counts64,
-				  uint64_t* offs64, uint4* rrec)
+				  uint64_t* offs64, uint4* rrec, bool counts_done)
 {
 	const int major_x = gx >= gy;
-	hipLaunchKernelGGL(span_counts_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, perm, radii, means2D,
-			   gx, gy, major_x, counts64, rrec);
+	if (!counts_done)
+		hipLaunchKernelGGL(span_counts_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, perm, radii, means2D,
+				   gx, gy, major_x, counts64, rrec);
 	return rocprim::inclusive_scan(temp, temp_bytes, (const uint64_t*)counts64, offs64, (size_t)P,
 				       rocprim::plus<uint64_t>(), st);
 }

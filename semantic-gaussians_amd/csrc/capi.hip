@@ -163,6 +163,8 @@ struct Carver {
 struct GeomLayout {
 	sgs_geometry_layout pub;
 	size_t scan_temp, scan_temp_bytes, trap_flag, count_rec, total;
+	size_t ds;                     // depth_sort.hip scratch, directly behind trap_flag's 128 bytes (one memset clears both)
+	sgs::DepthSortLayout ds_lay;
 	// depth presort of the Gaussians (binning modes 0 and 2)
 	size_t perm, gkeys, counts_sorted, gsort_temp, gsort_temp_bytes;
 	// mode 0: rows | tiles counts of the ranked Gaussians and their inclusive scan
@@ -185,8 +187,10 @@ GeomLayout geom_layout(int P)
 	g.pub.point_offsets = c.take(p * 4);
 	g.scan_temp_bytes = sgs::scan_temp_bytes(P);
 	g.scan_temp = c.take(g.scan_temp_bytes);
-	g.trap_flag = c.take(4);
 	g.count_rec = c.take(16);   // deferred-count forward: {num_rendered, major instances, trap, abort}
+	g.trap_flag = c.take(128);
+	sgs::depth_sort_layout(P, &g.ds_lay);
+	g.ds = c.take(g.ds_lay.total);   // (128-aligned: starts right behind trap_flag; its count matrices come first)
 	g.perm = c.take(p * 4);
 	g.gkeys = c.take(p * 4);
 	g.counts_sorted = c.take(p * 4);
@@ -369,6 +373,16 @@ const char* sgs_last_error(void) { return g_err.c_str(); }
 int sgs_set_blend_variant(int variant) { return g_default_opt[SGS_OPT_BLEND_VARIANT].exchange(variant); }
 int sgs_set_stage_timing(int enable) { return g_default_opt[SGS_OPT_STAGE_TIMING].exchange(enable); }
 int sgs_set_binning_mode(int mode) { return g_default_opt[SGS_OPT_BINNING_MODE].exchange(mode); }
+long long sgs_debug_depth_sort(int P, const unsigned* keys, unsigned* perm, void* scratch, void* stream)
+{
+	if (P < 0) return fail(SGS_EINVAL, "bad size");
+	sgs::DepthSortLayout lay;
+	sgs::depth_sort_layout(P, &lay);
+	if (!keys || !perm || !scratch) return (long long)lay.total + 128;   // size query
+	const hipError_t e = sgs::launch_depth_sort_standalone((hipStream_t)stream, P, lay, align_ptr((char*)scratch), keys, perm);
+	if (e != hipSuccess) return fail_hip(e, "depth sort");
+	return 0;
+}
 void sgs_debug_set_sweep_trace(void* device_words) { sgs::set_sweep_trace(device_words); }
 int sgs_set_backward_mode(int mode) { return g_default_opt[SGS_OPT_BACKWARD_MODE].exchange(mode); }
 
@@ -531,35 +545,45 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	int* trap_flag = (int*)(gchunk + gl.trap_flag);
 	if (radii == nullptr) radii = radii_int;
 
-	hipError_t e = hipMemsetAsync(trap_flag, 0, 4, st);
+	// binning mode 0: sort the P Gaussians by depth bits and emit instances in that order, so
+	// that the big instance sort only has to be stable on the tile bits (binning.hip)
+	const int bmode = cx->option(SGS_OPT_BINNING_MODE);
+	const bool presort = bmode == 0 || bmode == 2 || bmode == 3;
+	const bool own_sort = presort && bmode != 3;   // depth_sort.hip (3 = mode 0 with the library radix sort, for A/B runs)
+	// one clear: the trap flag and, right behind it, the depth sort's count matrices (filled by preprocess)
+	hipError_t e = hipMemsetAsync(trap_flag, 0, own_sort ? 128 + gl.ds_lay.counts_bytes : 4, st);
 	if (e != hipSuccess) return fail_hip(e, "memset");
+	uint32_t* ds_cnt0 = own_sort ? (uint32_t*)(gchunk + gl.ds + gl.ds_lay.counts) : nullptr;
+	uint32_t* ds_gcnt0 = own_sort ? ds_cnt0 + (size_t)gl.ds_lay.tiles * 256 : nullptr;
 
 	tm.mark();
 	sgs::launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities,
 				   shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos,
 				   width, height, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy,
 				   prefiltered, num_channels, radii, means2D, depths, cov3D, rgb, clamped,
-				   conic_opacity, tiles_touched, trap_flag);
+				   conic_opacity, tiles_touched, trap_flag, ds_cnt0, ds_gcnt0);
 	SGS_CHECK_STAGE("preprocess");
 	tm.mark();
-	// binning mode 0: sort the P Gaussians by depth bits and emit instances in that order, so
-	// that the big instance sort only has to be stable on the tile bits (binning.hip)
-	const int bmode = cx->option(SGS_OPT_BINNING_MODE);
-	const bool presort = bmode == 0 || bmode == 2;
 	// mode 0: per-tile lists from span partitions (binning_rows.hip); its per-wave bin tables live in LDS,
 	// so absurdly long grid axes (> 32k pixels) take the mode-2 path
-	const bool rows = bmode == 0 && gx <= 2048 && gy <= 2048;
+	const bool rows = (bmode == 0 || bmode == 3) && gx <= 2048 && gy <= 2048;
 	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
 	uint64_t* offs64 = (uint64_t*)(gchunk + gl.offs64);
 	if (presort) {
-		e = sgs::launch_gaussian_depth_sort(st, gchunk + gl.gsort_temp, gl.gsort_temp_bytes,
-						    (const uint32_t*)depths, (uint32_t*)(gchunk + gl.gkeys),
-						    perm, P);
+		sgs::DepthSortSpanOut span{radii, means2D, gx, gy, gx >= gy, (uint64_t*)(gchunk + gl.counts64),
+					   (uint4*)(gchunk + gl.rrec)};
+		if (own_sort)
+			e = sgs::launch_depth_sort(st, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm,
+						   rows ? &span : nullptr);
+		else
+			e = sgs::launch_gaussian_depth_sort(st, gchunk + gl.gsort_temp, gl.gsort_temp_bytes,
+							    (const uint32_t*)depths, (uint32_t*)(gchunk + gl.gkeys),
+							    perm, P);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
 		if (rows) {
 			e = sgs::launch_row_counts_scan(st, gchunk + gl.scan64_temp, gl.scan64_temp_bytes, P, perm, radii,
 							means2D, gx, gy, (uint64_t*)(gchunk + gl.counts64), offs64,
-							(uint4*)(gchunk + gl.rrec));
+							(uint4*)(gchunk + gl.rrec), own_sort);
 		} else {
 			uint32_t* counts_sorted = (uint32_t*)(gchunk + gl.counts_sorted);
 			sgs::launch_gather_counts(st, P, perm, tiles_touched, counts_sorted);

@@ -1,0 +1,293 @@
+// depth_sort.hip -- the depth presort of the Gaussians (binning modes 0 and 2): perm[r] = index of the Gaussian
+// of depth rank r, ties in index order.  Same result as the stable 32-bit radix sort of (depth bits, index) the
+// reference's 64-bit instance sort implies (CR/cuda_rasterizer/rasterizer_impl.cu:297-307 sorts tile << 32 | depth
+// with the Gaussian index as the stable tie-break).
+//
+// Why not the library sort.  rocPRIM's onesweep on 1M keys is 5 kernels + 9 buffer fills = 0.19 ms of a 1.7 ms
+// frame, all of it launch / latency bound (profiles/r02h_kernel_stats_views1.txt).  This one is seven small kernels
+// and no fill of its own, built for this size class (P ~ 10^5 .. 10^7):
+//   * least-significant-digit radix sort, 8-bit digits, a workgroup per tile of 4096 keys;
+//   * where a workgroup's keys go needs, per digit, the number of keys with that digit in all EARLIER tiles.  There is
+//     no look-back chain and no spinning: the count matrix cnt[tile][digit] of a pass is written by a counting
+//     kernel in front of it (pass 0's by the kernel that produces the keys, preprocess.hip).  A second matrix per
+//     group of 32 tiles keeps the column sums short: a workgroup reads <= groups + 31 rows of 1 KB.
+//   * inside a tile: a wave owns 1024 consecutive keys, 64 per step; the keys of a step that share a digit are found
+//     with eight ballots (no match_any on gfx9), their rank is a popcount, one lane per digit advances the wave's
+//     LDS counter; the tile is reordered through LDS so that the scatter writes runs of consecutive addresses.
+// Deterministic (atomics only add counts), stable, no inter-workgroup waiting.
+#include "sgs_kernels.h"
+
+namespace sgs {
+
+namespace {
+
+constexpr int DS_ITEMS = DS_TILE / 256;   // keys per thread
+
+// exclusive scan of one value per thread over the 256 threads of the workgroup; *total = sum
+__device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t* s_tmp, uint32_t* total)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t incl = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+		if (lane >= o) incl += u;
+	}
+	if (lane == 63) s_tmp[wave] = incl;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		const uint32_t x = s_tmp[w];
+		if (w < wave) base += x;
+		tot += x;
+	}
+	__syncthreads();   // s_tmp may be reused
+	if (total) *total = tot;
+	return base + incl - v;
+}
+
+} // namespace
+
+// PASS 0 reads the keys where preprocess left them and takes the element's index as its value; the last pass writes
+// only the values (= perm).
+// SPAN (last pass, binning mode 0): the rank's record and span counts for binning_rows.hip are written here, where
+// (rank, Gaussian) is known, instead of by a kernel of their own (span_counts_kernel).
+template <int PASS, bool SPAN>
+__global__ __launch_bounds__(256) void depth_sort_pass_kernel(
+	int P, int groups, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+	uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ cnt,
+	const uint32_t* __restrict__ gcnt, DepthSortSpanOut so)
+{
+	constexpr int SHIFT = 8 * PASS;
+	const int k = blockIdx.x;
+	const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	__shared__ uint32_t s_hist[4][256];   // per wave: keys per digit, then the wave's start inside the tile's digit run
+	__shared__ uint32_t s_base[256];      // output position of the tile's first key of each digit
+	__shared__ uint32_t s_excl[256];      // start of each digit's run inside the reordered tile
+	__shared__ uint32_t s_tmp[4];
+	__shared__ uint32_t s_keys[DS_TILE], s_vals[DS_TILE];
+
+#pragma unroll
+	for (int w = 0; w < 4; w++) s_hist[w][t] = 0u;
+
+	// ---- this tile's keys: element (wave, i, lane) = index  k * 4096 + wave * 1024 + i * 64 + lane
+	const uint32_t first = (uint32_t)k * DS_TILE + (uint32_t)wave * (DS_TILE / 4) + (uint32_t)lane;
+	uint32_t key[DS_ITEMS], val[DS_ITEMS];
+#pragma unroll
+	for (int i = 0; i < DS_ITEMS; i++) {
+		const uint32_t idx = first + 64u * i;
+		const bool ok = idx < (uint32_t)P;
+		key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+		val[i] = PASS == 0 ? idx : (ok ? vals_in[idx] : 0u);
+	}
+
+	// ---- where the tile's keys of digit d start in the output: all keys with a smaller digit, plus the keys of
+	// digit d in earlier tiles (whole groups from gcnt, the tiles of this tile's own group from cnt)
+	{
+		const int grp = k / DS_GRP;
+		uint32_t tot = 0, pre = 0;
+		for (int g = 0; g < groups; g++) {
+			const uint32_t c = gcnt[(size_t)g * 256 + t];
+			tot += c;
+			pre += g < grp ? c : 0u;
+		}
+		for (int kk = grp * DS_GRP; kk < k; kk++) pre += cnt[(size_t)kk * 256 + t];
+		const uint32_t start = wg_scan256(tot, s_tmp, nullptr);
+		s_base[t] = start + pre;
+	}
+	__syncthreads();   // s_hist zeroed (wg_scan256 has barriers too; this one is for clarity)
+
+	// ---- rank of every key among the keys of its wave with the same digit (wave order = (i, lane))
+	uint32_t rank[DS_ITEMS];
+	const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+	for (int i = 0; i < DS_ITEMS; i++) {
+		const bool ok = first + 64u * i < (uint32_t)P;
+		const uint32_t d = (key[i] >> SHIFT) & 255u;
+		unsigned long long m = __ballot(ok);
+#pragma unroll
+		for (int b = 0; b < 8; b++) {
+			const unsigned long long bal = __ballot((d >> b) & 1u);
+			m &= ((d >> b) & 1u) ? bal : ~bal;
+		}
+		// (lanes that are not ok: m is meaningless for them and they do not take part)
+		const uint32_t before = (uint32_t)__popcll(m & below);
+		uint32_t old = 0;
+		if (ok && before == 0u) {   // first lane of its digit: advance the wave's counter
+			old = s_hist[wave][d];
+			s_hist[wave][d] = old + (uint32_t)__popcll(m);
+		}
+		const int leader = ok ? (int)__builtin_ctzll(m) : lane;
+		old = (uint32_t)__shfl((int)old, leader);
+		rank[i] = old + before;
+	}
+	__syncthreads();
+
+	// ---- per digit: the waves' starts inside the digit's run, the run's start inside the tile
+	{
+		const uint32_t h0 = s_hist[0][t], h1 = s_hist[1][t], h2 = s_hist[2][t], h3 = s_hist[3][t];
+		s_hist[0][t] = 0u;
+		s_hist[1][t] = h0;
+		s_hist[2][t] = h0 + h1;
+		s_hist[3][t] = h0 + h1 + h2;
+		s_excl[t] = wg_scan256(h0 + h1 + h2 + h3, s_tmp, nullptr);
+	}
+	__syncthreads();
+
+	// ---- reorder the tile in LDS
+#pragma unroll
+	for (int i = 0; i < DS_ITEMS; i++) {
+		if (first + 64u * i < (uint32_t)P) {
+			const uint32_t d = (key[i] >> SHIFT) & 255u;
+			const uint32_t lp = s_excl[d] + s_hist[wave][d] + rank[i];
+			s_keys[lp] = key[i];
+			s_vals[lp] = val[i];
+		}
+	}
+	__syncthreads();
+
+	// ---- scatter: runs of consecutive output positions
+	const uint32_t nvalid = (uint32_t)P - (uint32_t)k * DS_TILE < (uint32_t)DS_TILE ? (uint32_t)P - (uint32_t)k * DS_TILE
+										 : (uint32_t)DS_TILE;
+#pragma unroll
+	for (int i = 0; i < DS_ITEMS; i++) {
+		const uint32_t j = (uint32_t)t + 256u * i;
+		const bool ok = j < nvalid;
+		uint32_t kv = 0, pos = 0;
+		if (ok) {
+			kv = s_keys[j];
+			const uint32_t d = (kv >> SHIFT) & 255u;
+			pos = s_base[d] + (j - s_excl[d]);
+			if (PASS < 3) keys_out[pos] = kv;
+			const uint32_t g = s_vals[j];
+			vals_out[pos] = g;
+			if (SPAN) {   // binning_rows.hip span_counts_kernel, rank = pos
+				uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+				uint64_t c64 = 0;
+				const int rad = so.radii[g];
+				if (rad > 0) {
+					const float2 pm = so.means2D[g];
+					uint32_t x0, y0, x1, y1;
+					get_rect(pm.x, pm.y, rad, so.gx, so.gy, x0, y0, x1, y1);
+					const uint32_t lo = so.major_x ? x0 : y0, hi = so.major_x ? x1 : y1;
+					const uint32_t payload = so.major_x ? (y0 | (y1 << 16)) : (x0 | (x1 << 16));
+					if (hi > lo) {
+						rec = make_uint4(g, lo | (hi << 16), payload, 0u);
+						const uint32_t nmaj = hi - lo, nmin = (payload >> 16) - (payload & 0xffffu);
+						c64 = ((uint64_t)nmaj << 32) | (uint64_t)(nmaj * nmin);
+					}
+				}
+				so.rrec[pos] = rec;
+				so.counts64[pos] = c64;
+			}
+		}
+	}
+}
+
+// cnt[tile][d] / gcnt[tile / 32][d] of one pass from the keys in the order that pass reads them: a workgroup per tile,
+// LDS histogram, the tile's row by plain stores, the group's row by 256 coalesced atomics.  (Counting the next pass's
+// digits from inside the scatter of the previous pass was tried first: 2M scattered device-scope atomics cost 0.2 -
+// 2.3 ms per pass, against 16 us for the pass itself.)
+template <int SHIFT>
+__global__ __launch_bounds__(256) void depth_sort_count_kernel(int P, const uint32_t* __restrict__ keys,
+								uint32_t* __restrict__ cnt, uint32_t* __restrict__ gcnt)
+{
+	__shared__ uint32_t s_h[256];
+	const int k = blockIdx.x, t = threadIdx.x;
+	s_h[t] = 0u;
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < DS_ITEMS; i++) {
+		const uint32_t idx = (uint32_t)k * DS_TILE + (uint32_t)t + 256u * i;
+		if (idx < (uint32_t)P) atomicAdd(&s_h[(keys[idx] >> SHIFT) & 255u], 1u);
+	}
+	__syncthreads();
+	const uint32_t c = s_h[t];
+	cnt[(size_t)k * 256 + t] = c;
+	if (c) atomicAdd(&gcnt[(size_t)(k / DS_GRP) * 256 + t], c);
+}
+
+// pass 0's count matrices from an array of keys (the forward gets them from preprocess.hip; this is for
+// sgs_debug_depth_sort and the tests)
+__global__ __launch_bounds__(256) void depth_sort_count0_kernel(int P, const uint32_t* __restrict__ keys,
+								 uint32_t* __restrict__ cnt0, uint32_t* __restrict__ gcnt0)
+{
+	__shared__ uint32_t s_h[256];
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	s_h[threadIdx.x] = 0u;
+	__syncthreads();
+	if (i < P) atomicAdd(&s_h[keys[i] & 255u], 1u);
+	__syncthreads();
+	const uint32_t c = s_h[threadIdx.x];
+	if (c) {
+		const uint32_t tile = blockIdx.x / (DS_TILE / 256);
+		atomicAdd(&cnt0[(size_t)tile * 256 + threadIdx.x], c);
+		atomicAdd(&gcnt0[(size_t)(tile / DS_GRP) * 256 + threadIdx.x], c);
+	}
+}
+
+hipError_t launch_depth_sort_standalone(hipStream_t st, int P, const DepthSortLayout& lay, char* scratch,
+					const uint32_t* keys, uint32_t* perm)
+{
+	if (P <= 0) return hipSuccess;
+	hipError_t e = hipMemsetAsync(scratch + lay.counts, 0, lay.counts_bytes, st);
+	if (e != hipSuccess) return e;
+	uint32_t* cnt0 = (uint32_t*)(scratch + lay.counts);
+	hipLaunchKernelGGL(depth_sort_count0_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, keys, cnt0,
+			   cnt0 + (size_t)lay.tiles * 256);
+	return launch_depth_sort(st, P, lay, scratch, keys, perm, nullptr);
+}
+
+void depth_sort_layout(int P, DepthSortLayout* lay)
+{
+	const int tiles = (P + DS_TILE - 1) / DS_TILE;
+	const int groups = (tiles + DS_GRP - 1) / DS_GRP;
+	size_t off = 0;
+	auto take = [&](size_t bytes) { off = (off + 127) & ~(size_t)127; const size_t o = off; off += bytes; return o; };
+	lay->tiles = tiles;
+	lay->groups = groups;
+	lay->counts = take((size_t)4 * ((size_t)tiles + groups) * 256 * 4);   // 4 passes x (tile rows | group rows)
+	lay->counts_bytes = off - lay->counts;
+	lay->keys[0] = take((size_t)P * 4);
+	lay->keys[1] = take((size_t)P * 4);
+	lay->vals[0] = take((size_t)P * 4);
+	lay->vals[1] = take((size_t)P * 4);
+	lay->total = (off + 127) & ~(size_t)127;
+}
+
+// scratch: depth_sort_layout bytes, its `counts` region zeroed before the kernel that fills pass 0's matrices ran
+hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, char* scratch,
+			     const uint32_t* depth_bits, uint32_t* perm, const DepthSortSpanOut* span)
+{
+	if (P <= 0) return hipSuccess;
+	const size_t rows = (size_t)lay.tiles + lay.groups;
+	uint32_t* cnt[4];
+	uint32_t* gcnt[4];
+	for (int p = 0; p < 4; p++) {
+		cnt[p] = (uint32_t*)(scratch + lay.counts) + (size_t)p * rows * 256;
+		gcnt[p] = cnt[p] + (size_t)lay.tiles * 256;
+	}
+	uint32_t* kA = (uint32_t*)(scratch + lay.keys[0]);
+	uint32_t* kB = (uint32_t*)(scratch + lay.keys[1]);
+	uint32_t* vA = (uint32_t*)(scratch + lay.vals[0]);
+	uint32_t* vB = (uint32_t*)(scratch + lay.vals[1]);
+	const dim3 grid(lay.tiles), block(256);
+	const DepthSortSpanOut none{};
+	hipLaunchKernelGGL((depth_sort_pass_kernel<0, false>), grid, block, 0, st, P, lay.groups, depth_bits, (const uint32_t*)nullptr,
+			   kA, vA, cnt[0], gcnt[0], none);
+	hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1]);
+	hipLaunchKernelGGL((depth_sort_pass_kernel<1, false>), grid, block, 0, st, P, lay.groups, kA, vA, kB, vB, cnt[1], gcnt[1], none);
+	hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2]);
+	hipLaunchKernelGGL((depth_sort_pass_kernel<2, false>), grid, block, 0, st, P, lay.groups, kB, vB, kA, vA, cnt[2], gcnt[2], none);
+	hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3]);
+	if (span)
+		hipLaunchKernelGGL((depth_sort_pass_kernel<3, true>), grid, block, 0, st, P, lay.groups, kA, vA, (uint32_t*)nullptr,
+				   perm, cnt[3], gcnt[3], *span);
+	else
+		hipLaunchKernelGGL((depth_sort_pass_kernel<3, false>), grid, block, 0, st, P, lay.groups, kA, vA, (uint32_t*)nullptr,
+				   perm, cnt[3], gcnt[3], none);
+	return hipGetLastError();
+}
+
+} // namespace sgs

@@ -60,10 +60,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 	int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depths,
 	float* __restrict__ cov3Ds, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
 	float4* __restrict__ conic_opacity, uint32_t* __restrict__ tiles_touched,
-	int* __restrict__ trap_flag)
+	int* __restrict__ trap_flag, uint32_t* __restrict__ ds_cnt0, uint32_t* __restrict__ ds_gcnt0)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= P) return;
+	uint32_t sort_key = 0xFFFFFFFFu;   // what depths[i] ends up holding
+	if (i < P) do {
 	radii[i] = 0;
 	tiles_touched[i] = 0;
 	// depth doubles as the presort key (binning mode 0): culled Gaussians sort last
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 		// reference: printf + __trap() (auxiliary.h:156-160); here: flag, the host
 		// turns it into SGS_ETRAP.
 		if (prefiltered) atomicOr(trap_flag, 1);
-		return;
+		break;
 	}
 	const float pw = 1.0f / (ph.w + 0.0000001f);
 	const float ppx = ph.x * pw, ppy = ph.y * pw;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 	}
 	const Cov2D c2 = cov2d_parts(px, py, pz, fx, fy, tanx, tany, cov3D, view);
 	const float det = c2.a * c2.c - c2.b * c2.b;
-	if (det == 0.0f) return;
+	if (det == 0.0f) break;
 	const float det_inv = 1.f / det;
 	const float conx = c2.c * det_inv, cony = -c2.b * det_inv, conz = c2.a * det_inv;
 	const float mid = 0.5f * (c2.a + c2.c);
@@ -106,17 +107,35 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 	const float pix_x = ndc2pix(ppx, W), pix_y = ndc2pix(ppy, H);
 	uint32_t x0, y0, x1, y1;
 	get_rect(pix_x, pix_y, (int)my_radius, gx, gy, x0, y0, x1, y1);
-	if ((x1 - x0) * (y1 - y0) == 0) return;
+	if ((x1 - x0) * (y1 - y0) == 0) break;
 
 	if (!colors_precomp)
 		sh_to_rgb(D, px, py, pz, campos, shs + (size_t)i * M * 3,
 			  rgb + (size_t)i * num_channels, clamped + 3 * (size_t)i);
 
 	depths[i] = pv.z;
+	sort_key = __float_as_uint(pv.z);
 	radii[i] = (int)my_radius;
 	means2D[i] = make_float2(pix_x, pix_y);
 	conic_opacity[i] = make_float4(conx, cony, conz, opacities[i]);
 	tiles_touched[i] = (y1 - y0) * (x1 - x0);
+	} while (0);
+
+	// depth_sort.hip's pass-0 count matrices: keys per (tile of 4096 Gaussians, lowest key byte), aggregated per
+	// workgroup in LDS (every Gaussian counts, the culled ones with their 0xFFFFFFFF key)
+	if (ds_cnt0) {
+		__shared__ uint32_t s_h[256];
+		s_h[threadIdx.x] = 0u;
+		__syncthreads();
+		if (i < P) atomicAdd(&s_h[sort_key & 255u], 1u);
+		__syncthreads();
+		const uint32_t c = s_h[threadIdx.x];
+		if (c) {
+			const uint32_t tile = blockIdx.x / (DS_TILE / 256);
+			atomicAdd(&ds_cnt0[(size_t)tile * 256 + threadIdx.x], c);
+			atomicAdd(&ds_gcnt0[(size_t)(tile / DS_GRP) * 256 + threadIdx.x], c);
+		}
+	}
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P,
@@ -139,13 +158,13 @@ void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* mea
 			   float fy, int gx, int gy, int prefiltered, int num_channels, int* radii,
 			   float2* means2D, float* depths, float* cov3Ds, float* rgb,
 			   uint8_t* clamped, float4* conic_opacity, uint32_t* tiles_touched,
-			   int* trap_flag)
+			   int* trap_flag, uint32_t* ds_cnt0, uint32_t* ds_gcnt0)
 {
 	hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, D, M,
 			   means3D, scales, mod, rotations, opacities, shs, cov3D_precomp,
 			   colors_precomp, view, proj, campos, W, H, tanx, tany, fx, fy, gx, gy,
 			   prefiltered, num_channels, radii, means2D, depths, cov3Ds, rgb, clamped,
-			   conic_opacity, tiles_touched, trap_flag);
+			   conic_opacity, tiles_touched, trap_flag, ds_cnt0, ds_gcnt0);
 }
 
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view,

@@ -14,9 +14,32 @@ void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* mea
 			   float fy, int gx, int gy, int prefiltered, int num_channels, int* radii,
 			   float2* means2D, float* depths, float* cov3Ds, float* rgb,
 			   uint8_t* clamped, float4* conic_opacity, uint32_t* tiles_touched,
-			   int* trap_flag);
+			   int* trap_flag, uint32_t* ds_cnt0 = nullptr, uint32_t* ds_gcnt0 = nullptr);
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view,
 			 uint8_t* present);
+
+// ---- depth_sort.hip: the depth presort of the Gaussians (4 kernels, no look-back, no fills of its own)
+constexpr int DS_TILE = 4096;   // keys per workgroup
+constexpr int DS_GRP = 32;      // tiles per group row of the count matrices
+struct DepthSortLayout {        // byte offsets inside the sort's scratch
+	size_t counts, counts_bytes;   // 4 passes x (tiles + groups) rows of 256 counters; must be ZERO before pass 0's
+	                               // matrices are filled (preprocess.hip does that, with atomics)
+	size_t keys[2], vals[2], total;
+	int tiles, groups;
+};
+struct DepthSortSpanOut {   // optional by-product of the last pass: what binning_rows.hip's span_counts_kernel writes
+	const int* radii;
+	const float2* means2D;
+	int gx, gy, major_x;
+	uint64_t* counts64;
+	uint4* rrec;
+};
+void depth_sort_layout(int P, DepthSortLayout* lay);
+hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, char* scratch,
+			     const uint32_t* depth_bits, uint32_t* perm, const DepthSortSpanOut* span = nullptr);
+// the same from a bare array of keys (clears and fills pass 0's count matrices itself)
+hipError_t launch_depth_sort_standalone(hipStream_t st, int P, const DepthSortLayout& lay, char* scratch,
+					const uint32_t* keys, uint32_t* perm);
 
 // ---- binning.hip
 size_t scan_temp_bytes(int P);
@@ -41,9 +64,10 @@ hipError_t launch_sort32_pairs(hipStream_t st, void* temp, size_t temp_bytes, ui
 void launch_tile_ranges32(hipStream_t st, size_t L, const uint32_t* tiles, uint2* ranges, int ntiles);
 // ---- binning_rows.hip (binning mode 0)
 size_t scan64_temp_bytes(int P);
+// counts_done: counts64 / rrec were already written (depth_sort.hip's last pass) -- only the scan runs
 hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes, int P, const uint32_t* perm,
 				  const int* radii, const float2* means2D, int gx, int gy, uint64_t* counts64,
-				  uint64_t* offs64, uint4* rrec);
+				  uint64_t* offs64, uint4* rrec, bool counts_done = false);
 void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, size_t* cmat_words,
 			 size_t* gtot_words, size_t* len_words);
 // R may be an upper bound of the major-instance count (grids and scratch are sized from it, the kernels read the

@@ -141,7 +141,7 @@ def test_forward_channel_counts(orc, C):
         _check_forward(orc, scene, cam, variant=15)   # SGS_BLEND_EXACT: bit-identical
 
 
-@pytest.mark.parametrize("binning_mode", [0, 1, 2])
+@pytest.mark.parametrize("binning_mode", [0, 1, 2, 3])   # 3 = mode 0 with the library radix sort as the depth presort
 def test_binning_modes_bit_exact(orc, binning_mode):
     """Both binning algorithms give the oracle's sorted keys / lists / ranges; the reference-order
     mode additionally reproduces point_offsets and the emission-order (unsorted) arrays."""
@@ -678,3 +678,41 @@ def test_pipelined_views_with_deferred_counts():
     assert len(outs) == 10
     for o in outs:
         assert isinstance(o, tuple) and torch.equal(o[1], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,kind", [(1, "random"), (63, "random"), (4096, "random"), (4097, "random"),
+                                    (300000, "random"), (1000003, "depth"), (200000, "equal"),
+                                    (500000, "planes"), (150001, "culled"), (5000000, "depth")])
+def test_depth_sort_matches_stable_sort(P, kind):
+    """csrc/depth_sort.hip (the forward's presort of the Gaussians) on bare keys against torch's stable sort:
+    full-range random keys, depth-like float bit patterns, all keys equal (ties resolve by index), a handful of
+    distinct values, mostly-culled (0xFFFFFFFF) keys, sizes around the 4096-key tile and one beyond 32 x 32 tiles."""
+    import ctypes as C
+    from sgs_hip import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(P)
+    if kind == "random":
+        keys = torch.randint(0, 2 ** 32, (P,), device=DEV, generator=g, dtype=torch.int64)
+    elif kind == "depth":
+        keys = (0.2 + 60.0 * torch.rand(P, device=DEV, generator=g)).view(torch.int32).to(torch.int64)
+    elif kind == "equal":
+        keys = torch.full((P,), 0x40490FDB, device=DEV, dtype=torch.int64)
+    elif kind == "planes":
+        keys = torch.tensor([1.0, 1.5, 2.0, 2.0000002, 7.25], device=DEV)[
+            torch.randint(0, 5, (P,), device=DEV, generator=g)].view(torch.int32).to(torch.int64)
+    else:
+        keys = (0.2 + 5.0 * torch.rand(P, device=DEV, generator=g)).view(torch.int32).to(torch.int64)
+        keys[torch.rand(P, device=DEV, generator=g) < 0.9] = 0xFFFFFFFF
+    want = torch.sort(keys, stable=True).indices.to(torch.int32)
+    k32 = (keys & 0xFFFFFFFF).to(torch.int64)
+    k32 = torch.where(k32 >= 2 ** 31, k32 - 2 ** 32, k32).to(torch.int32)   # same bits as uint32
+    need = lib.sgs_debug_depth_sort(P, None, None, None, None)
+    scratch = torch.empty(need, dtype=torch.uint8, device=DEV)
+    perm = torch.full((P,), -1, dtype=torch.int32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):   # (twice: the count matrices must be cleared every time)
+        rc = lib.sgs_debug_depth_sort(P, k32.data_ptr(), perm.data_ptr(), scratch.data_ptr(), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(perm, want)
