@@ -9,9 +9,13 @@ Metric (BASELINE.json): Gpixel*channels/s of the FORWARD feature render,
 What one JSON line carries (rank 0):
   value / ms_per_step   the contract's number: K timed steps between barriers, a step = `--views` (default 4)
                         views of the scene in flight on as many HIP streams; DEFAULT arithmetic of the C >= 128
-                        blend, which is split-bf16 x3 MFMA products with fp32 accumulation -- `dtype` says so;
+                        blend, which is split-bf16 x3 MFMA products with fp32 accumulation -- `dtype` says so.
+                        The forwards of a step are deferred-count ones (SGS_OPT_DEFER_COUNT: no blocking
+                        num_rendered read-back inside the call; counts checked per step, every num_rendered compared
+                        with the serial render); --blocking-count times the reference's host pattern instead;
   single_view           one view in flight (SURVEY.md 8(d)'s t_fwd: device time of one forward, hipEvents, median
                         of >= 20): value, ms_median, ms_mean -- for the default AND the exact fp32 arithmetic;
+  single_view_deferred_count   the same forward without the num_rendered read-back;
   exact_f32             the bit-exact fp32-MFMA arithmetic (SGS_BLEND_EXACT=1) timed like the headline;
   backward              cfg3 is "forward+backward": forward+backward device ms of the same scene (N = 1 only);
   roofline              the forward blend against the HBM roofline: achieved = SURVEY 8(d)'s algorithmic bytes of
@@ -263,9 +267,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def single_view(variant, n=24):
+    def single_view(variant, n=24, deferred=False):
         """One view in flight: per-forward device time (hipEvents on the launch stream = torch's current
-        stream) and the per-stage times (deferred resolution: no extra synchronisation)."""
+        stream) and the per-stage times (deferred resolution: no extra synchronisation).  deferred: the forward
+        without the num_rendered read-back (each frame's counts are checked before the next one is enqueued)."""
         raster.set_blend_variant(variant)
         for _ in range(3):
             render(0)
@@ -275,8 +280,10 @@ def main():
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in evs:
             a.record()
-            render(0)
+            h = render(0, deferred)
             b.record()
+            if deferred:
+                h.result()
         torch.cuda.synchronize(dev)
         raster.set_stage_timing(0)
         ms = sorted(a.elapsed_time(b) for a, b in evs)
@@ -320,6 +327,7 @@ def main():
 
     # ---- one view in flight (SURVEY 8(d)'s t_fwd), default arithmetic; its stage times feed the roofline
     sv_default, stage_ms = single_view(args.variant)
+    sv_deferred, _ = single_view(args.variant, deferred=True)
     # integrity reference: every view's num_rendered, rendered alone (concurrent forwards must reproduce it)
     ref_n = []
     for i in range(V):
@@ -449,6 +457,7 @@ def main():
             "ms_per_step_median": ms_step_median,
             "ms_per_view": ms_per_step / V,
             "single_view": sv_default,
+            "single_view_deferred_count": {k: sv_deferred[k] for k in ("value", "unit", "ms_median", "ms_min", "forwards")},
             "exact_f32": exact,
             "backward": backward,
             # the forward blend = blend_weights_kernel + blend_accum_sweep_kernel (one launch each);

@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
 	uint32_t* __restrict__ act_id, uint32_t* __restrict__ act_idx, float* __restrict__ wgt,
 	uint32_t* __restrict__ table, uint32_t* __restrict__ nact, uint32_t* __restrict__ counter,
-	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles)
+	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles, unsigned long long* __restrict__ trace)
 {
 	const int b = blockIdx.x;
+	const unsigned long long t_begin = trace ? wall_clock64() : 0ull;   // (debug timeline, tools/sweep_trace.py)
 	static_assert(MODE == 2 || MODE == 3, "weights format: 2 = split bf16 (default), 3 = fp32 rows (exact)");
 	constexpr bool BF = MODE == 2;   // weights as split bf16, k-major groups of 8 (else fp32 rows of 256)
 	constexpr bool SWEEP = true;     // parity-major pixel order, closing T * bg pseudo entry, zero padding to 16
@@ -362,6 +363,13 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		const size_t pix = (size_t)py * W + px;
 		final_T[pix] = T;
 		n_contrib[pix] = last;
+	}
+	if (trace && threadIdx.x == 0) {
+		trace[4 * (size_t)b] = t_begin;
+		trace[4 * (size_t)b + 1] = wall_clock64();
+		trace[4 * (size_t)b + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+					   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+		trace[4 * (size_t)b + 3] = (unsigned long long)total | ((unsigned long long)(ranges[tile].y - ranges[tile].x) << 32);
 	}
 }
 
@@ -978,7 +986,7 @@ hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const 
 			   (uint32_t*)(arena + lay.act_id), (uint32_t*)(arena + lay.act_idx),
 			   (float*)(arena + lay.wgt), (uint32_t*)(arena + lay.table),
 			   (uint32_t*)(arena + lay.nbatches), counter, lay.capacity, W, H, gx, (ntiles + 7) / 8,
-			   ntiles);
+			   ntiles, (unsigned long long*)nullptr);
 	return hipGetLastError();
 }
 
@@ -1029,7 +1037,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3((((NT_) + 7) / 8) * 8), dim3(256), 0, ST_,    \
 			   a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, \
 			   act_id, (uint32_t*)nullptr, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, \
-			   ((NT_) + 7) / 8, NT_)
+			   ((NT_) + 7) / 8, NT_, g_sweep_trace ? g_sweep_trace + 4 * 4096 : nullptr)
 	{
 		// ---- row-sweep path (default)
 		// segment length: long sweeps amortise the prologue and leave few half-line stores at segment

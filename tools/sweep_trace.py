@@ -29,13 +29,17 @@ for _ in range(3):
     fwd()
 torch.cuda.synchronize()
 NWG = 4096
-tr = torch.zeros(NWG, 4, dtype=torch.int64, device=dev)
+tr = torch.zeros(NWG + 8192, 4, dtype=torch.int64, device=dev)   # sweep workgroups | weights workgroups
 lib = _lib.load()
 lib.sgs_debug_set_sweep_trace(tr.data_ptr())
 fwd()
 torch.cuda.synchronize()
 lib.sgs_debug_set_sweep_trace(None)
-t = tr.cpu().numpy()
+t_all = tr.cpu().numpy()
+which = sys.argv[2] if len(sys.argv) > 2 else "sweep"
+t = t_all[:NWG] if which == "sweep" else t_all[NWG:]
+SLOTS = 512 if which == "sweep" else 1536
+print(f"== {which} kernel")
 t = t[t[:, 1] != 0]
 b, e = t[:, 0].astype(np.float64), t[:, 1].astype(np.float64)
 t0 = b.min()
