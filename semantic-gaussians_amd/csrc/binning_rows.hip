@@ -340,15 +340,22 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 	}
 	blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo);
 	bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
+	if (blo >= bhi) return;   // no item of this chunk covers a bin
+	// Which lanes cover bin b, as a 64-bit mask per bin in LDS: every lane ORs its bit into the bins of its own span
+	// (L / R = 4 bins per item on average) -- instead of one ballot per bin of the wave's whole range, which for 64
+	// depth-consecutive items is most of the axis (61 ballots + popcounts per wave; the kernel was issue bound on
+	// them).  The rank of an item inside a bin's list is still popcount(mask & lanes_below): same positions, same bits.
+	unsigned long long* cover = reinterpret_cast<unsigned long long*>(s_base + 4 * nb) + (size_t)wave * nb;   // (4 nb words: 16-byte aligned)
+	for (uint32_t b = blo + (uint32_t)lane; b < bhi; b += 64) cover[b] = 0ull;
+	__builtin_amdgcn_wave_barrier();
+	const unsigned long long mine = 1ull << lane;
+	for (uint32_t b = lo; b < hi; b++) atomicOr(&cover[b], mine);
+	__builtin_amdgcn_wave_barrier();
 	const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-	for (uint32_t b = blo; b < bhi; b++) {
-		const bool cov = lo <= b && b < hi;
-		const unsigned long long m = __ballot(cov);
-		if (cov) {
-			const uint32_t pos = base[b] + (uint32_t)__popcll(m & below);
-			if (FROM_RANKS) out_items[pos] = make_uint2(g, payload);
-			else point_list[pos] = g;
-		}
+	for (uint32_t b = lo; b < hi; b++) {
+		const uint32_t pos = base[b] + (uint32_t)__popcll(cover[b] & below);
+		if (FROM_RANKS) out_items[pos] = make_uint2(g, payload);
+		else point_list[pos] = g;
 	}
 }
 
@@ -383,6 +390,8 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	uint32_t* binlen = lens + ntiles;         // stage A list lengths
 	const uint32_t chA = ((uint32_t)P + RCH - 1) / RCH, grA = (chA + RGRP - 1) / RGRP;
 	const size_t ldsA = (size_t)4 * (nbA + 1) * 4, ldsB = (size_t)4 * (nbB + 1) * 4;
+	// the ballot-free scatter: [4 waves][nb] list bases (uint32) + [4 waves][nb] cover masks (uint64, 8-byte aligned)
+	const size_t ldsSA = (size_t)4 * nbA * 4 + (size_t)4 * nbA * 8, ldsSB = (size_t)4 * nbB * 4 + (size_t)4 * nbB * 8;
 
 	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
 	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
@@ -393,7 +402,7 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
 			   binlen, abort);
 	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort);
-	hipLaunchKernelGGL(span_scatter_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A, grp0A,
+	hipLaunchKernelGGL(span_scatter_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsSA, st, nbA, 1, segA, chunk0A, grp0A,
 			   (const uint2*)nullptr, rrec, cmat, gtot, segB, (const uint2*)nullptr, 0, 1, items,
 			   (uint32_t*)nullptr, abort);
 
@@ -408,7 +417,7 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
 			   seg_stride, bin_stride, lens, abort);
 	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, (uint32_t*)nullptr, abort);
-	hipLaunchKernelGGL(span_scatter_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B,
+	hipLaunchKernelGGL(span_scatter_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsSB, st, nbB, nbA, segB, chunk0B,
 			   grp0B, items, rrec, cmat, gtot, (const uint32_t*)nullptr, ranges, seg_stride, bin_stride,
 			   (uint2*)nullptr, point_list, abort);
 	return hipGetLastError();
