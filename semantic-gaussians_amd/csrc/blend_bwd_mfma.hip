@@ -637,6 +637,11 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 	if (real <= 0) return;
 
 	__shared__ StagedEntryG s_e[64];
+	// per staged entry and wave: the six wave-reduced sums (mean2D x/y, conic xx/xy/yy, opacity).  They are added up
+	// over the four waves and sent as ONE atomic per (entry, component), issued 64 lanes wide, after the block --
+	// a lane-0 atomic per wave, entry and component (24 narrow device-scope atomics per entry) was what bound this
+	// kernel.
+	__shared__ float s_acc[4][64][6];
 
 	const float T_final = inside ? final_Ts[pix] : 0.f;
 	float T = T_final;
@@ -655,6 +660,7 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 	for (int hi = real; hi > 0; hi -= 64) {
 		const int n = hi < 64 ? hi : 64;
 		__syncthreads();
+		for (int q = threadIdx.x; q < 4 * 64 * 6; q += 256) (&s_acc[0][0][0])[q] = 0.f;
 		if ((int)threadIdx.x < n) {
 			const uint32_t g = (uint32_t)(hi - 1 - (int)threadIdx.x);
 			const uint32_t slot = table[chunk_base + g / CHUNK] + g % CHUNK;
@@ -677,10 +683,13 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 			s_e[threadIdx.x] = e;
 		}
 		__syncthreads();
-		for (int k = 0; k < n; k++) {
-			const StagedEntryG e = s_e[k];
+		// One entry of the walk.  Dk (this pixel's D of the entry) arrives prefetched: the load is the only global
+		// access of a step and its address does not depend on the recurrence, so a group of 8 is requested while the
+		// previous group is processed (as written before -- one dependent load per step -- the kernel was bound by
+		// that latency: 0.73 ms for 455 k entries).
+		auto step = [&](const StagedEntryG& e, float Dk, int kslot) __attribute__((always_inline)) {
 			const int idx = (int)e.idx1 - 1;
-			if (idx >= wave_max) continue;
+			if (idx >= wave_max) return;
 			const float dx = e.x - pxf, dy = e.y - pyf;
 			const float power =
 				__builtin_fmaf(e.b2 * dx, dy, __builtin_fmaf(e.c2 * dy, dy, (e.a2 * dx) * dx));
@@ -688,9 +697,7 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 			const float alpha = fmin_(0.99f, e.o * G);
 			const bool valid = inside && (idx < last_contributor) && !(power > 0.0f) &&
 					   !(alpha < 1.0f / 255.0f);
-			if (__ballot(valid) == 0ull) continue;
-			const uint32_t slot = __builtin_amdgcn_readfirstlane(e.slot);
-			const float Dk = Drows[(size_t)slot * 256 + pxp];
+			if (__ballot(valid) == 0ull) return;
 			const float oma = 1.f - alpha;
 			if (valid) T = T / oma;
 			float dL_dalpha = (Dk - R) * T;
@@ -708,14 +715,40 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 			const float k1 = wave_sum(-0.5f * gdx * dy * dL_dG);
 			const float k3 = wave_sum(-0.5f * gdy * dy * dL_dG);
 			const float op = wave_sum(Gv * dL_dalpha);
-			const uint32_t id = __builtin_amdgcn_readfirstlane(e.id);
 			if (lane == 0) {
-				atomicAdd(&dL_dmean2D[3 * (size_t)id], m0);
-				atomicAdd(&dL_dmean2D[3 * (size_t)id + 1], m1);
-				atomicAdd(&dL_dconic[4 * (size_t)id], k0);
-				atomicAdd(&dL_dconic[4 * (size_t)id + 1], k1);
-				atomicAdd(&dL_dconic[4 * (size_t)id + 3], k3);
-				atomicAdd(&dL_dopacity[id], op);
+				float* a = s_acc[wave][kslot];
+				a[0] = m0;
+				a[1] = m1;
+				a[2] = k0;
+				a[3] = k1;
+				a[4] = k3;
+				a[5] = op;
+			}
+		};
+		constexpr int PF = 8;
+		float dcur[PF], dnext[PF];
+#pragma unroll
+		for (int u = 0; u < PF; u++) dcur[u] = u < n ? Drows[(size_t)s_e[u].slot * 256 + pxp] : 0.f;
+		for (int k0 = 0; k0 < n; k0 += PF) {
+#pragma unroll
+			for (int u = 0; u < PF; u++) {
+				const int kk = k0 + PF + u;
+				dnext[u] = kk < n ? Drows[(size_t)s_e[kk].slot * 256 + pxp] : 0.f;
+			}
+#pragma unroll
+			for (int u = 0; u < PF; u++)
+				if (k0 + u < n) step(s_e[k0 + u], dcur[u], k0 + u);
+#pragma unroll
+			for (int u = 0; u < PF; u++) dcur[u] = dnext[u];
+		}
+		__syncthreads();
+		for (int q = threadIdx.x; q < n * 6; q += 256) {
+			const int e = q / 6, c = q - 6 * e;
+			const float v = (s_acc[0][e][c] + s_acc[1][e][c]) + (s_acc[2][e][c] + s_acc[3][e][c]);
+			if (v != 0.f) {
+				const size_t id = s_e[e].id;
+				float* dst = c < 2 ? dL_dmean2D + 3 * id + c : (c < 5 ? dL_dconic + 4 * id + (c == 4 ? 3 : c - 2) : dL_dopacity + id);
+				atomicAdd(dst, v);
 			}
 		}
 	}
