@@ -60,6 +60,13 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 
 	__shared__ StagedEntryB s_e[256];
 	__shared__ int s_max[4];
+	// CC <= 4 (RGB / RGB-D): the wave-reduced sums of an entry (CC colour + 6 geometry components) of the four waves
+	// meet here and leave as one atomic per (entry, component), issued 64 lanes wide, after every 64 entries -- 9 x 4
+	// lane-0 device-scope atomics per entry were what bound the kernel.  CC = 32: the colour sums leave as one
+	// coalesced row of atomics per wave (lane c carries channel c) instead of 32 single-lane ones.
+	constexpr bool COMBINE = CC <= 4;
+	constexpr int NV = CC + 6;
+	__shared__ float s_acc[COMBINE ? 4 * 64 * NV : 1];
 
 	const float T_final = inside ? final_Ts[pix] : 0.f;
 	float T = T_final;
@@ -116,7 +123,13 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 			s_e[threadIdx.x] = e;
 		}
 		__syncthreads();
-		for (int k = 0; k < n; k++) {
+		for (int kb = 0; kb < n; kb += 64) {
+		const int ke = kb + 64 < n ? kb + 64 : n;
+		if (COMBINE) {
+			for (int q = threadIdx.x; q < 4 * 64 * NV; q += 256) s_acc[q] = 0.f;
+			__syncthreads();
+		}
+		for (int k = kb; k < ke; k++) {
 			const int idx = hi - 1 - k;          // 0-based list index of this entry
 			if (idx >= wave_max) continue;       // nobody in this strip got that far
 			const StagedEntryB e = s_e[k];
@@ -135,6 +148,8 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 			const float* __restrict__ col = colors + (size_t)id * C + c0;
 			float* __restrict__ dcol = dL_dcolors + (size_t)id * C + c0;
 			float S = 0.f;
+			float* acc_row = COMBINE ? &s_acc[(wave * 64 + (k - kb)) * NV] : nullptr;
+			float mine = 0.f;   // (CC = 32) lane c: the wave's sum for channel c
 #pragma unroll
 			for (int c = 0; c < CC; c++) {
 				if (c < cn) {
@@ -142,11 +157,16 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 					// contribution to dL/dalpha uses the colour accumulated BEHIND this entry
 					S += (cv - rec[c]) * g[c];
 					const float gc = wave_sum(wgt * g[c]);
-					if (lane == 0) atomicAdd(&dcol[c], gc);
+					if (COMBINE) {
+						if (lane == 0) acc_row[6 + c] = gc;
+					} else if (lane == c) {
+						mine = gc;
+					}
 					// fold this entry into the running "behind" colour for the next one
 					if (valid) rec[c] = alpha * cv + oma * rec[c];
 				}
 			}
+			if (!COMBINE && lane < cn) atomicAdd(&dcol[lane], mine);
 			float dL_dalpha = S * T;
 			dL_dalpha += (-T_final / oma) * bg_dot;
 			if (!valid) dL_dalpha = 0.f;
@@ -161,7 +181,16 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 			const float k1 = wave_sum(-0.5f * gdx * dy * dL_dG);
 			const float k3 = wave_sum(-0.5f * gdy * dy * dL_dG);
 			const float op = wave_sum(Gv * dL_dalpha);
-			if (lane == 0) {
+			if (COMBINE) {
+				if (lane == 0) {
+					acc_row[0] = m0;
+					acc_row[1] = m1;
+					acc_row[2] = k0;
+					acc_row[3] = k1;
+					acc_row[4] = k3;
+					acc_row[5] = op;
+				}
+			} else if (lane == 0) {
 				atomicAdd(&dL_dmean2D[3 * (size_t)id], m0);
 				atomicAdd(&dL_dmean2D[3 * (size_t)id + 1], m1);
 				atomicAdd(&dL_dconic[4 * (size_t)id], k0);
@@ -169,6 +198,24 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 				atomicAdd(&dL_dconic[4 * (size_t)id + 3], k3);
 				atomicAdd(&dL_dopacity[id], op);
 			}
+		}
+		if (COMBINE) {   // one atomic per (entry, component) of this group of 64 entries
+			__syncthreads();
+			for (int q = threadIdx.x; q < (ke - kb) * NV; q += 256) {
+				const int e = q / NV, c = q - NV * e;
+				const float v = (s_acc[(0 * 64 + e) * NV + c] + s_acc[(1 * 64 + e) * NV + c]) +
+						(s_acc[(2 * 64 + e) * NV + c] + s_acc[(3 * 64 + e) * NV + c]);
+				if (v != 0.f) {
+					const size_t id = s_e[kb + e].id;
+					float* dst = c < 2 ? dL_dmean2D + 3 * id + c
+						   : c < 5 ? dL_dconic + 4 * id + (c == 4 ? 3 : c - 2)
+						   : c == 5 ? dL_dopacity + id
+							    : dL_dcolors + id * C + c0 + (c - 6);
+					if (c < 6 || c - 6 < cn) atomicAdd(dst, v);
+				}
+			}
+			__syncthreads();
+		}
 		}
 	}
 }
