@@ -280,7 +280,10 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 				if (threadIdx.x == 0) {
 					uint32_t nc = nchunks;
 					while (nc * ACH < total + cnt && s_ovf == 0u) {
-						const uint32_t start = atomicAdd(&counter[0], (uint32_t)ACH);
+						// a tile's FIRST chunk is pre-assigned (slot tile * 128; the bump counter starts behind
+						// those): every tile needs one, and most need no other -- no returning device-scope
+						// atomic on the tile's critical path
+						const uint32_t start = nc == 0 ? (uint32_t)tile * ACH : atomicAdd(&counter[0], (uint32_t)ACH);
 						if (start + ACH > capacity) {   // arena overflow: flag it, emit nothing more
 							atomicExch(&counter[1], 1u);
 							s_ovf = 1u;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	if (SWEEP) {   // the closing T * bg pseudo entry (every tile gets one, also an empty tile)
 		__syncthreads();
 		if (threadIdx.x == 0 && nchunks * ACH < total + 1u && s_ovf == 0u) {
-			const uint32_t start = atomicAdd(&counter[0], (uint32_t)ACH);
+			const uint32_t start = nchunks == 0 ? (uint32_t)tile * ACH : atomicAdd(&counter[0], (uint32_t)ACH);
 			if (start + ACH > capacity) {
 				atomicExch(&counter[1], 1u);
 				s_ovf = 1u;
@@ -971,6 +974,15 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 	}
 }
 
+// counter[0] = work-list slots handed out, counter[1] = 0 ok / 1 the work list overflowed (the gated single-kernel
+// fallback renders the frame) / 2 the frame was aborted before the blend (deferred-count forward whose capacity
+// guess was too small: every blend kernel exits).  Replaces a memset so that the abort word is folded in.
+__global__ void arena_reset_kernel(uint32_t* __restrict__ counter, const uint32_t* __restrict__ abort, uint32_t first_free)
+{
+	counter[0] = first_free;   // slots [0, ntiles * 128) are the tiles' pre-assigned first chunks
+	counter[1] = (abort && *abort != 0u) ? 2u : 0u;
+}
+
 // The exact-format work list alone (fp32 weight rows + ids + list positions): the backward's first step.
 hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
 				     const float2* means2D, const float4* conic_opacity, float* final_T,
@@ -979,7 +991,9 @@ hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const 
 {
 	const int ntiles = gx * gy;
 	uint32_t* counter = (uint32_t*)(arena + lay.counter);
-	hipError_t e = hipMemsetAsync(counter, 0, 8, st);
+	hipLaunchKernelGGL(arena_reset_kernel, dim3(1), dim3(1), 0, st, counter, (const uint32_t*)nullptr,
+			   (uint32_t)ntiles * (uint32_t)ACH);
+	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(blend_weights_kernel<3>, dim3(((ntiles + 7) / 8) * 8), dim3(256), 0, st, ranges,
 			   point_list, means2D, conic_opacity, final_T, n_contrib,
@@ -1008,15 +1022,6 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	return a.total;
 }
 
-// counter[0] = work-list slots handed out, counter[1] = 0 ok / 1 the work list overflowed (the gated single-kernel
-// fallback renders the frame) / 2 the frame was aborted before the blend (deferred-count forward whose capacity
-// guess was too small: every blend kernel exits).  Replaces a memset so that the abort word is folded in.
-__global__ void arena_reset_kernel(uint32_t* __restrict__ counter, const uint32_t* __restrict__ abort)
-{
-	counter[0] = 0u;
-	counter[1] = (abort && *abort != 0u) ? 2u : 0u;
-}
-
 static unsigned long long* g_sweep_trace = nullptr;   // debug only (sgs_debug_set_sweep_trace)
 void set_sweep_trace(void* device_words) { g_sweep_trace = (unsigned long long*)device_words; }
 
@@ -1030,7 +1035,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	uint32_t* table = (uint32_t*)(arena + lay.table);
 	uint32_t* act_id = (uint32_t*)(arena + lay.act_id);
 	float* wgt = (float*)(arena + lay.wgt);
-	hipLaunchKernelGGL(arena_reset_kernel, dim3(1), dim3(1), 0, st, counter, a.abort);
+	hipLaunchKernelGGL(arena_reset_kernel, dim3(1), dim3(1), 0, st, counter, a.abort, (uint32_t)ntiles * (uint32_t)ACH);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 #define SGS_LAUNCH_W(M_, ST_, T0_, NT_)                                                             \
