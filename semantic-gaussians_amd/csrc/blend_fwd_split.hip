@@ -435,6 +435,16 @@ __global__ __launch_bounds__(1024) void sweep_plan_kernel(const uint32_t* __rest
 		key[s] = k;
 	}
 	__syncthreads();
+	if (np2 <= 1024) {   // few segments: rank by counting (keys are distinct), one pass over LDS
+		const int s = threadIdx.x;
+		if (s < n) {
+			const uint32_t mine = key[s];
+			int rank = 0;
+			for (int j = 0; j < n; j++) rank += key[j] > mine ? 1 : 0;
+			order[rank] = (uint32_t)(PLAN_MAX - 1) - (mine & 4095u);
+		}
+		return;
+	}
 	for (int k2 = 2; k2 <= np2; k2 <<= 1)   // bitonic sort, descending
 		for (int j = k2 >> 1; j > 0; j >>= 1) {
 			for (int i = threadIdx.x; i < np2; i += 1024) {

@@ -25,3 +25,19 @@ def test_random_shapes(orc, i):
     for mode in (0, 2):
         _check_forward(orc, scene, cam, binning_mode=mode)
     _check_forward(orc, scene, cam, variant=15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [16400, 66000])
+def test_sweep_plan_many_segments(H):
+    """The sweep's workgroup order (sweep_plan_kernel): more than 1024 segments take the bitonic sort, more than 4096
+    the unsorted deal -- the feature map must be the row-major order's, bit for bit (variant 0x1008)."""
+    import torch
+    from test_parity_gpu import _hip_forward
+    scene, cam = small_scene(P=30000, C=128, W=272, H=H, fx=300.0, seed=H)
+    a = _hip_forward(scene, cam, variant=0x1008)
+    ref_n, ref = a[0], a[1].clone()
+    del a
+    b = _hip_forward(scene, cam, variant=0)
+    assert b[0] == ref_n and ref_n > 0
+    assert torch.equal(b[1], ref)
