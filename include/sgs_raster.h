@@ -234,7 +234,13 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * see DESIGN.md 7.  Binning mode 0 only; ignored under debug; not for frames that will be differentiated (the
  * backward locates the lists from num_rendered).  2: as 1 with a capacity no frame fits (tests). */
 #define SGS_OPT_DEFER_COUNT 5
-#define SGS_OPT_COUNT 6
+/* 1: sgs_rasterize_backward clears dL_dcolor itself (the caller may pass uninitialised memory).  The reference's
+ * binding hands over torch::zeros for every gradient (CR/rasterize_points.cu:156-164) and so must a caller by
+ * default; for the N-channel gradient that fill is P * C * 4 bytes (2 GB at 1M x 512) of pure HBM writes in front
+ * of the backward -- with this option it is folded into the backward's first kernel (the work-list pre-pass, which
+ * is instruction bound and leaves the memory system idle): -0.2 ms at 1M x 512 x 968x1296. */
+#define SGS_OPT_BWD_CLEARS_DCOLOR 6
+#define SGS_OPT_COUNT 7
 /* value < 0 removes the override (the stream follows the process default again).  Returns the previous override,
  * or 0x7fffffff if there was none. */
 int sgs_stream_set_option(void *stream, int option, int value);

@@ -763,12 +763,13 @@ bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 }
 
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products)
+				      bool fp32_products, size_t clear_dcolor_floats)
 {
 	const int ntiles = a.gx * a.gy;
 	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
 						 const_cast<float*>(a.final_T), const_cast<uint32_t*>(a.n_contrib),
-						 arena, lay, a.W, a.H, a.gx, a.gy);
+						 arena, lay, a.W, a.H, a.gx, a.gy, clear_dcolor_floats ? a.dL_dcolors : nullptr,
+						 clear_dcolor_floats);
 	if (e != hipSuccess) return e;
 	const uint32_t* counter = (const uint32_t*)(arena + lay.counter);
 	const uint32_t* nact = (const uint32_t*)(arena + lay.nbatches);

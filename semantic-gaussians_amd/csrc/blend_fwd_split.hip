@@ -75,10 +75,18 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
 	uint32_t* __restrict__ act_id, uint32_t* __restrict__ act_idx, float* __restrict__ wgt,
 	uint32_t* __restrict__ table, uint32_t* __restrict__ nact, uint32_t* __restrict__ counter,
-	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles, unsigned long long* __restrict__ trace)
+	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles, unsigned long long* __restrict__ trace,
+	float4* __restrict__ clear_ptr, unsigned long long clear_n4)
 {
 	const int b = blockIdx.x;
 	const unsigned long long t_begin = trace ? wall_clock64() : 0ull;   // (debug timeline, tools/sweep_trace.py)
+	if (clear_ptr) {   // (backward, SGS_OPT_BWD_CLEARS_DCOLOR) this workgroup's slice of the gradient buffer: the stores
+		// drain under the instruction-bound work below
+		const unsigned long long per = (clear_n4 + gridDim.x - 1) / gridDim.x;
+		const unsigned long long i0 = (unsigned long long)b * per;
+		const unsigned long long i1 = i0 + per < clear_n4 ? i0 + per : clear_n4;
+		for (unsigned long long i = i0 + threadIdx.x; i < i1; i += 256) clear_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
 	static_assert(MODE == 2 || MODE == 3, "weights format: 2 = split bf16 (default), 3 = fp32 rows (exact)");
 	constexpr bool BF = MODE == 2;   // weights as split bf16, k-major groups of 8 (else fp32 rows of 256)
 	constexpr bool SWEEP = true;     // parity-major pixel order, closing T * bg pseudo entry, zero padding to 16
@@ -997,7 +1005,7 @@ __global__ void arena_reset_kernel(uint32_t* __restrict__ counter, const uint32_
 hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
 				     const float2* means2D, const float4* conic_opacity, float* final_T,
 				     uint32_t* n_contrib, char* arena, const SplitArena& lay, int W, int H, int gx,
-				     int gy)
+				     int gy, float* clear_ptr, size_t clear_floats)
 {
 	const int ntiles = gx * gy;
 	uint32_t* counter = (uint32_t*)(arena + lay.counter);
@@ -1010,7 +1018,7 @@ hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const 
 			   (uint32_t*)(arena + lay.act_id), (uint32_t*)(arena + lay.act_idx),
 			   (float*)(arena + lay.wgt), (uint32_t*)(arena + lay.table),
 			   (uint32_t*)(arena + lay.nbatches), counter, lay.capacity, W, H, gx, (ntiles + 7) / 8,
-			   ntiles, (unsigned long long*)nullptr);
+			   ntiles, (unsigned long long*)nullptr, (float4*)clear_ptr, (unsigned long long)(clear_floats / 4));
 	return hipGetLastError();
 }
 
@@ -1052,7 +1060,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3((((NT_) + 7) / 8) * 8), dim3(256), 0, ST_,    \
 			   a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, \
 			   act_id, (uint32_t*)nullptr, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, \
-			   ((NT_) + 7) / 8, NT_, g_sweep_trace ? g_sweep_trace + 4 * 4096 : nullptr)
+			   ((NT_) + 7) / 8, NT_, g_sweep_trace ? g_sweep_trace + 4 * 4096 : nullptr, (float4*)nullptr, 0ull)
 	{
 		// ---- row-sweep path (default)
 		// segment length: long sweeps amortise the prologue and leave few half-line stores at segment

@@ -848,6 +848,10 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 	a.dL_dconic = dL_dconic;
 	a.dL_dopacity = dL_dopacity;
 	a.dL_dcolors = dL_dcolor;
+	// SGS_OPT_BWD_CLEARS_DCOLOR: dL_dcolor arrives uninitialised; it is cleared by the work-list pre-pass where that
+	// path runs, by a memset otherwise
+	const size_t dcolor_floats = (size_t)P * (size_t)num_channels;
+	bool dcolor_dirty = cx->option(SGS_OPT_BWD_CLEARS_DCOLOR) > 0;
 	if (R > 0) {
 		hipError_t e = hipSuccess;
 		bool done = false;
@@ -883,7 +887,10 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 					     : hipMallocAsync(&scratch, bytes + 128, st);
 			if (ea == hipSuccess && scratch) {
 				char* arena = align_ptr((char*)scratch);
-				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3);
+				const bool fold = dcolor_dirty && (dcolor_floats & 3) == 0 && ((uintptr_t)dL_dcolor & 15u) == 0;
+				if (dcolor_dirty && !fold) (void)hipMemsetAsync(dL_dcolor, 0, dcolor_floats * 4, st);
+				dcolor_dirty = false;
+				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3, fold ? dcolor_floats : 0);
 				if (e == hipSuccess && cx->ensure(cx->bwd_usage_host, cx->bwd_ev)) {
 					if (hipMemcpyAsync(cx->bwd_usage_host, arena + lay.counter, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
 					    hipEventRecord(cx->bwd_ev, st) == hipSuccess)
@@ -896,8 +903,19 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 				(void)hipGetLastError();
 			}
 		}
-		if (!done) e = sgs::launch_blend_backward(st, a);
+		if (!done) {
+			if (dcolor_dirty) {
+				e = hipMemsetAsync(dL_dcolor, 0, dcolor_floats * 4, st);
+				if (e != hipSuccess) return fail_hip(e, "memset");
+				dcolor_dirty = false;
+			}
+			e = sgs::launch_blend_backward(st, a);
+		}
 		if (e != hipSuccess) return fail_hip(e, "blend backward");
+	}
+	if (dcolor_dirty && dcolor_floats) {   // (nothing was rendered)
+		const hipError_t e = hipMemsetAsync(dL_dcolor, 0, dcolor_floats * 4, st);
+		if (e != hipSuccess) return fail_hip(e, "memset");
 	}
 	SGS_CHECK_STAGE("blend backward");
 

@@ -130,7 +130,7 @@ hipError_t launch_blend_forward_fused_pc(hipStream_t st, const BlendFwdArgs& a, 
 hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
 				     const float2* means2D, const float4* conic_opacity, float* final_T,
 				     uint32_t* n_contrib, char* arena, const SplitArena& lay, int W, int H, int gx,
-				     int gy);
+				     int gy, float* clear_ptr = nullptr, size_t clear_floats = 0);   // clear: optional buffer this kernel zero-fills (a multiple of 4 floats, 16-B aligned)
 
 // ---- blend_bwd.hip
 struct BlendBwdArgs {
@@ -157,8 +157,9 @@ hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const ui
 // split_arena_bytes(capacity, ...) bytes.
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a);
 // fp32_products: the two channel products on v_mfma_f32_32x32x2_f32 (exact fp32 products) instead of split bf16
+// clear_dcolor: a.dL_dcolors (P x C floats) is zero-filled by the first kernel instead of by the caller
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products);
+				      bool fp32_products, size_t clear_dcolor_floats = 0);
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
 			   const int* radii, const float* shs, const uint8_t* clamped,
 			   const float* scales, const float* rotations, float mod,

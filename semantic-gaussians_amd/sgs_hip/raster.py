@@ -265,16 +265,22 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
     M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
     opts = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        dL_dmeans3D = torch.zeros(P, 3, **opts)
-        dL_dmeans2D = torch.zeros(P, 3, **opts)
-        dL_dcolors = torch.zeros(P, Cn, **opts)
-        dL_dconic = torch.zeros(P, 2, 2, **opts)
-        dL_dopacity = torch.zeros(P, 1, **opts)
-        dL_dcov3D = torch.zeros(P, 6, **opts)
-        dL_dsh = torch.zeros(P, M, 3, **opts)
-        dL_dscales = torch.zeros(P, 3, **opts)
-        dL_drotations = torch.zeros(P, 4, **opts)
+        # the per-Gaussian gradients: ONE zero-filled allocation carved into the eight tensors (one fill kernel instead
+        # of eight), each a contiguous view
+        widths = (3, 3, 4, 1, 6, 3 * M, 3, 4)
+        flat = torch.zeros(P * sum(widths), **opts)
+        parts, off = [], 0
+        for w in widths:
+            parts.append(flat[off:off + P * w])
+            off += P * w
+        dL_dmeans3D, dL_dmeans2D = parts[0].view(P, 3), parts[1].view(P, 3)
+        dL_dconic, dL_dopacity, dL_dcov3D = parts[2].view(P, 2, 2), parts[3].view(P, 1), parts[4].view(P, 6)
+        dL_dsh, dL_dscales, dL_drotations = parts[5].view(P, M, 3), parts[6].view(P, 3), parts[7].view(P, 4)
+        # the (P, C) colour gradient: the library clears it inside its first kernel (SGS_OPT_BWD_CLEARS_DCOLOR)
+        dL_dcolors = torch.empty(P, Cn, **opts) if P != 0 else torch.zeros(P, Cn, **opts)
         if P != 0:
+            sp = _stream_ptr(dev)
+            prev_clear = lib.sgs_stream_set_option(sp, _lib.OPT_BWD_CLEARS_DCOLOR, 1)
             keep = []
 
             def p(t, name, dtype=torch.float32):
@@ -295,7 +301,8 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
                 Cn, dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
-                dL_drotations.data_ptr(), int(bool(debug)), _stream_ptr(dev))
+                dL_drotations.data_ptr(), int(bool(debug)), sp)
+            lib.sgs_stream_set_option(sp, _lib.OPT_BWD_CLEARS_DCOLOR, -1 if prev_clear == 0x7fffffff else prev_clear)
             _lib.check(rc, "rasterize_gaussians_backward failed")
     return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
             dL_drotations)
