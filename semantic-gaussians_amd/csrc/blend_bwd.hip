@@ -149,24 +149,29 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 			float* __restrict__ dcol = dL_dcolors + (size_t)id * C + c0;
 			float S = 0.f;
 			float* acc_row = COMBINE ? &s_acc[(wave * 64 + (k - kb)) * NV] : nullptr;
-			float mine = 0.f;   // (CC = 32) lane c: the wave's sum for channel c
+			const int comp = wave_sum8_component(lane);
+			const bool head = (lane & 7) == 0;   // the lanes wave_sum8 leaves its eight totals in
+			float pc[8];   // (RGB chunk) this lane's wgt * g[c], 0 beyond cn
+#pragma unroll
+			for (int j = 0; j < 8; j++) pc[j] = 0.f;
+			float mine = 0.f;   // (32-channel chunk) lane c: the wave's sum for channel c
 #pragma unroll
 			for (int c = 0; c < CC; c++) {
 				if (c < cn) {
 					const float cv = col[c];
 					// contribution to dL/dalpha uses the colour accumulated BEHIND this entry
 					S += (cv - rec[c]) * g[c];
-					const float gc = wave_sum(wgt * g[c]);
 					if (COMBINE) {
-						if (lane == 0) acc_row[6 + c] = gc;
-					} else if (lane == c) {
-						mine = gc;
+						pc[c & 7] = wgt * g[c];
+					} else {
+						const float gc = wave_sum(wgt * g[c]);
+						if (lane == c) mine = gc;
 					}
 					// fold this entry into the running "behind" colour for the next one
 					if (valid) rec[c] = alpha * cv + oma * rec[c];
 				}
 			}
-			if (!COMBINE && lane < cn) atomicAdd(&dcol[lane], mine);
+			if (!COMBINE && lane < cn) atomicAdd(&dcol[lane], mine);   // one coalesced row of atomics per wave
 			float dL_dalpha = S * T;
 			dL_dalpha += (-T_final / oma) * bg_dot;
 			if (!valid) dL_dalpha = 0.f;
@@ -175,28 +180,24 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 			const float gdx = Gv * dx, gdy = Gv * dy;
 			const float dG_ddelx = -gdx * e.ca - gdy * e.cb;
 			const float dG_ddely = -gdy * e.cc - gdx * e.cb;
-			const float m0 = wave_sum(dL_dG * dG_ddelx * ddelx_dx);
-			const float m1 = wave_sum(dL_dG * dG_ddely * ddely_dy);
-			const float k0 = wave_sum(-0.5f * gdx * dx * dL_dG);
-			const float k1 = wave_sum(-0.5f * gdx * dy * dL_dG);
-			const float k3 = wave_sum(-0.5f * gdy * dy * dL_dG);
-			const float op = wave_sum(Gv * dL_dalpha);
+			// the six geometry sums (+ the first two colour sums of an RGB chunk) in one transposed reduction
+			const float u = wave_sum8(dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy, -0.5f * gdx * dx * dL_dG,
+						  -0.5f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG, Gv * dL_dalpha,
+						  COMBINE ? pc[0] : 0.f, COMBINE ? pc[1] : 0.f);
 			if (COMBINE) {
-				if (lane == 0) {
-					acc_row[0] = m0;
-					acc_row[1] = m1;
-					acc_row[2] = k0;
-					acc_row[3] = k1;
-					acc_row[4] = k3;
-					acc_row[5] = op;
+				if (head) acc_row[comp] = u;   // slots 0-5 geometry, 6 / 7 = colour channels 0 / 1
+#pragma unroll
+				for (int c = 2; c < CC; c++) {
+					if (c < cn) {
+						const float gc = wave_sum(pc[c]);
+						if (lane == 0) acc_row[6 + c] = gc;
+					}
 				}
-			} else if (lane == 0) {
-				atomicAdd(&dL_dmean2D[3 * (size_t)id], m0);
-				atomicAdd(&dL_dmean2D[3 * (size_t)id + 1], m1);
-				atomicAdd(&dL_dconic[4 * (size_t)id], k0);
-				atomicAdd(&dL_dconic[4 * (size_t)id + 1], k1);
-				atomicAdd(&dL_dconic[4 * (size_t)id + 3], k3);
-				atomicAdd(&dL_dopacity[id], op);
+			} else if (head && comp < 6) {
+				float* dst = comp < 2 ? dL_dmean2D + 3 * (size_t)id + comp
+					   : comp < 5 ? dL_dconic + 4 * (size_t)id + (comp == 4 ? 3 : comp - 2)
+						      : dL_dopacity + id;
+				atomicAdd(dst, u);
 			}
 		}
 		if (COMBINE) {   // one atomic per (entry, component) of this group of 64 entries

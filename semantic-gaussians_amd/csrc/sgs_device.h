@@ -77,6 +77,36 @@ __device__ __forceinline__ float wave_sum(float v)
 	return (r0 + r1) + (r2 + r3);
 }
 
+// Eight wave64 sums at once, as a transposed reduction: 18 VALU instead of 8 x 11.  Each step halves the number of
+// lanes a partial sum is spread over AND the number of live registers: v_permlane32_swap / v_permlane16_swap exchange
+// halves / 16-lane rows between two registers so that one add folds two components at a time; from 8 lanes down, DPP.
+// Result: lane l with (l & 7) == 0 holds the total of component wave_sum8_component(l) (other lanes: partial sums).
+__device__ __forceinline__ int wave_sum8_component(int lane) { return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2); }
+__device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
+{
+	// (inline asm, not __builtin_amdgcn_permlane*_swap: hipcc 7.2 folds `s[0] + s[1]` of the builtin's result pair into
+	// `s[0] + s[0]`; the s_nop covers the VALU-write -> permlane-read distance the compiler cannot see into the asm for)
+	auto fold32 = [](float a, float b) __attribute__((always_inline)) {   // lanes < 32: sum of a's halves; >= 32: of b's
+		asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+		return a + b;
+	};
+	auto fold16 = [](float a, float b) __attribute__((always_inline)) {   // rows 0 / 2: a's row pairs; rows 1 / 3: b's
+		asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+		return a + b;
+	};
+	const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7);
+	const float s01 = fold16(r0, r1), s23 = fold16(r2, r3);
+	// 16 -> 8 lanes: lanes with bit 3 clear keep s01, the others s23; the partner's value arrives by a row rotation by 8
+	const bool up = (__lane_id() & 8) != 0;
+	const float keep = up ? s23 : s01, give = up ? s01 : s23;
+	float u = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0x128, 0xF, 0xF, false));
+	// 8 -> 1 inside each group of 8 lanes: row_half_mirror, quad reverse [3,2,1,0] = 0x1B, quad_perm [1,0,3,2] = 0xB1
+	u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x141, 0xF, 0xF, false));
+	u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x1B, 0xF, 0xF, false));
+	u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, false));
+	return u;
+}
+
 // Blend exponential ("exp contract"): range reduction by the 1.5*2^23 magic
 // add, two-term ln2, degree-5 Horner with explicit fma, exponent insertion by integer
 // add.  <= 5 ulp from exp(); reproduced bit for bit by the oracle so that the
