@@ -87,11 +87,11 @@ __device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v
 	// (inline asm, not __builtin_amdgcn_permlane*_swap: hipcc 7.2 folds `s[0] + s[1]` of the builtin's result pair into
 	// `s[0] + s[0]`; the s_nop covers the VALU-write -> permlane-read distance the compiler cannot see into the asm for)
 	auto fold32 = [](float a, float b) __attribute__((always_inline)) {   // lanes < 32: sum of a's halves; >= 32: of b's
-		asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+		asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 		return a + b;
 	};
 	auto fold16 = [](float a, float b) __attribute__((always_inline)) {   // rows 0 / 2: a's row pairs; rows 1 / 3: b's
-		asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+		asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 		return a + b;
 	};
 	const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7);
