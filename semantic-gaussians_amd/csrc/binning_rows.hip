@@ -31,6 +31,8 @@ namespace sgs {
 namespace {
 constexpr int RCH = 64;    // items per chunk (one wave)
 constexpr int RGRP = 32;   // chunks per scan group
+constexpr int SCAT_CPW = 1;      // chunks per wave of the scatter kernels (4 was measured: 54 -> 76 us -- the kernel wants MORE waves in flight, not fewer launches)
+constexpr int SCAT_CAP = 512;    // stage B scatter: ids a wave stages in LDS per chunk (beyond: written directly)
 
 // wave-uniform: the segment whose chunk range contains `id`: largest s with first[s] <= id.  The
 // table (nseg + 1 entries, first[nseg] = total > id) is read 64 entries per load and resolved with a
@@ -151,7 +153,7 @@ template <bool FROM_RANKS>
 __global__ __launch_bounds__(256) void span_hist_kernel(
 	int nb, int nseg, const uint32_t* __restrict__ segstart, const uint32_t* __restrict__ chunk0,
 	const uint2* __restrict__ items, const uint4* __restrict__ rrec, uint32_t* __restrict__ cmat,
-	const uint32_t* __restrict__ abort)
+	const uint32_t* __restrict__ grp0, uint4* __restrict__ desc, const uint32_t* __restrict__ abort)
 {
 	if (abort && *abort != 0u) return;
 	extern __shared__ int s_diff[];   // [4 waves][nb + 1]
@@ -163,6 +165,9 @@ __global__ __launch_bounds__(256) void span_hist_kernel(
 	if (c >= chunk0[nseg]) return;
 	const int s = seg_of(chunk0, nseg, c);
 	const uint32_t idx = segstart[s] + (c - chunk0[s]) * RCH + (uint32_t)lane, end = segstart[s + 1];
+	// the chunk's descriptor for the scatter kernel (segment, scan group, first item, end of the segment): the scatter's
+	// waves are bound by their chain of dependent loads, and this is three links of it
+	if (lane == 0) desc[c] = make_uint4((uint32_t)s, grp0[s] + (c - chunk0[s]) / RGRP, idx, end);
 	uint32_t lo = 0, hi = 0;
 	if (FROM_RANKS) {
 		if (idx < end) {
@@ -262,10 +267,12 @@ __global__ __launch_bounds__(256) void span_scan_lists_kernel(int nb, int nseg, 
 // exclusive scan of n list lengths in list order.  RANGES: ranges[t] = [start, start + len), (0, 0) for an
 // empty tile as the reference's memset + identifyTileRanges leaves it (CR/cuda_rasterizer/
 // rasterizer_impl.cu:116-138,313); else starts[t] = start, starts[n] = total.  One workgroup.
+// RANGES also writes the list starts once more, segment-major (tstart[s * nb + b]): the stage B scatter reads a
+// segment's nb starts per chunk, which in `ranges` are gx * 8 bytes apart (one cache line each).
 template <bool RANGES>
 __global__ __launch_bounds__(1024) void list_scan_kernel(int n, const uint32_t* __restrict__ len,
 							  uint2* __restrict__ ranges, uint32_t* __restrict__ starts,
-							  const uint32_t* __restrict__ abort)
+							  const uint32_t* __restrict__ abort, int gx, int major_x, int nb)
 {
 	if (abort && *abort != 0u) return;
 	__shared__ uint32_t s_part[1024];
@@ -284,8 +291,13 @@ __global__ __launch_bounds__(1024) void list_scan_kernel(int n, const uint32_t* 
 	uint32_t run = s_part[threadIdx.x] - sum;
 	for (int t = t0; t < t1; t++) {
 		const uint32_t m = len[t];
-		if (RANGES) ranges[t] = m ? make_uint2(run, run + m) : make_uint2(0u, 0u);
-		else starts[t] = run;
+		if (RANGES) {
+			ranges[t] = m ? make_uint2(run, run + m) : make_uint2(0u, 0u);
+			const int x = t % gx, y = t / gx;
+			starts[(major_x ? x : y) * nb + (major_x ? y : x)] = run;
+		} else {
+			starts[t] = run;
+		}
 		run += m;
 	}
 	if (!RANGES && threadIdx.x == 1023) starts[n] = s_part[1023];
@@ -299,22 +311,24 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 	const uint32_t* __restrict__ grp0, const uint2* __restrict__ items, const uint4* __restrict__ rrec,
 	const uint32_t* __restrict__ cmat, const uint32_t* __restrict__ gtot, const uint32_t* __restrict__ starts,
 	const uint2* __restrict__ ranges, int seg_stride, int bin_stride, uint2* __restrict__ out_items,
-	uint32_t* __restrict__ point_list, const uint32_t* __restrict__ abort)
+	uint32_t* __restrict__ point_list, const uint4* __restrict__ desc, const uint32_t* __restrict__ abort)
 {
 	if (abort && *abort != 0u) return;
 	extern __shared__ uint32_t s_base[];   // [4 waves][nb]: first position of this chunk in each list
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t c = blockIdx.x * 4u + (uint32_t)wave;
-	if (c >= chunk0[nseg]) return;   // (no barrier in this kernel: waves are independent)
-	const int s = seg_of(chunk0, nseg, c);
-	const uint32_t G = grp0[s] + (c - chunk0[s]) / RGRP;
+	// a wave takes SCAT_CPW consecutive chunks (1: see the constant)
+	const uint32_t nchunks_all = chunk0[nseg];
+	auto one_chunk = [&](const uint32_t c) __attribute__((always_inline)) {
+	const uint4 dsc = desc[c];   // written by span_hist_kernel: (segment, scan group, first item, segment end)
+	const int s = (int)__builtin_amdgcn_readfirstlane((int)dsc.x);
+	const uint32_t G = (uint32_t)__builtin_amdgcn_readfirstlane((int)dsc.y);
 	uint32_t* base = s_base + wave * nb;
 	for (int b = lane; b < nb; b += 64) {
 		const int list = s * seg_stride + b * bin_stride;
-		base[b] = (FROM_RANKS ? starts[list] : ranges[list].x) + gtot[(size_t)G * nb + b] + cmat[(size_t)c * nb + b];
+		base[b] = (FROM_RANKS ? starts[list] : starts[(size_t)s * nb + b]) + gtot[(size_t)G * nb + b] + cmat[(size_t)c * nb + b];
 	}
-	const uint32_t idx = segstart[s] + (c - chunk0[s]) * RCH + (uint32_t)lane, end = segstart[s + 1];
+	const uint32_t idx = dsc.z + (uint32_t)lane, end = dsc.w;
 	uint32_t g = 0, lo = 0, hi = 0, payload = 0;
 	if (FROM_RANKS) {
 		if (idx < end) {
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 	}
 	blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo);
 	bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
-	if (blo >= bhi) return;   // no item of this chunk covers a bin
+	if (blo >= bhi) return;   // no item of this chunk covers a bin (next chunk)
 	// Which lanes cover bin b, as a 64-bit mask per bin in LDS: every lane ORs its bit into the bins of its own span
 	// (L / R = 4 bins per item on average) -- instead of one ballot per bin of the wave's whole range, which for 64
 	// depth-consecutive items is most of the axis (61 ballots + popcounts per wave; the kernel was issue bound on
@@ -352,10 +366,55 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 	for (uint32_t b = lo; b < hi; b++) atomicOr(&cover[b], mine);
 	__builtin_amdgcn_wave_barrier();
 	const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	if (!FROM_RANKS) {
+		// Stage B writes 4-byte ids, ~4 per item, each into a different list: written straight from the lane loop
+		// that is 64 separate memory requests per instruction and the kernel is bound by the L2's request rate
+		// (16.5 M requests at cfg3).  So the chunk's output is first laid out in LDS grouped by bin (a bin's
+		// entries are consecutive in its list), then written with consecutive lanes on consecutive entries: one
+		// request per run instead of one per id.
+		uint32_t* off = s_base + 4 * nb + 8 * nb + (size_t)wave * nb;                       // [4][nb] after the masks
+		uint32_t* st_g = s_base + 4 * nb + 8 * nb + 4 * nb + (size_t)wave * SCAT_CAP;        // [4][SCAT_CAP]
+		uint16_t* st_b = reinterpret_cast<uint16_t*>(s_base + 4 * nb + 8 * nb + 4 * nb + 4 * SCAT_CAP) + (size_t)wave * SCAT_CAP;
+		uint32_t total = 0;
+		for (uint32_t b0 = blo; b0 < bhi; b0 += 64) {   // per bin: entries of this chunk, exclusive prefix
+			const uint32_t b = b0 + (uint32_t)lane;
+			const uint32_t c = b < bhi ? (uint32_t)__popcll(cover[b]) : 0u;
+			uint32_t incl = c;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+				if (lane >= o) incl += u;
+			}
+			if (b < bhi) {
+				off[b] = total + incl - c;
+				base[b] -= total + incl - c;   // list position of staged entry i of bin b = i + base[b]
+			}
+			total += (uint32_t)__shfl((int)incl, 63);
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (total <= (uint32_t)SCAT_CAP) {
+			for (uint32_t b = lo; b < hi; b++) {
+				const uint32_t i = off[b] + (uint32_t)__popcll(cover[b] & below);
+				st_g[i] = g;
+				st_b[i] = (uint16_t)b;
+			}
+			__builtin_amdgcn_wave_barrier();
+			for (uint32_t i = (uint32_t)lane; i < total; i += 64) point_list[i + base[st_b[i]]] = st_g[i];
+		} else {   // (a chunk of very large items: more entries than the staging area holds)
+			for (uint32_t b = lo; b < hi; b++) point_list[off[b] + base[b] + (uint32_t)__popcll(cover[b] & below)] = g;
+		}
+		return;
+	}
 	for (uint32_t b = lo; b < hi; b++) {
 		const uint32_t pos = base[b] + (uint32_t)__popcll(cover[b] & below);
-		if (FROM_RANKS) out_items[pos] = make_uint2(g, payload);
-		else point_list[pos] = g;
+		out_items[pos] = make_uint2(g, payload);
+	}
+	};
+	const uint32_t c_first = (blockIdx.x * 4u + (uint32_t)wave) * (uint32_t)SCAT_CPW;
+	for (int it = 0; it < SCAT_CPW; it++) {
+		if (c_first + (uint32_t)it >= nchunks_all) break;
+		one_chunk(c_first + (uint32_t)it);
+		__builtin_amdgcn_wave_barrier();   // the next chunk reuses this wave's LDS areas
 	}
 }
 
@@ -368,9 +427,9 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 	const size_t chB = (size_t)R / RCH + (size_t)nbA, grB = chB / RGRP + (size_t)nbA;
 	const size_t cmA = chA * nbA, cmB = chB * nbB, gtA = grA * nbA, gtB = grB * nbB;
 	*tab_words = 3 * ((size_t)nbA + 2) + 8;          // segstart | chunk0 | grp0 of stage B (+ stage A's two-entry tables)
-	*cmat_words = cmA > cmB ? cmA : cmB;              // the stages run one after the other
+	*cmat_words = (cmA > cmB ? cmA : cmB) + 4 * (chA > chB ? chA : chB) + 4;   // the stages run one after the other; + chunk descriptors
 	*gtot_words = gtA > gtB ? gtA : gtB;
-	*len_words = (size_t)gx * gy + nbA + 2;           // tile lengths (stage B) | bin lengths (stage A)
+	*len_words = 2 * (size_t)gx * gy + nbA + 2;       // tile lengths (stage B) | bin lengths (stage A) | segment-major list starts
 }
 
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
@@ -388,38 +447,44 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	uint32_t* chunk0A = segA + 2;
 	uint32_t* grp0A = segA + 4;
 	uint32_t* binlen = lens + ntiles;         // stage A list lengths
+	uint32_t* tstart = lens + ntiles + nbA + 2;   // stage B list starts, segment-major
 	const uint32_t chA = ((uint32_t)P + RCH - 1) / RCH, grA = (chA + RGRP - 1) / RGRP;
 	const size_t ldsA = (size_t)4 * (nbA + 1) * 4, ldsB = (size_t)4 * (nbB + 1) * 4;
+	const uint32_t chB_ub = R / RCH + (uint32_t)nbA;
+	// chunk descriptors (16 B each, 16-byte aligned) behind the larger of the two count matrices
+	const size_t cmA_w = (size_t)chA * nbA, cmB_w = (size_t)chB_ub * nbB;
+	uint4* desc = reinterpret_cast<uint4*>(cmat + (((cmA_w > cmB_w ? cmA_w : cmB_w) + 3) & ~(size_t)3));
 	// the ballot-free scatter: [4 waves][nb] list bases (uint32) + [4 waves][nb] cover masks (uint64, 8-byte aligned)
-	const size_t ldsSA = (size_t)4 * nbA * 4 + (size_t)4 * nbA * 8, ldsSB = (size_t)4 * nbB * 4 + (size_t)4 * nbB * 8;
+	const size_t ldsSA = (size_t)4 * nbA * 4 + (size_t)4 * nbA * 8;
+	const size_t ldsSB = (size_t)4 * nbB * 4 + (size_t)4 * nbB * 8 + (size_t)4 * nbB * 4 + (size_t)4 * SCAT_CAP * 6;   // + prefixes + staging
 
 	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
 	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
 	hipLaunchKernelGGL(span_hist_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A,
-			   (const uint2*)nullptr, rrec, cmat, abort);
+			   (const uint2*)nullptr, rrec, cmat, grp0A, desc, abort);
 	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grA * nbA + 255) / 256)), dim3(256), 0, st,
 			   nbA, 1, chunk0A, grp0A, cmat, gtot, abort);
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
 			   binlen, abort);
-	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort);
-	hipLaunchKernelGGL(span_scatter_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsSA, st, nbA, 1, segA, chunk0A, grp0A,
+	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort, 1, 1, 1);
+	hipLaunchKernelGGL(span_scatter_kernel<true>, dim3((chA + 4 * SCAT_CPW - 1) / (4 * SCAT_CPW)), dim3(256), ldsSA, st, nbA, 1, segA, chunk0A, grp0A,
 			   (const uint2*)nullptr, rrec, cmat, gtot, segB, (const uint2*)nullptr, 0, 1, items,
-			   (uint32_t*)nullptr, abort);
+			   (uint32_t*)nullptr, desc, abort);
 
 	// ---- stage B: the major instances of each major bin -> per-tile lists
 	const uint32_t chB = R / RCH + (uint32_t)nbA, grB = chB / RGRP + (uint32_t)nbA;   // upper bounds
 	const int seg_stride = major_x ? 1 : gx, bin_stride = major_x ? gx : 1;          // tile = y * gx + x
 	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, nbA, R, segB, false, chunk0B, grp0B, abort);
 	hipLaunchKernelGGL(span_hist_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B, items,
-			   rrec, cmat, abort);
+			   rrec, cmat, grp0B, desc, abort);
 	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grB * nbB + 255) / 256)), dim3(256), 0, st,
 			   nbB, nbA, chunk0B, grp0B, cmat, gtot, abort);
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
 			   seg_stride, bin_stride, lens, abort);
-	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, (uint32_t*)nullptr, abort);
-	hipLaunchKernelGGL(span_scatter_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsSB, st, nbB, nbA, segB, chunk0B,
-			   grp0B, items, rrec, cmat, gtot, (const uint32_t*)nullptr, ranges, seg_stride, bin_stride,
-			   (uint2*)nullptr, point_list, abort);
+	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB);
+	hipLaunchKernelGGL(span_scatter_kernel<false>, dim3((chB + 4 * SCAT_CPW - 1) / (4 * SCAT_CPW)), dim3(256), ldsSB, st, nbB, nbA, segB, chunk0B,
+			   grp0B, items, rrec, cmat, gtot, tstart, ranges, seg_stride, bin_stride,
+			   (uint2*)nullptr, point_list, desc, abort);
 	return hipGetLastError();
 }
 

@@ -14,10 +14,12 @@ feats = torch.randn(P, C, device=DEV, generator=g); feats /= feats.norm(dim=1, k
 s, c = scene._replace(features=torch.empty(0, C)).to(DEV), cam.to(DEV)
 bg = torch.zeros(C, device=DEV)
 pool = raster.ScratchPool()
+if len(sys.argv) > 1:
+    raster.set_binning_mode(int(sys.argv[1]))   # 3 = the library radix sort as the depth presort
 def fwd():
     return raster.rasterize_forward(bg, s.means3D, feats, s.opacities, s.scales, s.rotations, 1.0, E, c.world_view_transform,
                                     c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, E, 0, c.camera_center, False, False, C, False, pool=pool)
-for align in (0, 32, 0, 32):
+for align in (0, 32):
     raster.OUTPUT_PITCH_ALIGN = align
     for _ in range(3): fwd()
     torch.cuda.synchronize(); raster.get_stage_ms(); raster.set_stage_timing(2)
