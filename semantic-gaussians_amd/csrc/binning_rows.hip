@@ -32,6 +32,9 @@ namespace {
 constexpr int RCH = 64;    // items per chunk (one wave)
 constexpr int RGRP = 32;   // chunks per scan group
 constexpr int SCAT_CPW = 1;      // chunks per wave of the scatter kernels (4 was measured: 54 -> 76 us -- the kernel wants MORE waves in flight, not fewer launches)
+// scatter kernels: SCAT_NW waves per workgroup (template; 16 unless a long bin axis makes the per-wave LDS tables too big).
+// The waves are independent: a big workgroup only amortises the launch (PMC: the kernel holds 1.4 waves per SIMD in
+// flight with 4-wave workgroups = workgroups launched per us x wave lifetime).
 constexpr int SCAT_CAP = 512;    // stage B scatter: ids a wave stages in LDS per chunk (beyond: written directly)
 
 // wave-uniform: the segment whose chunk range contains `id`: largest s with first[s] <= id.  The
@@ -305,8 +308,8 @@ __global__ __launch_bounds__(1024) void list_scan_kernel(int n, const uint32_t* 
 
 // the ballot sweep: every covering item is written to its final position in the list of
 // (segment, bin).  OUT_ITEMS: stage A (the item with its payload span); else the Gaussian id.
-template <bool FROM_RANKS>
-__global__ __launch_bounds__(256) void span_scatter_kernel(
+template <bool FROM_RANKS, int SCAT_NW>
+__global__ __launch_bounds__(64 * SCAT_NW) void span_scatter_kernel(
 	int nb, int nseg, const uint32_t* __restrict__ segstart, const uint32_t* __restrict__ chunk0,
 	const uint32_t* __restrict__ grp0, const uint2* __restrict__ items, const uint4* __restrict__ rrec,
 	const uint32_t* __restrict__ cmat, const uint32_t* __restrict__ gtot, const uint32_t* __restrict__ starts,
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 	// (L / R = 4 bins per item on average) -- instead of one ballot per bin of the wave's whole range, which for 64
 	// depth-consecutive items is most of the axis (61 ballots + popcounts per wave; the kernel was issue bound on
 	// them).  The rank of an item inside a bin's list is still popcount(mask & lanes_below): same positions, same bits.
-	unsigned long long* cover = reinterpret_cast<unsigned long long*>(s_base + 4 * nb) + (size_t)wave * nb;   // (4 nb words: 16-byte aligned)
+	unsigned long long* cover = reinterpret_cast<unsigned long long*>(s_base + SCAT_NW * nb) + (size_t)wave * nb;   // (16-byte aligned)
 	for (uint32_t b = blo + (uint32_t)lane; b < bhi; b += 64) cover[b] = 0ull;
 	__builtin_amdgcn_wave_barrier();
 	const unsigned long long mine = 1ull << lane;
@@ -372,9 +375,9 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 		// (16.5 M requests at cfg3).  So the chunk's output is first laid out in LDS grouped by bin (a bin's
 		// entries are consecutive in its list), then written with consecutive lanes on consecutive entries: one
 		// request per run instead of one per id.
-		uint32_t* off = s_base + 4 * nb + 8 * nb + (size_t)wave * nb;                       // [4][nb] after the masks
-		uint32_t* st_g = s_base + 4 * nb + 8 * nb + 4 * nb + (size_t)wave * SCAT_CAP;        // [4][SCAT_CAP]
-		uint16_t* st_b = reinterpret_cast<uint16_t*>(s_base + 4 * nb + 8 * nb + 4 * nb + 4 * SCAT_CAP) + (size_t)wave * SCAT_CAP;
+		uint32_t* off = s_base + 3 * SCAT_NW * nb + (size_t)wave * nb;                      // [waves][nb] after the masks
+		uint32_t* st_g = s_base + 4 * SCAT_NW * nb + (size_t)wave * SCAT_CAP;               // [waves][SCAT_CAP]
+		uint16_t* st_b = reinterpret_cast<uint16_t*>(s_base + 4 * SCAT_NW * nb + SCAT_NW * SCAT_CAP) + (size_t)wave * SCAT_CAP;
 		uint32_t total = 0;
 		for (uint32_t b0 = blo; b0 < bhi; b0 += 64) {   // per bin: entries of this chunk, exclusive prefix
 			const uint32_t b = b0 + (uint32_t)lane;
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256) void span_scatter_kernel(
 		out_items[pos] = make_uint2(g, payload);
 	}
 	};
-	const uint32_t c_first = (blockIdx.x * 4u + (uint32_t)wave) * (uint32_t)SCAT_CPW;
+	const uint32_t c_first = (blockIdx.x * (uint32_t)SCAT_NW + (uint32_t)wave) * (uint32_t)SCAT_CPW;
 	for (int it = 0; it < SCAT_CPW; it++) {
 		if (c_first + (uint32_t)it >= nchunks_all) break;
 		one_chunk(c_first + (uint32_t)it);
@@ -455,8 +458,11 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	const size_t cmA_w = (size_t)chA * nbA, cmB_w = (size_t)chB_ub * nbB;
 	uint4* desc = reinterpret_cast<uint4*>(cmat + (((cmA_w > cmB_w ? cmA_w : cmB_w) + 3) & ~(size_t)3));
 	// the ballot-free scatter: [4 waves][nb] list bases (uint32) + [4 waves][nb] cover masks (uint64, 8-byte aligned)
-	const size_t ldsSA = (size_t)4 * nbA * 4 + (size_t)4 * nbA * 8;
-	const size_t ldsSB = (size_t)4 * nbB * 4 + (size_t)4 * nbB * 8 + (size_t)4 * nbB * 4 + (size_t)4 * SCAT_CAP * 6;   // + prefixes + staging
+	// per wave: bases + masks (+ prefixes + staging in stage B); as many waves per workgroup as fit 64 KB
+	const size_t ldsWA = (size_t)nbA * 12, ldsWB = (size_t)nbB * 16 + (size_t)SCAT_CAP * 6;
+	const int nwA = 16 * ldsWA <= 65536 ? 16 : (4 * ldsWA <= 65536 ? 4 : 1);
+	const int nwB = 4 * ldsWB <= 65536 ? 4 : 1;   // (16 measured slower for stage B: 58 vs 53 us; stage A: 20 vs 22)
+	const size_t ldsSA = nwA * ldsWA, ldsSB = nwB * ldsWB;
 
 	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
 	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
@@ -467,9 +473,14 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
 			   binlen, abort);
 	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort, 1, 1, 1);
-	hipLaunchKernelGGL(span_scatter_kernel<true>, dim3((chA + 4 * SCAT_CPW - 1) / (4 * SCAT_CPW)), dim3(256), ldsSA, st, nbA, 1, segA, chunk0A, grp0A,
-			   (const uint2*)nullptr, rrec, cmat, gtot, segB, (const uint2*)nullptr, 0, 1, items,
-			   (uint32_t*)nullptr, desc, abort);
+#define SGS_SCATTER_A(NW_)                                                                                          \
+	hipLaunchKernelGGL((span_scatter_kernel<true, NW_>), dim3((chA + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)),  \
+			   dim3(64 * NW_), ldsSA, st, nbA, 1, segA, chunk0A, grp0A, (const uint2*)nullptr, rrec,    \
+			   cmat, gtot, segB, (const uint2*)nullptr, 0, 1, items, (uint32_t*)nullptr, desc, abort)
+	if (nwA == 16) SGS_SCATTER_A(16);
+	else if (nwA == 4) SGS_SCATTER_A(4);
+	else SGS_SCATTER_A(1);
+#undef SGS_SCATTER_A
 
 	// ---- stage B: the major instances of each major bin -> per-tile lists
 	const uint32_t chB = R / RCH + (uint32_t)nbA, grB = chB / RGRP + (uint32_t)nbA;   // upper bounds
@@ -482,9 +493,13 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
 			   seg_stride, bin_stride, lens, abort);
 	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB);
-	hipLaunchKernelGGL(span_scatter_kernel<false>, dim3((chB + 4 * SCAT_CPW - 1) / (4 * SCAT_CPW)), dim3(256), ldsSB, st, nbB, nbA, segB, chunk0B,
-			   grp0B, items, rrec, cmat, gtot, tstart, ranges, seg_stride, bin_stride,
-			   (uint2*)nullptr, point_list, desc, abort);
+#define SGS_SCATTER_B(NW_)                                                                                          \
+	hipLaunchKernelGGL((span_scatter_kernel<false, NW_>), dim3((chB + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)), \
+			   dim3(64 * NW_), ldsSB, st, nbB, nbA, segB, chunk0B, grp0B, items, rrec, cmat, gtot,      \
+			   tstart, ranges, seg_stride, bin_stride, (uint2*)nullptr, point_list, desc, abort)
+	if (nwB == 4) SGS_SCATTER_B(4);
+	else SGS_SCATTER_B(1);
+#undef SGS_SCATTER_B
 	return hipGetLastError();
 }
 
