@@ -571,7 +571,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	uint64_t* offs64 = (uint64_t*)(gchunk + gl.offs64);
 	if (presort) {
 		sgs::DepthSortSpanOut span{radii, means2D, gx, gy, gx >= gy, (uint64_t*)(gchunk + gl.counts64),
-					   (uint4*)(gchunk + gl.rrec)};
+					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.trap_flag + 64)};
 		if (own_sort)
 			e = sgs::launch_depth_sort(st, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm,
 						   rows ? &span : nullptr);
@@ -581,9 +581,11 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 							    perm, P);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
 		if (rows) {
-			e = sgs::launch_row_counts_scan(st, gchunk + gl.scan64_temp, gl.scan64_temp_bytes, P, perm, radii,
-							means2D, gx, gy, (uint64_t*)(gchunk + gl.counts64), offs64,
-							(uint4*)(gchunk + gl.rrec), own_sort);
+			// own sort: its last pass has written the span counts and their total (behind the trap flag) -- no scan
+			if (!own_sort)
+				e = sgs::launch_row_counts_scan(st, gchunk + gl.scan64_temp, gl.scan64_temp_bytes, P, perm, radii,
+								means2D, gx, gy, (uint64_t*)(gchunk + gl.counts64), offs64,
+								(uint4*)(gchunk + gl.rrec), false);
 		} else {
 			uint32_t* counts_sorted = (uint32_t*)(gchunk + gl.counts_sorted);
 			sgs::launch_gather_counts(st, P, perm, tiles_touched, counts_sorted);
@@ -604,6 +606,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// record and reported by sgs_forward_result().  The host never waits for the GPU inside the call, so one host
 	// thread can keep several streams fed.  The return value is then the CAPACITY the binning buffer was laid out
 	// for, not num_rendered -- such a forward cannot be handed to sgs_rasterize_backward.
+	// sum over the Gaussians of (major instances << 32 | instances): the scan's last element, or the own sort's total
+	const uint64_t* totals64 = (own_sort && rows) ? (const uint64_t*)(gchunk + gl.trap_flag + 64) : offs64 + (P - 1);
 	const int defer_opt = cx->option(SGS_OPT_DEFER_COUNT);
 	if (cx->count_pending && cx->count_ev && hipEventQuery(cx->count_ev) == hipSuccess) {
 		// a deferred frame nobody asked about: still learn from it
@@ -620,7 +624,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		L = defer_opt == 2 ? 4096u : cx->L_hint;   // (2: tests -- a capacity no real frame fits, exercises the abort)
 		Rrows = defer_opt == 2 ? 4096u : cx->R_hint;
 		uint32_t* rec = (uint32_t*)(gchunk + gl.count_rec);
-		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, st, offs64 + (P - 1), trap_flag, L, Rrows, rec);
+		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, st, totals64, trap_flag, L, Rrows, rec);
 		e = hipMemcpyAsync(cx->count_host, rec, 16, hipMemcpyDeviceToHost, st);
 		if (e == hipSuccess) e = hipEventRecord(cx->count_ev, st);
 		if (e != hipSuccess) return fail_hip(e, "deferred count record");
@@ -630,7 +634,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	} else {
 		int host_vals[2] = {0, 0};
 		uint64_t host_rl = 0;   // mode 0: row instances << 32 | num_rendered
-		if (rows) e = hipMemcpyAsync(&host_rl, offs64 + (P - 1), 8, hipMemcpyDeviceToHost, st);
+		if (rows) e = hipMemcpyAsync(&host_rl, totals64, 8, hipMemcpyDeviceToHost, st);
 		else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
 		if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
 		if (e == hipSuccess) e = hipStreamSynchronize(st);

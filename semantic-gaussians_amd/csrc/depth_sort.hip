@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void depth_sort_pass_kernel(
 	// ---- scatter: runs of consecutive output positions
 	const uint32_t nvalid = (uint32_t)P - (uint32_t)k * DS_TILE < (uint32_t)DS_TILE ? (uint32_t)P - (uint32_t)k * DS_TILE
 										 : (uint32_t)DS_TILE;
+	unsigned long long csum = 0;   // (SPAN) this thread's share of sum(counts64) = major instances << 32 | instances
 #pragma unroll
 	for (int i = 0; i < DS_ITEMS; i++) {
 		const uint32_t j = (uint32_t)t + 256u * i;
@@ -179,9 +180,21 @@ __global__ __launch_bounds__(256) void depth_sort_pass_kernel(
 					}
 				}
 				so.rrec[pos] = rec;
-				so.counts64[pos] = c64;
+				csum += c64;   // (the per-rank counts themselves have no reader: only their total)
 			}
 		}
+	}
+	if (SPAN) {   // only the TOTAL of counts64 is ever needed (num_rendered and the major-instance count): one atomic
+		// per workgroup instead of a scan of the array
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) {
+			const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)csum, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(csum >> 32), o);
+			csum += ((unsigned long long)hi << 32) | lo;
+		}
+		__shared__ unsigned long long s_sum[4];
+		if (lane == 0) s_sum[wave] = csum;
+		__syncthreads();
+		if (t == 0) atomicAdd(so.total, (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
 	}
 }
 

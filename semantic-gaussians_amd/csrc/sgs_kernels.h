@@ -33,6 +33,7 @@ struct DepthSortSpanOut {   // optional by-product of the last pass: what binnin
 	int gx, gy, major_x;
 	uint64_t* counts64;
 	uint4* rrec;
+	unsigned long long* total;   // += sum(counts64); zero before the sort
 };
 void depth_sort_layout(int P, DepthSortLayout* lay);
 hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, char* scratch,
