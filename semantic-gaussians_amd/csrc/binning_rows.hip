@@ -202,6 +202,72 @@ __global__ __launch_bounds__(256) void span_hist_kernel(
 	}
 }
 
+// The two kernels above in one, for bin axes that fit LDS (nb <= HG_NB_MAX): a workgroup per scan GROUP (32 chunks, 8
+// waves x 4 chunks).  The chunks' coverage rows stay in LDS, the in-group exclusive prefix over the chunks is taken
+// there, and cmat receives the prefix directly -- one launch and one round trip of the count matrix less per stage.
+constexpr int HG_NB_MAX = 256;
+template <bool FROM_RANKS>
+__global__ __launch_bounds__(512) void span_hist_group_kernel(
+	int nb, int nseg, const uint32_t* __restrict__ segstart, const uint32_t* __restrict__ chunk0,
+	const uint2* __restrict__ items, const uint4* __restrict__ rrec, uint32_t* __restrict__ cmat,
+	const uint32_t* __restrict__ grp0, uint32_t* __restrict__ gtot, uint4* __restrict__ desc,
+	const uint32_t* __restrict__ abort)
+{
+	if (abort && *abort != 0u) return;
+	extern __shared__ int s_cov[];   // [RGRP chunks][nb + 1]: difference arrays, then coverage counts
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t G = blockIdx.x;
+	if (G >= grp0[nseg]) return;
+	const int s = seg_of(grp0, nseg, G);
+	const uint32_t cbeg = chunk0[s] + (G - grp0[s]) * RGRP;
+	const uint32_t cend = cbeg + RGRP < chunk0[s + 1] ? cbeg + RGRP : chunk0[s + 1];
+	const uint32_t seg_first = segstart[s], seg_end = segstart[s + 1], c_seg0 = chunk0[s];
+	const int pitch = nb + 1;
+	for (int q = threadIdx.x; q < RGRP * pitch; q += 512) s_cov[q] = 0;
+	__syncthreads();
+	for (uint32_t c = cbeg + (uint32_t)wave; c < cend; c += 8) {   // a wave: chunks wave, wave + 8, ...
+		int* diff = s_cov + (c - cbeg) * pitch;
+		const uint32_t idx = seg_first + (c - c_seg0) * RCH + (uint32_t)lane;
+		if (lane == 0) desc[c] = make_uint4((uint32_t)s, G, idx, seg_end);
+		uint32_t lo = 0, hi = 0;
+		if (idx < seg_end) {
+			const uint32_t sp = FROM_RANKS ? rrec[idx].y : items[idx].y;
+			lo = sp & 0xffffu;
+			hi = sp >> 16;
+		}
+		if (hi > lo) {
+			atomicAdd(&diff[lo], 1);
+			atomicAdd(&diff[hi], -1);
+		}
+		__builtin_amdgcn_wave_barrier();
+		int carry = 0;   // inclusive prefix over the bins = coverage count per bin (in place)
+		for (int b0 = 0; b0 < nb; b0 += 64) {
+			const int b = b0 + lane;
+			int v = b < nb ? diff[b] : 0;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const int u = __shfl_up(v, o);
+				if (lane >= o) v += u;
+			}
+			v += carry;
+			if (b < nb) diff[b] = v;
+			carry = __shfl(v, 63);
+		}
+	}
+	__syncthreads();
+	// exclusive prefix over the group's chunks, per bin
+	for (int b = threadIdx.x; b < nb; b += 512) {
+		uint32_t run = 0;
+		for (uint32_t c = cbeg; c < cend; c++) {
+			const uint32_t v = (uint32_t)s_cov[(c - cbeg) * pitch + b];
+			cmat[(size_t)c * nb + b] = run;
+			run += v;
+		}
+		gtot[(size_t)G * nb + b] = run;
+	}
+}
+
 // in-group exclusive prefix over the chunks of a scan group (in place), group total to gtot
 __global__ __launch_bounds__(256) void span_scan_groups_kernel(int nb, int nseg, const uint32_t* __restrict__ chunk0,
 								const uint32_t* __restrict__ grp0,
@@ -466,10 +532,15 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 
 	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
 	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
-	hipLaunchKernelGGL(span_hist_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A,
-			   (const uint2*)nullptr, rrec, cmat, grp0A, desc, abort);
-	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grA * nbA + 255) / 256)), dim3(256), 0, st,
-			   nbA, 1, chunk0A, grp0A, cmat, gtot, abort);
+	if (nbA <= HG_NB_MAX) {
+		hipLaunchKernelGGL(span_hist_group_kernel<true>, dim3(grA), dim3(512), (size_t)RGRP * (nbA + 1) * 4, st, nbA, 1,
+				   segA, chunk0A, (const uint2*)nullptr, rrec, cmat, grp0A, gtot, desc, abort);
+	} else {
+		hipLaunchKernelGGL(span_hist_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A,
+				   (const uint2*)nullptr, rrec, cmat, grp0A, desc, abort);
+		hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grA * nbA + 255) / 256)), dim3(256), 0, st,
+				   nbA, 1, chunk0A, grp0A, cmat, gtot, abort);
+	}
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
 			   binlen, abort);
 	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort, 1, 1, 1);
@@ -486,10 +557,15 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	const uint32_t chB = R / RCH + (uint32_t)nbA, grB = chB / RGRP + (uint32_t)nbA;   // upper bounds
 	const int seg_stride = major_x ? 1 : gx, bin_stride = major_x ? gx : 1;          // tile = y * gx + x
 	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, nbA, R, segB, false, chunk0B, grp0B, abort);
-	hipLaunchKernelGGL(span_hist_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B, items,
-			   rrec, cmat, grp0B, desc, abort);
-	hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grB * nbB + 255) / 256)), dim3(256), 0, st,
-			   nbB, nbA, chunk0B, grp0B, cmat, gtot, abort);
+	if (nbB <= HG_NB_MAX) {
+		hipLaunchKernelGGL(span_hist_group_kernel<false>, dim3(grB), dim3(512), (size_t)RGRP * (nbB + 1) * 4, st, nbB, nbA,
+				   segB, chunk0B, items, rrec, cmat, grp0B, gtot, desc, abort);
+	} else {
+		hipLaunchKernelGGL(span_hist_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B, items,
+				   rrec, cmat, grp0B, desc, abort);
+		hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grB * nbB + 255) / 256)), dim3(256), 0, st,
+				   nbB, nbA, chunk0B, grp0B, cmat, gtot, abort);
+	}
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
 			   seg_stride, bin_stride, lens, abort);
 	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB);
