@@ -252,7 +252,9 @@ int sgs_stream_set_option(void *stream, int option, int value);
 #define SGS_STAT_DEFERRED_RETRIES 5    /* deferred-count frames that did not fit (sgs_forward_result: SGS_ERETRY) */
 #define SGS_STAT_COUNT 6
 int sgs_stream_get_stat(void *stream, int stat, uint64_t *out);
-/* The counts of the last forward on `stream` (see SGS_OPT_DEFER_COUNT).  wait != 0: blocks until they have arrived
+/* The counts of the last forward on `stream` (see SGS_OPT_DEFER_COUNT): the deferred form of the reference's blocking
+ * `cudaMemcpy(&num_rendered, geomState.point_offsets + P - 1, sizeof(int), cudaMemcpyDeviceToHost)`
+ * (CR/cuda_rasterizer/rasterizer_impl.cu:283).  wait != 0: blocks until they have arrived
  * (that is after the frame's scan, long before its blend); wait == 0: SGS_ENOTREADY if they have not.  After an
  * ordinary forward: 0 and its num_rendered, immediately. */
 int sgs_forward_result(void *stream, int wait, int *num_rendered);

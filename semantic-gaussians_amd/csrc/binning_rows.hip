@@ -2,7 +2,7 @@
 //
 // The reference turns (Gaussian, tile) instances into per-tile depth-ordered lists with a
 // 45-bit radix sort of L = 16.5 M pairs (cfg3).  With the Gaussians already in depth order
-// (binning.hip: depth presort) a tile's list is just "the Gaussians whose rect covers the tile,
+// (depth_sort.hip: the depth presort) a tile's list is just "the Gaussians whose rect covers the tile,
 // in rank order", and a rect is a span of columns times a span of rows.  A stable partition of
 // items that each cover a SPAN of bins needs no sort at all: for 64 consecutive items (one wave)
 // and one bin, the ballot of "covers the bin" is both the chunk's count for that bin and, through
