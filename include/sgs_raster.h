@@ -229,7 +229,8 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * (1.25 x what its previous frame needed; the first frame of a stream still blocks), the true counts stay on the
  * device, and a frame that does not fit aborts itself on the device.  sgs_rasterize_forward then returns at once
  * with the CAPACITY the binning buffer was laid out for; the caller MUST call sgs_forward_result() before it uses
- * the outputs: 0 = valid (and the true num_rendered), SGS_ERETRY = render that frame again (the guess has grown).
+ * the outputs AND before the next forward on the same stream (the context keeps one pending record per stream):
+ * 0 = valid (and the true num_rendered), SGS_ERETRY = render that frame again (the guess has grown).
  * One host thread can so keep several streams full: 1M Gaussians x 512 channels, 4 views in flight:
  * see DESIGN.md 7.  Binning mode 0 only; ignored under debug; not for frames that will be differentiated (the
  * backward locates the lists from num_rendered).  2: as 1 with a capacity no frame fits (tests). */

@@ -150,7 +150,7 @@ def _check_bg(bg, Cn):
 class DeferredForward:
     """A forward whose instance counts stayed on the device (SGS_OPT_DEFER_COUNT, include/sgs_raster.h): the call
     that made it did not wait for the GPU.  result() -- call it on the host thread that made the forward, before the
-    outputs are used -- waits for the counts (they arrive after the frame's scan, long before its blend) and returns
+    outputs are used and before the next forward on the same stream -- waits for the counts (they arrive after the frame's scan, long before its blend) and returns
     the same tuple rasterize_forward returns, with the true num_rendered; a frame that did not fit this stream's
     capacity guess is rendered again the ordinary way (the guess has grown by then).  Inference only: the
     binning buffer is laid out for `layout_count` (>= num_rendered) entries, which rasterize_backward cannot know."""
