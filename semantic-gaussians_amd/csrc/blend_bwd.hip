@@ -151,27 +151,28 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 			float* acc_row = COMBINE ? &s_acc[(wave * 64 + (k - kb)) * NV] : nullptr;
 			const int comp = wave_sum8_component(lane);
 			const bool head = (lane & 7) == 0;   // the lanes wave_sum8 leaves its eight totals in
-			float pc[8];   // (RGB chunk) this lane's wgt * g[c], 0 beyond cn
+			float pc[8];   // this lane's wgt * g[c] of the current eight channels, 0 beyond cn
 #pragma unroll
 			for (int j = 0; j < 8; j++) pc[j] = 0.f;
-			float mine = 0.f;   // (32-channel chunk) lane c: the wave's sum for channel c
 #pragma unroll
 			for (int c = 0; c < CC; c++) {
 				if (c < cn) {
 					const float cv = col[c];
 					// contribution to dL/dalpha uses the colour accumulated BEHIND this entry
 					S += (cv - rec[c]) * g[c];
-					if (COMBINE) {
-						pc[c & 7] = wgt * g[c];
-					} else {
-						const float gc = wave_sum(wgt * g[c]);
-						if (lane == c) mine = gc;
-					}
+					pc[c & 7] = wgt * g[c];
 					// fold this entry into the running "behind" colour for the next one
 					if (valid) rec[c] = alpha * cv + oma * rec[c];
 				}
+				if (!COMBINE && (c & 7) == 7) {   // 32-channel chunk: eight channel sums per transposed reduction
+					if (c - 7 < cn) {
+						const float u8 = wave_sum8(pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7]);
+						if (head && c - 7 + comp < cn) atomicAdd(&dcol[c - 7 + comp], u8);
+					}
+#pragma unroll
+					for (int j = 0; j < 8; j++) pc[j] = 0.f;
+				}
 			}
-			if (!COMBINE && lane < cn) atomicAdd(&dcol[lane], mine);   // one coalesced row of atomics per wave
 			float dL_dalpha = S * T;
 			dL_dalpha += (-T_final / oma) * bg_dot;
 			if (!valid) dL_dalpha = 0.f;
