@@ -334,16 +334,24 @@ struct StageTimer {
 // Deferred-count forward: the instance counts stay on the device.  rec = {num_rendered, major instances, trap flag,
 // abort}; abort != 0 (a count exceeds the capacity the buffers were sized for, or the prefiltered trap fired) makes
 // every later kernel of the frame exit.
+// `host` is the stream's pinned record (device-accessible): the kernel writes it directly -- a copy would be one
+// more launch on the frame's critical path.
 __global__ void count_check_kernel(const uint64_t* __restrict__ offs_last, const int* __restrict__ trap_flag,
-				   uint32_t L_cap, uint32_t R_cap, uint32_t* __restrict__ rec)
+				   uint32_t L_cap, uint32_t R_cap, uint32_t* __restrict__ rec, volatile uint32_t* host)
 {
 	const uint64_t rl = *offs_last;
 	const uint64_t L = rl & 0xffffffffull, R = rl >> 32;
 	const uint32_t trap = (uint32_t)*trap_flag;
+	const uint32_t abort = (L > (uint64_t)L_cap || R > (uint64_t)R_cap || trap != 0u) ? 1u : 0u;
 	rec[0] = (uint32_t)L;
 	rec[1] = (uint32_t)R;
 	rec[2] = trap;
-	rec[3] = (L > (uint64_t)L_cap || R > (uint64_t)R_cap || trap != 0u) ? 1u : 0u;
+	rec[3] = abort;
+	host[0] = (uint32_t)L;
+	host[1] = (uint32_t)R;
+	host[2] = trap;
+	host[3] = abort;
+	__threadfence_system();
 }
 
 // capacity guess for a count: 1.25 x what the last frame needed, 64k granularity (stable buffer sizes)
@@ -624,8 +632,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		L = defer_opt == 2 ? 4096u : cx->L_hint;   // (2: tests -- a capacity no real frame fits, exercises the abort)
 		Rrows = defer_opt == 2 ? 4096u : cx->R_hint;
 		uint32_t* rec = (uint32_t*)(gchunk + gl.count_rec);
-		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, st, totals64, trap_flag, L, Rrows, rec);
-		e = hipMemcpyAsync(cx->count_host, rec, 16, hipMemcpyDeviceToHost, st);
+		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, st, totals64, trap_flag, L, Rrows, rec, cx->count_host);
+		e = hipGetLastError();
 		if (e == hipSuccess) e = hipEventRecord(cx->count_ev, st);
 		if (e != hipSuccess) return fail_hip(e, "deferred count record");
 		cx->count_pending = true;
@@ -634,10 +642,18 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	} else {
 		int host_vals[2] = {0, 0};
 		uint64_t host_rl = 0;   // mode 0: row instances << 32 | num_rendered
-		if (rows) e = hipMemcpyAsync(&host_rl, totals64, 8, hipMemcpyDeviceToHost, st);
-		else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (own_sort && rows) {   // the trap flag and the totals share one 128-byte block: ONE copy (each is a kernel)
+			uint64_t blk[9];
+			e = hipMemcpyAsync(blk, trap_flag, sizeof(blk), hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			host_vals[1] = (int)(uint32_t)blk[0];
+			host_rl = blk[8];
+		} else {
+			if (rows) e = hipMemcpyAsync(&host_rl, totals64, 8, hipMemcpyDeviceToHost, st);
+			else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);
+		}
 		if (e != hipSuccess) return fail_hip(e, "num_rendered read-back");
 		if (host_vals[1] != 0)
 			return fail(SGS_ETRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
