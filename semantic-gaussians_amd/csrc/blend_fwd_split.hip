@@ -423,8 +423,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // the same work to within one small segment and its last workgroups are its shortest.
 constexpr int PLAN_MAX = 4096;   // segments (beyond: row-major order)
 __global__ __launch_bounds__(1024) void sweep_plan_kernel(const uint32_t* __restrict__ nact, uint32_t* __restrict__ order,
-							   const uint32_t* __restrict__ counter, int gx, int gy, int seg, int nseg)
+							   const uint32_t* __restrict__ counter, int gx, int gy, int seg, int nseg,
+							   volatile uint32_t* usage_host)
 {
+	if (usage_host && threadIdx.x == 0) {   // the work-list usage feedback, straight into the stream's pinned words
+		usage_host[0] = counter[0];         // (a device-to-host copy at the end of the frame would be one more launch)
+		usage_host[1] = counter[1];
+		__threadfence_system();
+	}
 	if (counter[1] != 0u) return;
 	__shared__ uint32_t key[PLAN_MAX];
 	const int n = gy * nseg;
@@ -1045,8 +1051,9 @@ void set_sweep_trace(void* device_words) { g_sweep_trace = (unsigned long long*)
 
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
-				      int split_mode)
+				      int split_mode, bool* usage_reported)
 {
+	if (usage_reported) *usage_reported = false;
 	const int ntiles = a.gx * a.gy;
 	uint32_t* counter = (uint32_t*)(arena + lay.counter);
 	uint32_t* nbatches = (uint32_t*)(arena + lay.nbatches);
@@ -1085,7 +1092,9 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		if (nsegs > PLAN_MAX && plan == 3) plan = 2;
 		uint32_t* order = (uint32_t*)(arena + lay.order);
 		if (plan == 3)
-			hipLaunchKernelGGL(sweep_plan_kernel, dim3(1), dim3(1024), 0, st, nbatches, order, counter, a.gx, a.gy, seg, nseg);
+			hipLaunchKernelGGL(sweep_plan_kernel, dim3(1), dim3(1024), 0, st, nbatches, order, counter, a.gx, a.gy, seg, nseg,
+					   a.usage_host);
+		if (usage_reported) *usage_reported = plan == 3 && a.usage_host != nullptr;
 		const int dealt = plan >= 2;
 		const int items = dealt ? nsegs : nsegs * nc * 2;   // x 2 row parities
 		const int pxcd = dealt ? 2 * ((nsegs + 15) / 16) * nc * 2 : (items + 7) / 8;   // workgroups per XCD

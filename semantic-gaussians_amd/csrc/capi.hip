@@ -780,6 +780,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.out_depth = out_depth;
 	a.pitch = cx->option(SGS_OPT_OUT_PITCH) > 0 ? cx->option(SGS_OPT_OUT_PITCH) : width;
 	a.abort = abort_word;
+	a.usage_host = nullptr;
 	if (a.pitch < width) return fail(SGS_EINVAL, "output pitch smaller than the image width");
 	if (want_fused && (variant & 0xff) >= 34 && sgs::blend_forward_fused_pc_eligible(a)) {
 		tm.mark();
@@ -790,7 +791,10 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	} else if (use_split) {
 		char* arena = bchunk + bl.arena;
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
-		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 15 ? 9 : 8));
+		const bool can_report = cx->ensure(cx->usage_host, cx->usage_ev);
+		a.usage_host = can_report ? cx->usage_host : nullptr;
+		bool usage_reported = false;
+		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 15 ? 9 : 8), &usage_reported);
 		if (e != hipSuccess) return fail_hip(e, "blend forward (split)");
 		const uint32_t* counter = (const uint32_t*)(arena + bl.arena_lay.counter);
 		const int c_split = (num_channels / 128) * 128;
@@ -798,8 +802,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 			e = sgs::launch_blend_forward(st, a, 0, counter, 0);
 		if (e == hipSuccess && c_split < num_channels)
 			e = sgs::launch_blend_forward(st, a, 0, nullptr, c_split);
-		if (e == hipSuccess && cx->ensure(cx->usage_host, cx->usage_ev)) {
-			e = hipMemcpyAsync(cx->usage_host, counter, 8, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess && can_report) {
+			if (!usage_reported) e = hipMemcpyAsync(cx->usage_host, counter, 8, hipMemcpyDeviceToHost, st);
 			if (e == hipSuccess) e = hipEventRecord(cx->usage_ev, st);
 			cx->usage_pending = e == hipSuccess;
 		}

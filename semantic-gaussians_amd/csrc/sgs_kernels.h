@@ -100,6 +100,7 @@ struct BlendFwdArgs {
 	float* out_depth;            // (H*W) or null
 	int pitch;                   // output row pitch in pixels
 	const uint32_t* abort;       // optional device word: != 0 -> every blend kernel exits (deferred-count forward, capi.hip)
+	uint32_t* usage_host;        // optional pinned {work-list slots requested, overflow flag}: written by the sweep plan kernel
 };
 // gate: optional device word; when non-null the 128-channel-aligned kernels exit unless
 // *gate != 0 (used as the arena-overflow fallback of the split path).
@@ -114,9 +115,10 @@ struct SplitArena {   // byte offsets inside the arena chunk
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay);
 // `mark` is called (with `mark_user`) between the weights pre-pass and the accumulate kernel, on `st`
 // (stage timing).
+// *usage_reported: the plan kernel wrote a.usage_host (no copy of the counter needed)
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
-				      int split_mode);
+				      int split_mode, bool* usage_reported = nullptr);
 
 // debug: 4 x uint64 per sweep workgroup (begin, end on the 100 MHz steady counter, HW_ID | XCC_ID << 32, batches | tiles << 32)
 void set_sweep_trace(void* device_words);
