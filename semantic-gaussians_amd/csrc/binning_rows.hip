@@ -341,8 +341,15 @@ __global__ __launch_bounds__(256) void span_scan_lists_kernel(int nb, int nseg, 
 template <bool RANGES>
 __global__ __launch_bounds__(1024) void list_scan_kernel(int n, const uint32_t* __restrict__ len,
 							  uint2* __restrict__ ranges, uint32_t* __restrict__ starts,
-							  const uint32_t* __restrict__ abort, int gx, int major_x, int nb)
+							  const uint32_t* __restrict__ abort, int gx, int major_x, int nb,
+							  uint32_t* __restrict__ arena_counter, uint32_t first_free)
 {
+	// (RANGES, the last single-workgroup kernel in front of the blend) also resets the split blend's work-list
+	// counter -- what blend_fwd_split.hip's arena_reset_kernel does -- so that launch disappears from the frame
+	if (arena_counter && threadIdx.x == 0) {
+		arena_counter[0] = first_free;
+		arena_counter[1] = (abort && *abort != 0u) ? 2u : 0u;
+	}
 	if (abort && *abort != 0u) return;
 	__shared__ uint32_t s_part[1024];
 	const int per = (n + 1023) / 1024;
@@ -502,7 +509,8 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 }
 
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
-			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort)
+			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort,
+			      uint32_t* arena_counter, uint32_t arena_first_free)
 {
 	const int ntiles = gx * gy;
 	if (R == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st);
@@ -543,7 +551,8 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	}
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
 			   binlen, abort);
-	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort, 1, 1, 1);
+	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort, 1, 1, 1,
+			   (uint32_t*)nullptr, 0u);
 #define SGS_SCATTER_A(NW_)                                                                                          \
 	hipLaunchKernelGGL((span_scatter_kernel<true, NW_>), dim3((chA + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)),  \
 			   dim3(64 * NW_), ldsSA, st, nbA, 1, segA, chunk0A, grp0A, (const uint2*)nullptr, rrec,    \
@@ -568,7 +577,8 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	}
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
 			   seg_stride, bin_stride, lens, abort);
-	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB);
+	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB,
+			   arena_counter, arena_first_free);
 #define SGS_SCATTER_B(NW_)                                                                                          \
 	hipLaunchKernelGGL((span_scatter_kernel<false, NW_>), dim3((chB + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)), \
 			   dim3(64 * NW_), ldsSB, st, nbB, nbA, segB, chunk0B, grp0B, items, rrec, cmat, gtot,      \

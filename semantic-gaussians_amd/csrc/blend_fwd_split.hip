@@ -1060,7 +1060,8 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	uint32_t* table = (uint32_t*)(arena + lay.table);
 	uint32_t* act_id = (uint32_t*)(arena + lay.act_id);
 	float* wgt = (float*)(arena + lay.wgt);
-	hipLaunchKernelGGL(arena_reset_kernel, dim3(1), dim3(1), 0, st, counter, a.abort, (uint32_t)ntiles * (uint32_t)ACH);
+	if (!a.counter_reset_done)
+		hipLaunchKernelGGL(arena_reset_kernel, dim3(1), dim3(1), 0, st, counter, a.abort, (uint32_t)ntiles * (uint32_t)ACH);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 #define SGS_LAUNCH_W(M_, ST_, T0_, NT_)                                                             \

@@ -713,6 +713,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	uint32_t* point_list = (uint32_t*)(bchunk + bl.pub.point_list);
 
 	uint2* ranges = (uint2*)(ichunk + il.ranges);
+	bool counter_reset_done = false;
 	if (rows) {
 		// mode 0: two span partitions, no instance sort (binning_rows.hip).  The 8-B-per-instance
 		// keys_unsorted area holds the major instances (8 B each, R <= L).
@@ -720,7 +721,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		e = sgs::launch_row_binning(st, P, Rrows, gx, gy, (const uint4*)(gchunk + gl.rrec), (uint2*)keys_u,
 					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
 					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list,
-					    abort_word);
+					    abort_word, use_split ? (uint32_t*)(bchunk + bl.arena + bl.arena_lay.counter) : nullptr,
+					    (uint32_t)ntiles * 128u);
+		counter_reset_done = use_split && Rrows != 0;   // (launch_row_binning with R == 0 is just a memset)
 		if (e != hipSuccess) return fail_hip(e, "row binning");
 		SGS_CHECK_STAGE("row binning");
 		tm.mark();
@@ -781,6 +784,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.pitch = cx->option(SGS_OPT_OUT_PITCH) > 0 ? cx->option(SGS_OPT_OUT_PITCH) : width;
 	a.abort = abort_word;
 	a.usage_host = nullptr;
+	a.counter_reset_done = counter_reset_done;
 	if (a.pitch < width) return fail(SGS_EINVAL, "output pitch smaller than the image width");
 	if (want_fused && (variant & 0xff) >= 34 && sgs::blend_forward_fused_pc_eligible(a)) {
 		tm.mark();

@@ -74,7 +74,8 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 // R may be an upper bound of the major-instance count (grids and scratch are sized from it, the kernels read the
 // actual counts from device tables); abort: optional device word, != 0 -> every kernel exits
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
-			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort = nullptr);
+			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort = nullptr,
+			      uint32_t* arena_counter = nullptr, uint32_t arena_first_free = 0);   // optional: also reset the split blend's counter
 void launch_reconstruct_keys_ranges(hipStream_t st, int ntiles, const uint2* ranges, const uint32_t* point_list,
 				    const float* depths, uint64_t* keys_sorted);
 size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit);
@@ -101,6 +102,7 @@ struct BlendFwdArgs {
 	int pitch;                   // output row pitch in pixels
 	const uint32_t* abort;       // optional device word: != 0 -> every blend kernel exits (deferred-count forward, capi.hip)
 	uint32_t* usage_host;        // optional pinned {work-list slots requested, overflow flag}: written by the sweep plan kernel
+	bool counter_reset_done;     // the work-list counter was already reset (launch_row_binning): no arena_reset_kernel
 };
 // gate: optional device word; when non-null the 128-channel-aligned kernels exit unless
 // *gate != 0 (used as the arena-overflow fallback of the split path).
