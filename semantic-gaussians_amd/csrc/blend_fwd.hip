@@ -189,7 +189,13 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 {
 	if (gate && gate[1] != 1u) return;   // fallback instance: runs only if the split path's work list overflowed (1; 2 = aborted frame)
 	if (abort && *abort != 0u) return;
-	const int b = blockIdx.x;
+	__shared__ StagedEntry s_e[BATCH];
+	__shared__ float4 s_w[BATCH * 64];          // [entry][lane] -> (strip0..3)
+	__shared__ unsigned s_active[BATCH];        // per entry: any pixel of the tile takes it
+	__shared__ int s_alive[4];
+	// The gated fallback instance is launched with a SMALL grid whose workgroups stride over the items: when the gate
+	// is closed (every frame but an overflowing one) only that many workgroups have to start and exit.
+	auto one_item = [&](const int b) __attribute__((always_inline)) {
 	const int v = (b & 7) * per_xcd + (b >> 3);
 	if (v >= total) return;
 	const int tile = v / nchunks;
@@ -208,11 +214,6 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 
 	const uint2 range = ranges[tile];
 	const int n_total = (int)(range.y - range.x);
-
-	__shared__ StagedEntry s_e[BATCH];
-	__shared__ float4 s_w[BATCH * 64];          // [entry][lane] -> (strip0..3)
-	__shared__ unsigned s_active[BATCH];        // per entry: any pixel of the tile takes it
-	__shared__ int s_alive[4];
 
 	f2 acc[4][CW / 2];   // packed pairs: v_pk_fma_f32 with an SGPR-pair feature operand
 #pragma unroll
@@ -294,6 +295,11 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 				out[(size_t)(c0 + c) * HW + pix] = __builtin_fmaf(Tp, bg[c0 + c], acc[p][c >> 1][c & 1]);
 		}
 	}
+	};
+	for (int b = blockIdx.x; b < 8 * per_xcd; b += gridDim.x) {
+		one_item(b);
+		__syncthreads();   // the next item reuses the shared arrays
+	}
 }
 
 // -------------------------------------------------------------------------------------
@@ -314,7 +320,8 @@ static void launch_px4(hipStream_t st, const BlendFwdArgs& a, int nchunks, const
 {
 	const int total = a.gx * a.gy * nchunks;
 	const int per_xcd = (total + 7) / 8;
-	hipLaunchKernelGGL((blend_fwd_px4_kernel<CW, BATCH>), dim3(per_xcd * 8), dim3(256), 0, st,
+	const int grid = gate && per_xcd * 8 > 2048 ? 2048 : per_xcd * 8;   // (gated fallback: see the kernel)
+	hipLaunchKernelGGL((blend_fwd_px4_kernel<CW, BATCH>), dim3(grid), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.bg,
 			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate, a.pitch, a.abort);
 }
