@@ -153,6 +153,23 @@ def blend_forward(pre, binn, features, bg, W, H, want_depth=False, tile_lo=None,
     return dict(out=out, final_T=final_T, n_contrib=n_contrib, depth=depth)
 
 
+def blend_forward_f64(pre, binn, features, bg, W, H, tile_lo=None, tile_hi=None):
+    """The composite with the channel sums in float64 (weights and every decision stay the contract's fp32 values):
+    the exact value the fp32 multiply-add chain approximates.  (C,H,W) float64; tiles outside [lo, hi) stay 0."""
+    features = _c32(features)
+    Cn = features.shape[1]
+    bg = _c32(bg).reshape(-1)
+    assert bg.shape[0] >= Cn, "bg shorter than num_channels"
+    out = np.zeros((Cn, H, W), np.float64)
+    gx, gy = tile_grid(W, H)
+    lo = 0 if tile_lo is None else tile_lo
+    hi = gx * gy if tile_hi is None else tile_hi
+    lib().orc_blend_forward_tiles_f64(
+        C.c_int(W), C.c_int(H), C.c_int(Cn), _p(binn["ranges"]), _p(binn["point_list"]),
+        _p(pre["means2D"]), _p(features), _p(pre["conic_opacity"]), _p(bg), _p(out), C.c_int(lo), C.c_int(hi))
+    return out
+
+
 def forward(means3D, opacities, view, proj, campos, W, H, tanfovx, tanfovy, bg, num_channels,
             scales=None, rotations=None, scale_modifier=1.0, cov3D_precomp=None,
             colors_precomp=None, shs=None, sh_degree=0, prefiltered=False, want_depth=False):

@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		const unsigned long long i1 = i0 + per < clear_n4 ? i0 + per : clear_n4;
 		for (unsigned long long i = i0 + threadIdx.x; i < i1; i += 256) clear_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
-	static_assert(MODE == 2 || MODE == 3, "weights format: 2 = split bf16 (default), 3 = fp32 rows (exact)");
-	constexpr bool BF = MODE == 2;   // weights as split bf16, k-major groups of 8 (else fp32 rows of 256)
+	static_assert(MODE == 2 || MODE == 3 || MODE == 4, "weights format: 2 = two bf16 terms, 3 = fp32 rows, 4 = three bf16 terms");
+	constexpr bool BF = MODE == 2 || MODE == 4;   // weights as bf16 terms, k-major groups of 8 (else fp32 rows of 256)
+	constexpr int GROUP_BYTES = MODE == 4 ? 12288 : 8192;   // 8 entries x 256 px x (2 | 3) terms x 2 B
 	constexpr bool SWEEP = true;     // parity-major pixel order, closing T * bg pseudo entry, zero padding to 16
 	const int tile = (b & 7) * per_xcd + (b >> 3);
 	if (tile >= ntiles) return;
@@ -121,6 +122,29 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		const uint32_t g0 = gi * 8u, ci = g0 / ACH;
 		const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
 		const uint32_t slot = cstart + (g0 % ACH);
+		if constexpr (MODE == 4) {
+			// three terms, w = t1 + t2 + t3 EXACTLY (8 significant bits each; the fp32 difference of a value and its own
+			// rounding is exact): what the sweep's six products need to be fp32-equivalent (blend_sweep2.hip)
+			uint32_t t1[4], t2[4], t3[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const float x0 = s_pend[(2 * k) * 256 + threadIdx.x], x1 = s_pend[(2 * k + 1) * 256 + threadIdx.x];
+				typedef float f32x2_ __attribute__((ext_vector_type(2)));
+				typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+				const f32x2_ v0 = {x0, x1};
+				t1[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2_));
+				const float r0 = x0 - __uint_as_float(t1[k] << 16), r1 = x1 - __uint_as_float(t1[k] & 0xffff0000u);
+				const f32x2_ v1 = {r0, r1};
+				t2[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2_));
+				const f32x2_ v2 = {r0 - __uint_as_float(t2[k] << 16), r1 - __uint_as_float(t2[k] & 0xffff0000u)};
+				t3[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_));
+			}
+			uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * GROUP_BYTES);
+			dst[pxp_own] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+			dst[256 + pxp_own] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+			dst[512 + pxp_own] = make_uint4(t3[0], t3[1], t3[2], t3[3]);
+			return;
+		}
 		bf16x8 hi, lo;
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
@@ -1040,7 +1064,7 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	a.act_id = take((size_t)capacity * 4);
 	a.act_idx = take((size_t)capacity * 4);
 	a.order = take((size_t)PLAN_MAX * 4);
-	a.wgt = take((size_t)capacity * 1024);
+	a.wgt = take((size_t)capacity * 1536);   // 1 KB per slot (fp32 rows / two bf16 terms), 1.5 KB with three bf16 terms
 	a.total = (off + 127) & ~(size_t)127;
 	if (lay) *lay = a;
 	return a.total;
@@ -1081,8 +1105,15 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			while (seg > 8 && (long long)a.gy * ((a.gx + seg - 1) / seg) * nc * 2 < 1536) seg /= 2;
 		const int nseg = (a.gx + seg - 1) / seg;
 		seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
-		const bool exact = (split_mode & 15) == 9;
-		if (exact) SGS_LAUNCH_W(3, st, 0, ntiles);
+		// accumulate kernel (low nibble of the variant): 8 = round 2's split-bf16 (three products) sweep, 9 = the same sweep on
+		// fp32-input MFMA; blend_sweep2.hip: 10 = f32-equivalent (six bf16 products), 11 = exact fp32 MFMA, 12 = six
+		// products on the double-rate MFMA (experiment).  All but 8 take fp32 weight rows.
+		const int arith_nib = split_mode & 15;
+		const bool sweep2 = arith_nib >= 10 && arith_nib <= 14;
+		const bool presplit3 = arith_nib == 14;   // weights handed over as three bf16 terms
+		const bool exact = arith_nib == 9;
+		if (presplit3) SGS_LAUNCH_W(4, st, 0, ntiles);
+		else if (exact || sweep2) SGS_LAUNCH_W(3, st, 0, ntiles);
 		else SGS_LAUNCH_W(2, st, 0, ntiles);
 		if (mark) mark(mark_user);
 		// workgroup order (bits [13:12] of the variant): 0 / 3 = segments sorted by work and dealt to the XCDs
@@ -1104,7 +1135,12 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	hipLaunchKernelGGL((blend_accum_sweep_kernel<D_, E_>), dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
-		if (exact) SGS_LAUNCH_SWEEP(0, true);
+		if (sweep2) {
+			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : 1))), (split_mode >> 8) & 15, a, table,
+								  nbatches, act_id, (const char*)wgt, counter, nc, seg, nseg, pxcd, items,
+								  g_sweep_trace, order_arg, dealt);
+			if (e2 != hipSuccess) return e2;
+		} else if (exact) SGS_LAUNCH_SWEEP(0, true);
 		else
 			switch ((split_mode >> 8) & 15) {
 			case 1: SGS_LAUNCH_SWEEP(1, false); break;

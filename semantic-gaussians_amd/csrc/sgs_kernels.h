@@ -122,6 +122,13 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
 				      int split_mode, bool* usage_reported = nullptr);
 
+// ---- blend_sweep2.hip: the accumulate sweep in fp32-class arithmetic (arith: 0 = exact fp32 MFMA, 1 = six bf16 products,
+// 2 = the same on the x16 MFMA), LDS-polled DMA arrival, stores spread over the next tile; takes fp32 weight rows
+hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFwdArgs& a, const uint32_t* table,
+			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
+			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
+			       const uint32_t* order, int dealt);
+
 // debug: 4 x uint64 per sweep workgroup (begin, end on the 100 MHz steady counter, HW_ID | XCC_ID << 32, batches | tiles << 32)
 void set_sweep_trace(void* device_words);
 

@@ -1,0 +1,120 @@
+"""Round 3: the accumulate sweep of blend_sweep2.hip (LDS-polled DMA arrival, stores spread over the next tile) against
+the oracle, through the C-ABI.  Variants (low nibble of the blend variant; 0x60 = 48-tile segments, the default):
+  0x6B  exact fp32 MFMA   -- bit-identical feature map;
+  0x6A  f32-equivalent    -- six bf16 products of the exact three-term splits; |error| <= X6_TOL * sum |f| w;
+  0x6C  (experiment) the same on the double-rate MFMA.
+Every integer output stays bit-exact (it comes from the shared front end and weights pre-pass)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import small_scene, oracle_forward
+from test_parity_gpu import _hip_forward
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+V_X6, V_EXACT, V_X6W, V_X6S, V_X6P = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E
+# Against the fp32 ORACLE the difference is dominated by the oracle's own roundings: its multiply-add chain rounds once
+# per contribution (<= 2^-24 |partial sum| each, K ~ 50-300 contributions), the six-product path drops
+# F2 W3 + F3 W2 + F3 W3 <= 2^-23 |f w| per term and rounds once per MFMA.  4e-6 of the ABSOLUTE composite
+# (sum |f| w + T |bg|) covers both and is 25x inside the north star's 1e-4.  The sharper statement is
+# check_vs_f64 below: against the exact (float64) composite the path is as accurate as the oracle's fp32 chain.
+X6_TOL = 4e-6
+
+
+def check(orc, scene, cam, variant, seg=None, **kw):
+    v = variant if seg is None else (variant & 15) | (seg << 4)
+    fw = oracle_forward(orc, scene, cam, **kw)
+    n, color, radii, geom, binn, img, depth = _hip_forward(scene, cam, variant=v, **kw)
+    from sgs_hip import raster
+    W, H = cam.image_width, cam.image_height
+    assert n == fw["num_rendered"]
+    assert np.array_equal(radii.cpu().numpy(), fw["radii"])
+    im = {k: t.cpu().numpy() for k, t in raster.image_views(img, W, H).items()}
+    assert np.array_equal(im["n_contrib"].view(np.uint32), fw["n_contrib"])
+    assert np.array_equal(im["final_T"].view(np.uint32), fw["final_T"].view(np.uint32))
+    out = color.cpu().numpy()
+    if (variant & 15) == 11:
+        assert np.array_equal(out.view(np.uint32), fw["out"].view(np.uint32))
+        return fw, 0.0
+    sa = scene._replace(features=scene.features.abs(), bg=scene.bg.abs())
+    fa = oracle_forward(orc, sa, cam, **kw)["out"]
+    err = np.abs(out - fw["out"])
+    assert (err <= X6_TOL * fa + 1e-30).all(), float((err / (fa + 1e-30)).max())
+    # "f32-equivalent": measured against the EXACT composite (float64 sums of the same fp32 weights), the six-product
+    # path is no less accurate than the reference's own fp32 multiply-add chain
+    bgv = scene.bg.numpy() if kw.get("bg") is None else np.asarray(kw["bg"], np.float32)
+    truth = orc.blend_forward_f64(fw, fw, fw["features"], bgv, W, H)
+    e_hip = np.abs(out.astype(np.float64) - truth) / (fa + 1e-30)
+    e_orc = np.abs(fw["out"].astype(np.float64) - truth) / (fa + 1e-30)
+    assert e_hip.max() <= 1.5 * e_orc.max() + 2.0 ** -22, (e_hip.max(), e_orc.max())
+    assert np.sqrt((e_hip ** 2).mean()) <= 1.25 * np.sqrt((e_orc ** 2).mean()) + 2.0 ** -26, (np.sqrt((e_hip ** 2).mean()), np.sqrt((e_orc ** 2).mean()))
+    return fw, float(e_hip.max())
+
+
+SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64), (128, 336, 48)]
+
+
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6W, V_X6S, V_X6P])
+@pytest.mark.parametrize("C,W,H", SHAPES)
+def test_sweep2_shapes(orc, variant, C, W, H):
+    """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
+    (guarded edge pairs), a single tile, an odd tile count (trailing unpaired left half)."""
+    scene, cam = small_scene(P=3000, C=C, W=W, H=H, fx=170.0, seed=C + W)
+    check(orc, scene, cam, variant)
+    check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
+
+
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P])
+def test_sweep2_background_and_short_lists(orc, variant):
+    """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
+    scene, cam = small_scene(P=60, C=128, W=208, H=96, fx=170.0, seed=5)
+    g = torch.Generator().manual_seed(3)
+    scene = scene._replace(bg=torch.randn(128, generator=g), scales=scene.scales * 0.3)
+    fw, _ = check(orc, scene, cam, variant)
+    r = fw["ranges"].reshape(-1, 2)
+    assert (r[:, 0] == r[:, 1]).any()   # empty tiles exist
+
+
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P])
+def test_sweep2_long_lists(orc, variant):
+    """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
+    deferred stores ride along tiles of very different lengths."""
+    scene, cam = small_scene(P=40000, C=128, W=784, H=32, fx=600.0, seed=77)
+    scene = scene._replace(scales=scene.scales * 3.0, opacities=scene.opacities * 0.05)
+    check(orc, scene, cam, variant)        # (first frame may take the overflow fallback)
+    fw, _ = check(orc, scene, cam, variant)
+    assert fw["n_contrib"].max() > 900
+    check(orc, scene, cam, variant, seg=6)   # one 49-tile segment: ~2900 batches
+
+
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P])
+def test_sweep2_padded_pitch(orc, variant):
+    """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
+    from sgs_hip import raster
+    scene, cam = small_scene(P=2500, C=128, W=203, H=90, fx=170.0, seed=9)
+    raster.OUTPUT_PITCH_ALIGN = 32
+    try:
+        check(orc, scene, cam, variant)
+    finally:
+        raster.OUTPUT_PITCH_ALIGN = 0
+
+
+def test_sweep2_deterministic_under_load(orc):
+    """The same frame 300 times with two other views in flight on other streams: every feature map bit-identical
+    (a stale ring stage -- a bundle consumed before it landed -- would show up as a differing map)."""
+    from sgs_hip import raster
+    scene, cam = small_scene(P=6000, C=256, W=400, H=160, fx=300.0, seed=21)
+    V = V_X6P
+    ref = _hip_forward(scene, cam, variant=V)[1].clone()
+    side = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    bad = 0
+    for it in range(300):
+        for st in side:
+            with torch.cuda.stream(st):
+                _hip_forward(scene, cam, variant=V)
+        out = _hip_forward(scene, cam, variant=V)[1]
+        bad += int(not torch.equal(out, ref))
+    torch.cuda.synchronize()
+    assert bad == 0

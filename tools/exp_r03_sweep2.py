@@ -1,0 +1,73 @@
+"""Round-3 experiment: the sweep2 accumulate kernels at cfg3 -- stage times per variant, error statistics of the
+f32-equivalent arithmetic against the exact path, determinism."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "semantic-gaussians_amd"))
+import torch
+from sgs_hip import raster
+from sgs_hip.synthetic import CONFIGS, make_config
+DEV = "cuda:0"; E = torch.Tensor([])
+P, C, W, H, fx = CONFIGS["cfg3"]
+scene, cam = make_config("cfg3", features=False)
+g = torch.Generator(device=DEV).manual_seed(3)
+feats = torch.randn(P, C, device=DEV, generator=g); feats /= feats.norm(dim=1, keepdim=True)
+s, c = scene._replace(features=torch.empty(0, C)).to(DEV), cam.to(DEV)
+bg = torch.zeros(C, device=DEV)
+pool = raster.ScratchPool()
+def fwd(v):
+    raster.set_blend_variant(v)
+    return raster.rasterize_forward(bg, s.means3D, feats, s.opacities, s.scales, s.rotations, 1.0, E, c.world_view_transform,
+                                    c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, E, 0, c.camera_center, False, False, C, False, pool=pool)
+res = {}
+names = {0x6E: "sweep2 x6 pre-split", 0x16E: "sweep2 x6p no stores", 0x26E: "sweep2 x6p no mfma", 0x36E: "sweep2 x6p ring only", 0: "r2 bf16x3 sweep", 15: "r2 exact sweep", 0x6B: "sweep2 exact", 0x6A: "sweep2 x6 interleaved", 0x6D: "sweep2 x6 block by block", 0x6C: "sweep2 x6 wide(x16)",
+         0x16A: "sweep2 x6 ilv no stores", 0x16D: "sweep2 x6 bbb no stores", 0x26A: "sweep2 x6 no mfma", 0x36A: "sweep2 x6 ring only", 0x16B: "sweep2 exact no stores", 0x26B: "sweep2 exact no mfma"}
+TIMING_ONLY = len(sys.argv) > 1
+if TIMING_ONLY: names = {int(a, 0): a for a in sys.argv[1:]}
+for v in list(names):
+    try:
+        for _ in range(3): fwd(v)
+        torch.cuda.synchronize(); raster.get_stage_ms(); raster.set_stage_timing(2)
+        t0 = time.perf_counter()
+        for _ in range(12): out = fwd(v)
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 12
+        raster.set_stage_timing(0); ms = raster.get_stage_ms()
+        res[hex(v)] = {"name": names[v], "frame_ms": round(t * 1e3, 4), "stages": [round(x, 4) for x in ms]}
+        print(f"{v:#6x} {names[v]:28s} frame {t*1e3:.3f} ms  stages {[round(x, 3) for x in ms]}", flush=True)
+    except Exception as ex:
+        print(f"{v:#6x} {names[v]} FAILED: {ex}", flush=True)
+        res[hex(v)] = {"name": names[v], "error": str(ex)}
+if TIMING_ONLY: sys.exit(0)
+# ---- arithmetic
+ref_old = fwd(15)[1].clone()
+ex2 = fwd(0x6B)[1]
+print("sweep2 exact == r2 exact (bitwise):", torch.equal(ref_old, ex2), flush=True)
+res["exact_bitwise_equal"] = bool(torch.equal(ref_old, ex2))
+del ex2
+def stats(v):
+    o = fwd(v)[1]
+    err = (o - ref_old).abs()
+    pn = ref_old.abs().amax(dim=0, keepdim=True)
+    r_norm = (err / pn.clamp_min(1e-30)).max().item()
+    den = torch.maximum(ref_old.abs(), 1e-3 * pn).clamp_min(1e-30)
+    el = err / den
+    out = {"max_err_over_pixel_norm": r_norm, "elementwise_max": el.max().item(),
+           "elementwise_frac_gt_1e-4": (el > 1e-4).float().mean().item(), "elementwise_frac_gt_1e-5": (el > 1e-5).float().mean().item(),
+           "elementwise_frac_gt_1e-6": (el > 1e-6).float().mean().item(), "bitwise_equal_frac": (o == ref_old).float().mean().item()}
+    return out
+for v in (0x6E, 0x6A, 0):
+    try:
+        st = stats(v); res["err_" + hex(v)] = st; print(hex(v), st, flush=True)
+    except Exception as ex:
+        print("stats failed", hex(v), ex, flush=True)
+# ---- determinism of the x6 path: 200 frames
+o0 = fwd(0x6E)[1].clone(); bad = 0
+for _ in range(200):
+    bad += int(not torch.equal(fwd(0x6E)[1], o0))
+print("x6 nondeterministic frames of 200:", bad, flush=True); res["x6_nondet_of_200"] = bad
+o0 = fwd(0x6B)[1].clone(); bad = 0
+for _ in range(100):
+    bad += int(not torch.equal(fwd(0x6B)[1], o0))
+print("exact2 nondeterministic frames of 100:", bad, flush=True); res["exact2_nondet_of_100"] = bad
+raster.set_blend_variant(0)
+os.makedirs(os.path.join(ROOT, "gpurun_out", "r03a"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r03a", "sweep2.json"), "w"), indent=1)

@@ -47,6 +47,12 @@ def run(name, variant, rounds):
 
 if __name__ == "__main__":
     R = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+    if len(sys.argv) > 2:   # only the named variants, e.g. "0x808 0x6C"
+        for a in sys.argv[2:]:
+            run(a, int(a, 0), R)
+        sys.exit(0)
     run("x8 pairs (shipped)", 0, R)
     run("x16 (v_mfma_f32_32x32x16_bf16)", 0x808, R)
+    run("sweep2, six products on x16 (0x6C)", 0x6C, R)
+    run("sweep2, six products on x8 pairs (0x6E)", 0x6E, R)
     run("x8 pairs again", 0, R)
