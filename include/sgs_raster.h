@@ -217,7 +217,8 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
 #define SGS_OPT_BINNING_MODE 1
 #define SGS_OPT_BACKWARD_MODE 2
 #define SGS_OPT_STAGE_TIMING 3
-/* Row pitch, in pixels, of the out_color planes the NEXT forwards on this stream write: out_color is then
+/* Row pitch, in pixels, of the out_color planes the NEXT forward on this stream writes (ONE call: the forward consumes
+ * the override, so a pitch can never leak into a later call that passes a contiguous buffer): out_color is then
  * (C, H, pitch) floats and pixel (c, y, x) lives at out_color[(c * H + y) * pitch + x].  0 (default) = width
  * (contiguous (C,H,W), the reference's layout).  A pitch that is a multiple of 32 pixels makes every 16-pixel tile
  * pair a whole number of 128-byte lines whatever the image width is (BASELINE config 4: width 1297); the padding
@@ -251,15 +252,21 @@ int sgs_stream_set_option(void *stream, int option, int value);
 #define SGS_STAT_FORWARDS 3        /* forwards issued on this stream */
 #define SGS_STAT_DEFERRED_FORWARDS 4   /* of those, deferred-count ones */
 #define SGS_STAT_DEFERRED_RETRIES 5    /* deferred-count frames that did not fit (sgs_forward_result: SGS_ERETRY) */
-#define SGS_STAT_COUNT 6
+#define SGS_STAT_BWD_POOL_FALLBACKS 6  /* work-list backwards that got no scratch from the stream-ordered pool and ran on the
+                                         per-chunk kernel instead (the pool keeps up to SGS_BWD_POOL_RELEASE_MB, default
+                                         4096, resident outside the caller's allocator) */
+#define SGS_STAT_COUNT 7
 int sgs_stream_get_stat(void *stream, int stat, uint64_t *out);
 /* The counts of the last forward on `stream` (see SGS_OPT_DEFER_COUNT): the deferred form of the reference's blocking
  * `cudaMemcpy(&num_rendered, geomState.point_offsets + P - 1, sizeof(int), cudaMemcpyDeviceToHost)`
  * (CR/cuda_rasterizer/rasterizer_impl.cu:283).  wait != 0: blocks until they have arrived
  * (that is after the frame's scan, long before its blend); wait == 0: SGS_ENOTREADY if they have not.  After an
- * ordinary forward: 0 and its num_rendered, immediately. */
+ * ordinary forward: 0 and its num_rendered, immediately.  SGS_EINVAL if no forward was ever issued on (current
+ * device, stream) -- contexts are keyed by the CURRENT device: call it under the device the forward ran on. */
 int sgs_forward_result(void *stream, int wait, int *num_rendered);
-/* Frees the context of (current device, stream); returns 1 if there was one. */
+/* Frees the context of (current device, stream); returns 1 if there was one.  Drains `stream` first (kernels already
+ * enqueued may still write the context's pinned feedback words); calls in flight on other host threads keep the
+ * context alive until they return. */
 int sgs_stream_release(void *stream);
 
 /* Selects the forward blend kernels (tuning / A-B measurements).

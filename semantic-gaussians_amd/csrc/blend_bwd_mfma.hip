@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	for (int ci = 0; ci * CHUNK < total; ci++) {
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
 		const int mb = (cnt + 31) >> 5;
-		const uint32_t cstart = table[chunk_base + ci];
+		const uint32_t cstart = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)ci);
 		__syncthreads();
 		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
 		f32x16 acc[4];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		const int cnt16 = (cnt + 15) & ~15;   // rows up to here are initialised (zero padding of the work list)
 		const int mb = ((cnt + 31) >> 5) - 2 * mh;   // M blocks of this wave's entry half that hold entries
 		const bool wave_on = cbase + 32 * nb < C && mb > 0;   // (C % 32 == 0)
-		const uint32_t cstart = table[chunk_base + ci];
+		const uint32_t cstart = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)ci);
 		__syncthreads();
 		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
 		f32x16 acc[2];
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	for (int ci = 0; ci * CHUNK < total; ci++) {
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
 		const int mb = (cnt + 31) >> 5;
-		const uint32_t cstart = table[chunk_base + ci];
+		const uint32_t cstart = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)ci);
 		__syncthreads();
 		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
 		f32x16 acc[4];
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		const int cnt16 = (cnt + 15) & ~15;
 		const int mb = ((cnt + 31) >> 5) - 2 * mh;
 		const bool wave_on = cbase + 32 * nb < C && mb > 0;
-		const uint32_t cstart = table[chunk_base + ci];
+		const uint32_t cstart = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)ci);
 		__syncthreads();
 		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
 		f32x16 acc[2];
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 		const int o = __shfl_xor(wave_max, off);
 		wave_max = o > wave_max ? o : wave_max;
 	}
-	const uint32_t bg_slot = table[chunk_base + (uint32_t)real / CHUNK] + (uint32_t)real % CHUNK;
+	const uint32_t bg_slot = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)real / CHUNK) + (uint32_t)real % CHUNK;
 	const float bg_dot = Drows[(size_t)bg_slot * 256 + pxp];
 	const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 	float R = 0.f;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 		for (int q = threadIdx.x; q < 4 * 64 * 6; q += 256) (&s_acc[0][0][0])[q] = 0.f;
 		if ((int)threadIdx.x < n) {
 			const uint32_t g = (uint32_t)(hi - 1 - (int)threadIdx.x);
-			const uint32_t slot = table[chunk_base + g / CHUNK] + g % CHUNK;
+			const uint32_t slot = sgs_chunk_start(table, chunk_base, (uint32_t)tile, g / CHUNK) + g % CHUNK;
 			const uint32_t id = act_id[slot];
 			const float2 xy = means2D[id];
 			const float4 co = conic_opacity[id];

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	// Thread p only ever touches column p of s_pend, so no barrier is involved.
 	auto flush_group = [&](uint32_t gi) {
 		const uint32_t g0 = gi * 8u, ci = g0 / ACH;
-		const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+		const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];   // (ci >= 64 > 0: a table entry)
 		const uint32_t slot = cstart + (g0 % ACH);
 		if constexpr (MODE == 4) {
 			// three terms, w = t1 + t2 + t3 EXACTLY (8 significant bits each; the fp32 difference of a value and its own
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 							s_ovf = 1u;
 							break;
 						}
-						table[chunk_base + nc] = start;
+						if (nc != 0) table[chunk_base + nc] = start;   // chunk 0 is implicit (sgs_chunk_start)
 						if (nc < 64) s_chunk[nc] = start;
 						nc++;
 					}
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 					const int e = __builtin_ctz(m);
 					m &= m - 1;
 					const uint32_t g = total + r, ci = g / ACH;
-					const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+					const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];   // (ci >= 64 > 0: a table entry)
 					const uint32_t slot = cstart + (g % ACH);
 					if (BF) {
 						s_pend[(g & 7u) * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 				atomicExch(&counter[1], 1u);
 				s_ovf = 1u;
 			} else {
-				table[chunk_base + nchunks] = start;
+				if (nchunks != 0) table[chunk_base + nchunks] = start;
 				if (nchunks < 64) s_chunk[nchunks] = start;
 				nchunks++;
 			}
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 		__syncthreads();
 		if (s_ovf == 0u) {
 			const uint32_t g = total, ci = g / ACH;
-			const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+			const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];   // (ci >= 64 > 0: a table entry)
 			const float wT = inside ? T : 0.0f;
 			if (BF) {
 				s_pend[(g & 7u) * 256 + threadIdx.x] = wT;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 				if ((g & 7u) == 7u) flush_group(g >> 3);
 			} else {
 				const uint32_t ci = g / ACH;
-				const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];
+				const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];   // (ci >= 64 > 0: a table entry)
 				wgt[(size_t)(cstart + (g % ACH)) * 256 + pxp_own] = 0.0f;
 			}
 		}
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 					const uint32_t p0 = s_pref[t], nb = s_pref[t + 1] - p0;
 					if (q < nb && p0 + q >= wbase && p0 + q < wbase + SW_JMAX) {
 						const uint32_t tot = s_tot[t], first = q * AB;
-						const uint32_t slot = table[s_cb[t] + (first >> 7)] + (first & 127u);
+						const uint32_t slot = sgs_chunk_start(table, s_cb[t], (uint32_t)(ty * gx + tx0 + t), first >> 7) + (first & 127u);
 						const uint32_t n = (tot - first) < (uint32_t)AB ? (tot - first) : (uint32_t)AB;
 						s_bt[p0 + q - wbase] = make_uint2(slot, n | ((uint32_t)t << 8) | (q + 1 == nb ? 1u << 16 : 0u));
 					}
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep_kernel(
 			}
 		// past the end: 2 LA dummy batches (re-reads of a valid batch, never consumed)
 		if (threadIdx.x < 2 * LA && J + threadIdx.x >= wbase && J + threadIdx.x - wbase < SW_JMAX)
-			s_bt[J + threadIdx.x - wbase] = make_uint2(table[s_cb[nt - 1]], 1u | ((uint32_t)(nt - 1) << 8));
+			s_bt[J + threadIdx.x - wbase] = make_uint2((uint32_t)(ty * gx + tx0 + nt - 1) * 128u, 1u | ((uint32_t)(nt - 1) << 8));
 	};
 	fill_table(0);
 	__syncthreads();
@@ -1109,8 +1109,8 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// fp32-input MFMA; blend_sweep2.hip: 10 = f32-equivalent (six bf16 products), 11 = exact fp32 MFMA, 12 = six
 		// products on the double-rate MFMA (experiment).  All but 8 take fp32 weight rows.
 		const int arith_nib = split_mode & 15;
-		const bool sweep2 = arith_nib >= 10 && arith_nib <= 14;
-		const bool presplit3 = arith_nib == 14;   // weights handed over as three bf16 terms
+		const bool sweep2 = arith_nib >= 10 && arith_nib <= 15;
+		const bool presplit3 = arith_nib >= 14;   // weights handed over as three bf16 terms
 		const bool exact = arith_nib == 9;
 		if (presplit3) SGS_LAUNCH_W(4, st, 0, ntiles);
 		else if (exact || sweep2) SGS_LAUNCH_W(3, st, 0, ntiles);
@@ -1136,7 +1136,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
 		if (sweep2) {
-			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : 1))), (split_mode >> 8) & 15, a, table,
+			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : (arith_nib == 15 ? 5 : 1)))), (split_mode >> 8) & 15, a, table,
 								  nbatches, act_id, (const char*)wgt, counter, nc, seg, nseg, pxcd, items,
 								  g_sweep_trace, order_arg, dealt);
 			if (e2 != hipSuccess) return e2;

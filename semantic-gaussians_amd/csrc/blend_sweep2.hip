@@ -340,6 +340,37 @@ __device__ __forceinline__ void mfma_dense(const Op3& A, const u32x4 (&x)[3], co
 #undef S2_MY
 }
 
+// the double-rate forms: one v_mfma_f32_32x32x16_bf16 per (A term, B term) and block
+template <int BX, int BY>
+__device__ __forceinline__ void mfma_pair_wide(u32x4 a, u32x4 bx, u32x4 by)
+{
+	asm volatile(
+		"s_nop 1\n\t"
+		"v_mfma_f32_32x32x16_bf16 a[%c0:%c1], %4, %5, a[%c0:%c1]\n\t"
+		"v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %4, %6, a[%c2:%c3]"
+		: : "i"(BX * 16), "i"(BX * 16 + 15), "i"(BY * 16), "i"(BY * 16 + 15), "v"(a), "v"(bx), "v"(by)
+		: S2_ACC, "memory");
+}
+
+template <int BX, int BY>
+__device__ __forceinline__ void mfma_dense_wide(const u32x4 (&a)[3], const u32x4 (&x)[3], const u32x4 (&y)[3])
+{
+#define S2_P(a_, bx_, by_) "v_mfma_f32_32x32x16_bf16 a[%c0:%c1], " a_ ", " bx_ ", a[%c0:%c1]\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], " a_ ", " by_ ", a[%c2:%c3]\n\t"
+	asm volatile(
+		"s_nop 1\n\t"
+		S2_P("%6", "%7", "%10")     // A3 B1
+		S2_P("%4", "%9", "%12")     // A1 B3
+		S2_P("%5", "%8", "%11")     // A2 B2
+		S2_P("%5", "%7", "%10")     // A2 B1
+		S2_P("%4", "%8", "%11")     // A1 B2
+		S2_P("%4", "%7", "%10")     // A1 B1
+		"s_nop 0"
+		: : "i"(BX * 16), "i"(BX * 16 + 15), "i"(BY * 16), "i"(BY * 16 + 15),
+		    "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(y[0]), "v"(y[1]), "v"(y[2])
+		: S2_ACC, "memory");
+#undef S2_P
+}
+
 // The batch with the weights already split by the weights pre-pass (work-list format MODE 4): stage = features (fp32,
 // split here: 44 VALU) | [group h][term][128 px x 8 bf16].  A lane's B operand of a (term, pixel block) is ONE 16-byte
 // read: its two halves are the operands of the two MFMAs over k = 8 h + 4 q + i.  Pixel blocks in pairs, consecutive
@@ -347,7 +378,7 @@ __device__ __forceinline__ void mfma_dense(const Op3& A, const u32x4 (&x)[3], co
 // after 32); the second pair's operands land while the first pair multiplies.  The first pair is one dense statement;
 // the NP pieces of the next bundle's DMA (`piece`) go between the second pair's statements, where their issue slots
 // (~60 cycles each) hide behind 64 cycles of matrix work.
-template <int B0, int B1, int B2, int B3, int NP, typename F>
+template <bool WIDE, int B0, int B1, int B2, int B3, int NP, typename F>
 __device__ __forceinline__ void s2_compute_x6p(uint32_t st, int cg, int half, int l31, F piece)
 {
 	const uint32_t fa = st + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;
@@ -373,10 +404,26 @@ __device__ __forceinline__ void s2_compute_x6p(uint32_t st, int cg, int half, in
 	S2_RDB(y2, 3);
 	S2_WTB(x, 9);
 	S2_WTB(y, 6);
+	constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+	if constexpr (WIDE) {   // the lane's 8 k-values of a term are one operand of the double-rate MFMA
+		u32x4 a[3];
+#pragma unroll
+		for (int t = 0; t < 3; t++) a[t] = u32x4{A.t[t][0].x, A.t[t][0].y, A.t[t][1].x, A.t[t][1].y};
+		mfma_dense_wide<B0, B1>(a, x, y);
+		S2_WTB(x2, 3);
+		S2_WTB(y2, 0);
+#define S2_HALF2W(c_)                                                                                \
+	do {                                                                                             \
+		mfma_pair_wide<B2, B3>(a[TA[c_]], x2[TB[c_]], y2[TB[c_]]);                                   \
+		if constexpr ((c_) < NP) piece(std::integral_constant<int, (c_)>{});                         \
+	} while (0)
+		S2_HALF2W(0); S2_HALF2W(1); S2_HALF2W(2); S2_HALF2W(3); S2_HALF2W(4); S2_HALF2W(5);
+#undef S2_HALF2W
+		return;
+	}
 	mfma_dense<B0, B1>(A, x, y);
 	S2_WTB(x2, 3);
 	S2_WTB(y2, 0);
-	constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
 #define S2_HALF2(c_)                                                                                 \
 	do {                                                                                             \
 		mfma_pair<B2, B3>(A.t[TA[c_]][0], u32x2{x2[TB[c_]].x, x2[TB[c_]].y}, u32x2{y2[TB[c_]].x, y2[TB[c_]].y}); \
@@ -528,7 +575,7 @@ __device__ __forceinline__ void s2_store_single(float* bp, size_t HW, bool ok)
 
 } // namespace
 
-enum { S2_EXACT = 0, S2_X6 = 1, S2_X6W = 2, S2_X6S = 3, S2_X6P = 4 };   // X6P: weights pre-split by the weights kernel   // X6S: the six products block by block (the first form; A/B)
+enum { S2_EXACT = 0, S2_X6 = 1, S2_X6W = 2, S2_X6S = 3, S2_X6P = 4, S2_X6PW = 5 };   // X6PW: X6P on v_mfma_f32_32x32x16_bf16   // X6P: weights pre-split by the weights kernel   // X6S: the six products block by block (the first form; A/B)
 
 // DBG (development ablations, 0 in production): 1 = no stores, 2 = no matrix work, 4 / 8 = store ablations (s2_store4).
 template <int ARITH, int DBG>
@@ -571,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	const int c0 = cbase + cg * 32;
 	const size_t HW = (size_t)H * PW;
 
-	constexpr bool PRE = ARITH == S2_X6P;
+	constexpr bool PRE = ARITH == S2_X6P || ARITH == S2_X6PW;
 	constexpr int S2_NST = RingCfg<PRE>::NST, S2_LA = RingCfg<PRE>::LA, S2_STAGE = RingCfg<PRE>::STAGE;
 	__shared__ float4 s_ring[S2_NST * S2_STAGE / 16];
 	__shared__ uint2 s_bt[S2_JMAX];   // .x = first arena slot of the batch, .y = entries | tile in segment << 8 | last of tile << 16
@@ -605,14 +652,14 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 					const uint32_t p0 = s_pref[t], nb = s_pref[t + 1] - p0;
 					if (q < nb && p0 + q >= wbase && p0 + q < wbase + S2_JMAX) {
 						const uint32_t tot = s_tot[t], first = q * AB;
-						const uint32_t slot = table[s_cb[t] + (first >> 7)] + (first & 127u);
+						const uint32_t slot = sgs_chunk_start(table, s_cb[t], (uint32_t)(ty * gx + tx0 + t), first >> 7) + (first & 127u);
 						const uint32_t n = (tot - first) < (uint32_t)AB ? (tot - first) : (uint32_t)AB;
 						s_bt[p0 + q - wbase] = make_uint2(slot, n | ((uint32_t)t << 8) | (q + 1 == nb ? 1u << 16 : 0u));
 					}
 				}
 			}
 		if (threadIdx.x < 2 * S2_LA && J + threadIdx.x >= wbase && J + threadIdx.x - wbase < S2_JMAX)
-			s_bt[J + threadIdx.x - wbase] = make_uint2(table[s_cb[nt - 1]], 1u | ((uint32_t)(nt - 1) << 8));
+			s_bt[J + threadIdx.x - wbase] = make_uint2((uint32_t)(ty * gx + tx0 + nt - 1) * 128u, 1u | ((uint32_t)(nt - 1) << 8));
 	};
 	fill_table(0);
 	__syncthreads();
@@ -747,10 +794,10 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 // between its MFMA statements; the others issue the bundle first.
 #define S2_COMPUTE(b0_, b1_, b2_, b3_)                                                               \
 	do {                                                                                             \
-		if ((DBG & 2) || ARITH != S2_X6P) issue_all(nb);                                             \
+		if ((DBG & 2) || !PRE) issue_all(nb);                                                        \
 		if (!(DBG & 2)) {                                                                            \
 			if (ARITH == S2_EXACT) s2_compute_exact<b0_, b1_, b2_, b3_>(st0, cg, half, l31);          \
-			else if (ARITH == S2_X6P) s2_compute_x6p<b0_, b1_, b2_, b3_, NPIECE>(st0, cg, half, l31, [&](auto I) __attribute__((always_inline)) { dma_piece(I, nb); }); \
+			else if (PRE) s2_compute_x6p<ARITH == S2_X6PW, b0_, b1_, b2_, b3_, NPIECE>(st0, cg, half, l31, [&](auto I) __attribute__((always_inline)) { dma_piece(I, nb); }); \
 			else s2_compute_x6<ARITH == S2_X6W, ARITH == S2_X6, b0_, b1_, b2_, b3_>(st0, cg, half, l31); \
 		}                                                                                            \
 	} while (0)
@@ -891,6 +938,10 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 		else S2_LAUNCH(S2_EXACT, 0);
 	} else if (arith == S2_X6W) {
 		S2_LAUNCH(S2_X6W, 0);
+	} else if (arith == S2_X6PW) {
+		if (dbg == 1) S2_LAUNCH(S2_X6PW, 1);
+		else if (dbg == 2) S2_LAUNCH(S2_X6PW, 2);
+		else S2_LAUNCH(S2_X6PW, 0);
 	} else if (arith == S2_X6P) {
 		if (dbg == 1) S2_LAUNCH(S2_X6P, 1);
 		else if (dbg == 2) S2_LAUNCH(S2_X6P, 2);

@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -53,6 +54,7 @@ struct StreamCtx {
 	uint32_t* count_host = nullptr;
 	hipEvent_t count_ev = nullptr;
 	bool count_pending = false;
+	bool any_forward = false;   // a forward has been issued on this (device, stream)
 	int last_num_rendered = 0;
 	uint64_t stat[SGS_STAT_COUNT];
 	StreamCtx()
@@ -91,16 +93,18 @@ struct StreamCtx {
 };
 
 std::mutex g_ctx_mu;
-std::map<std::pair<int, void*>, std::unique_ptr<StreamCtx>> g_ctx;
+std::map<std::pair<int, void*>, std::shared_ptr<StreamCtx>> g_ctx;
 
-StreamCtx* ctx_of(void* stream)
+// Shared ownership: a call holds its context for its whole duration, so sgs_stream_release() from another thread
+// cannot free a context that a forward / backward / result call is still using (it only drops the map's reference).
+std::shared_ptr<StreamCtx> ctx_of(void* stream)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) dev = 0;
 	std::lock_guard<std::mutex> lk(g_ctx_mu);
 	auto& slot = g_ctx[std::make_pair(dev, stream)];
-	if (!slot) slot.reset(new StreamCtx());
-	return slot.get();
+	if (!slot) slot = std::make_shared<StreamCtx>();
+	return slot;
 }
 
 // The backward's work-list scratch: a PRIVATE stream-ordered pool per device.  The default pool is left alone
@@ -126,7 +130,11 @@ hipMemPool_t scratch_pool()
 		(void)hipGetLastError();
 		pool = nullptr;
 	} else {
+		// memory this pool keeps across synchronisations is invisible to the host framework's allocator (torch's
+		// empty_cache() cannot reclaim it): SGS_BWD_POOL_RELEASE_MB bounds it (default 4096; 0 = give everything
+		// back at every synchronisation, one driver allocation per backward)
 		uint64_t threshold = 4ull << 30;
+		if (const char* env = getenv("SGS_BWD_POOL_RELEASE_MB")) threshold = (uint64_t)strtoull(env, nullptr, 10) << 20;
 		(void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
 	}
 	g_pool[dev] = pool;
@@ -397,7 +405,7 @@ int sgs_set_backward_mode(int mode) { return g_default_opt[SGS_OPT_BACKWARD_MODE
 int sgs_stream_set_option(void* stream, int option, int value)
 {
 	if (option < 0 || option >= SGS_OPT_COUNT) return fail(SGS_EINVAL, "unknown option");
-	StreamCtx* c = ctx_of(stream);
+	const std::shared_ptr<StreamCtx> c = ctx_of(stream);
 	std::lock_guard<std::mutex> lk(c->mu);
 	const int prev = c->opt[option];
 	c->opt[option] = value < 0 ? -1 : value;
@@ -406,8 +414,10 @@ int sgs_stream_set_option(void* stream, int option, int value)
 
 int sgs_forward_result(void* stream, int wait, int* num_rendered)
 {
-	StreamCtx* c = ctx_of(stream);
+	const std::shared_ptr<StreamCtx> c = ctx_of(stream);
 	std::lock_guard<std::mutex> lk(c->mu);
+	if (!c->any_forward)   // wrong stream, or the wrong current device: contexts are keyed by (hipGetDevice(), stream)
+		return fail(SGS_EINVAL, "sgs_forward_result: no forward has been issued on this (current device, stream)");
 	if (!c->count_pending) {   // the last forward on this stream was an ordinary (blocking) one
 		if (num_rendered) *num_rendered = c->last_num_rendered;
 		return 0;
@@ -435,7 +445,7 @@ int sgs_forward_result(void* stream, int wait, int* num_rendered)
 int sgs_stream_get_stat(void* stream, int stat, uint64_t* out)
 {
 	if (stat < 0 || stat >= SGS_STAT_COUNT || !out) return fail(SGS_EINVAL, "unknown statistic");
-	StreamCtx* c = ctx_of(stream);
+	const std::shared_ptr<StreamCtx> c = ctx_of(stream);
 	std::lock_guard<std::mutex> lk(c->mu);
 	*out = c->stat[stat];
 	return 0;
@@ -445,8 +455,21 @@ int sgs_stream_release(void* stream)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-	std::lock_guard<std::mutex> lk(g_ctx_mu);
-	return (int)g_ctx.erase(std::make_pair(dev, stream));
+	std::shared_ptr<StreamCtx> c;
+	{
+		std::lock_guard<std::mutex> lk(g_ctx_mu);
+		auto it = g_ctx.find(std::make_pair(dev, stream));
+		if (it == g_ctx.end()) return 0;
+		c = it->second;
+		g_ctx.erase(it);
+	}
+	// calls in flight on other threads keep their own reference; kernels already enqueued on the stream may still
+	// write the pinned feedback words, so the stream is drained before the last reference (and with it the pinned
+	// memory) goes away
+	std::lock_guard<std::mutex> lk(c->mu);
+	(void)hipStreamSynchronize((hipStream_t)stream);
+	(void)hipGetLastError();
+	return 1;
 }
 
 int sgs_get_stage_ms(float* ms7)
@@ -527,9 +550,15 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	const int gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
 	const int ntiles = gx * gy;
 
-	StreamCtx* const cx = ctx_of(stream);
+	const std::shared_ptr<StreamCtx> cx_owner = ctx_of(stream);
+	StreamCtx* const cx = cx_owner.get();
 	std::lock_guard<std::mutex> ctx_lock(cx->mu);
 	cx->stat[SGS_STAT_FORWARDS]++;
+	cx->any_forward = true;
+	// the output pitch is consumed by the forward it was set for (a per-stream override never outlives one call: a
+	// stale pitch on a later forward with a contiguous buffer would be an out-of-bounds write)
+	const int out_pitch_opt = cx->option(SGS_OPT_OUT_PITCH);
+	cx->opt[SGS_OPT_OUT_PITCH] = -1;
 	StageTimer tm(cx->option(SGS_OPT_STAGE_TIMING), st);
 
 	const GeomLayout gl = geom_layout(P);
@@ -676,7 +705,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// variants 32 / 33: the fused single-kernel blend (split-bf16 / exact fp32), bits [11:8] = segment length / 2
 	// 32-35: the experimental single-kernel blends (contiguous output only)
 	const bool want_fused = !defer && (variant & 0xff) >= 32 && (variant & 0xff) <= 35 &&
-				(cx->option(SGS_OPT_OUT_PITCH) <= 0 || cx->option(SGS_OPT_OUT_PITCH) == width);
+				(out_pitch_opt <= 0 || out_pitch_opt == width);
 	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
@@ -781,7 +810,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.n_contrib = (uint32_t*)(ichunk + il.n_contrib);
 	a.out = out_color;
 	a.out_depth = out_depth;
-	a.pitch = cx->option(SGS_OPT_OUT_PITCH) > 0 ? cx->option(SGS_OPT_OUT_PITCH) : width;
+	a.pitch = out_pitch_opt > 0 ? out_pitch_opt : width;
 	a.abort = abort_word;
 	a.usage_host = nullptr;
 	a.counter_reset_done = counter_reset_done;
@@ -843,7 +872,8 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 		return fail(SGS_EINVAL, "null gradient buffer");
 	if (shs && num_channels != 3) return fail(SGS_EINVAL, "SH colours imply 3 channels");
 
-	StreamCtx* const cx = ctx_of(stream);
+	const std::shared_ptr<StreamCtx> cx_owner = ctx_of(stream);
+	StreamCtx* const cx = cx_owner.get();
 	std::lock_guard<std::mutex> ctx_lock(cx->mu);
 	const int gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
 	const GeomLayout gl = geom_layout(P);
@@ -927,8 +957,9 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 				const hipError_t e2 = hipFreeAsync(scratch, st);
 				if (e == hipSuccess) e = e2;
 				done = true;
-			} else {
+			} else {   // no scratch: this backward runs on the per-chunk kernel (counted: it is ~25x slower at C = 512)
 				(void)hipGetLastError();
+				cx->stat[SGS_STAT_BWD_POOL_FALLBACKS]++;
 			}
 		}
 		if (!done) {

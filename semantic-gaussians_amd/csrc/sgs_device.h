@@ -227,4 +227,15 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 				       -0.4570457994644658f, 1.445305721320277f,
 				       -0.5900435899266435f};
 
+
+// Work-list chunk starts (blend_fwd_split.hip): chunk 0 of EVERY tile is pre-assigned (slots [tile * 128, tile * 128 + 128));
+// only chunks >= 1 go through `table`, at index (range.x >> 7) + tile + c.  That index is collision free among
+// non-empty tiles (consecutive lists satisfy floor((x+n)/128) + 1 >= floor(x/128) + ceil(n/128)); an EMPTY tile has
+// range (0, 0) like the reference's, so its index would be `tile` and can coincide with an early tile's -- which is why
+// chunk 0 never touches the table (round 3: an empty tile next to a short-offset tile rendered that tile's first entry).
+__device__ __forceinline__ uint32_t sgs_chunk_start(const uint32_t* __restrict__ table, uint32_t chunk_base, uint32_t tile, uint32_t ci)
+{
+	return ci == 0u ? tile * 128u : table[chunk_base + ci];
+}
+
 } // namespace sgs

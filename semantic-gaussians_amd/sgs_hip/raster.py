@@ -165,9 +165,11 @@ class DeferredForward:
             return self._out
         lib = _lib.load()
         n = C.c_int(0)
-        rc = lib.sgs_forward_result(C.c_void_p(self._stream.cuda_stream), 1, C.byref(n))
+        # the library keys its per-stream context on (current device, stream): resolve under the forward's device
+        with torch.cuda.device(self._stream.device):
+            rc = lib.sgs_forward_result(C.c_void_p(self._stream.cuda_stream), 1, C.byref(n))
         if rc == _lib.ERETRY:
-            with torch.cuda.stream(self._stream):
+            with torch.cuda.device(self._stream.device), torch.cuda.stream(self._stream):
                 self._out = rasterize_forward(*self._args, **self._kwargs)
             self.retried = True
             self.layout_count = self._out[0]
@@ -224,8 +226,6 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         if OUTPUT_PITCH_ALIGN > 1 and W % OUTPUT_PITCH_ALIGN and Cn >= 128 and not want_depth:
             pitch = -(-W // OUTPUT_PITCH_ALIGN) * OUTPUT_PITCH_ALIGN
         color = torch.empty(Cn, H, pitch, dtype=torch.float32, device=dev)   # fully overwritten
-        if pitch != W:
-            lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, pitch)
         if want_depth:
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
 
@@ -236,18 +236,25 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
 
         bg = _check_bg(background, Cn)
         M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
-        rc = lib.sgs_rasterize_forward(
-            *bufs.callback("g"), *bufs.callback("b"), *bufs.callback("i"),
-            P, int(degree), int(M), p(bg, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
-            p(colors, "colors_precomp"), p(opacity, "opacities"), p(scales, "scales"),
-            float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
-            p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
-            float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), Cn, color.data_ptr(),
-            depth.data_ptr() if depth is not None else None, radii.data_ptr(), int(bool(debug)),
-            _stream_ptr(dev))
-        bufs.release()
+        # every argument is marshalled BEFORE the pitch is set (nothing between the set and the call can raise); the
+        # library consumes the override in that call, the finally covers a failure inside ctypes itself
+        args = (*bufs.callback("g"), *bufs.callback("b"), *bufs.callback("i"),
+                P, int(degree), int(M), p(bg, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
+                p(colors, "colors_precomp"), p(opacity, "opacities"), p(scales, "scales"),
+                float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), Cn, color.data_ptr(),
+                depth.data_ptr() if depth is not None else None, radii.data_ptr(), int(bool(debug)),
+                _stream_ptr(dev))
+        try:
+            if pitch != W:
+                lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, pitch)
+            rc = lib.sgs_rasterize_forward(*args)
+        finally:
+            bufs.release()
+            if pitch != W:
+                lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, -1)
         if pitch != W:
-            lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, -1)
             color = color[:, :, :W]
         num_rendered = _lib.check(rc, "rasterize_gaussians failed")
     return num_rendered, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
@@ -280,7 +287,6 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
         dL_dcolors = torch.empty(P, Cn, **opts) if P != 0 else torch.zeros(P, Cn, **opts)
         if P != 0:
             sp = _stream_ptr(dev)
-            prev_clear = lib.sgs_stream_set_option(sp, _lib.OPT_BWD_CLEARS_DCOLOR, 1)
             keep = []
 
             def p(t, name, dtype=torch.float32):
@@ -288,7 +294,7 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
                 keep.append(kept)
                 return ptr
 
-            rc = lib.sgs_rasterize_backward(
+            bargs = (
                 P, int(degree), int(M), int(R), p(background, "bg"), W, H, p(means3D, "means3D"),
                 p(sh, "sh"), p(colors, "colors_precomp"), p(scales, "scales"),
                 float(scale_modifier), p(rotations, "rotations"),
@@ -302,7 +308,11 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
                 dL_drotations.data_ptr(), int(bool(debug)), sp)
-            lib.sgs_stream_set_option(sp, _lib.OPT_BWD_CLEARS_DCOLOR, -1 if prev_clear == 0x7fffffff else prev_clear)
+            prev_clear = lib.sgs_stream_set_option(sp, _lib.OPT_BWD_CLEARS_DCOLOR, 1)
+            try:
+                rc = lib.sgs_rasterize_backward(*bargs)
+            finally:
+                lib.sgs_stream_set_option(sp, _lib.OPT_BWD_CLEARS_DCOLOR, -1 if prev_clear == 0x7fffffff else prev_clear)
             _lib.check(rc, "rasterize_gaussians_backward failed")
     return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
             dL_drotations)

@@ -14,7 +14,7 @@ from test_parity_gpu import _hip_forward
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-V_X6, V_EXACT, V_X6W, V_X6S, V_X6P = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E
+V_X6, V_EXACT, V_X6W, V_X6S, V_X6P, V_X6PW = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E, 0x6F
 # Against the fp32 ORACLE the difference is dominated by the oracle's own roundings: its multiply-add chain rounds once
 # per contribution (<= 2^-24 |partial sum| each, K ~ 50-300 contributions), the six-product path drops
 # F2 W3 + F3 W2 + F3 W3 <= 2^-23 |f w| per term and rounds once per MFMA.  4e-6 of the ABSOLUTE composite
@@ -56,7 +56,7 @@ def check(orc, scene, cam, variant, seg=None, **kw):
 SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64), (128, 336, 48)]
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6W, V_X6S, V_X6P])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6W, V_X6S, V_X6P, V_X6PW])
 @pytest.mark.parametrize("C,W,H", SHAPES)
 def test_sweep2_shapes(orc, variant, C, W, H):
     """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
@@ -66,7 +66,7 @@ def test_sweep2_shapes(orc, variant, C, W, H):
     check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW])
 def test_sweep2_background_and_short_lists(orc, variant):
     """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
     scene, cam = small_scene(P=60, C=128, W=208, H=96, fx=170.0, seed=5)
@@ -77,7 +77,7 @@ def test_sweep2_background_and_short_lists(orc, variant):
     assert (r[:, 0] == r[:, 1]).any()   # empty tiles exist
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW])
 def test_sweep2_long_lists(orc, variant):
     """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
     deferred stores ride along tiles of very different lengths."""
@@ -89,7 +89,7 @@ def test_sweep2_long_lists(orc, variant):
     check(orc, scene, cam, variant, seg=6)   # one 49-tile segment: ~2900 batches
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW])
 def test_sweep2_padded_pitch(orc, variant):
     """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
     from sgs_hip import raster
