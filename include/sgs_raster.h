@@ -270,15 +270,24 @@ int sgs_forward_result(void *stream, int wait, int *num_rendered);
 int sgs_stream_release(void *stream);
 
 /* Selects the forward blend kernels (tuning / A-B measurements).
- *   0 (default) = for num_channels >= 128: weights pre-pass + row-sweep split-bf16 MFMA accumulate for the
- *                 128-channel-aligned part (feature map within 5e-5 of the absolute composite, every
- *                 integer output bit-exact), px1 for the remainder; px1 below 128 channels / RGB-D;
- *  15           = as 0 but the accumulate is the fp32-input MFMA kernel: bit-identical feature map
- *                 (what SGS_BLEND_EXACT=1 selects in the Python layer);
+ *   0 (default) = for num_channels >= 128: weights pre-pass + row-sweep accumulate for the 128-channel-aligned part in
+ *                 "f32-equivalent" arithmetic: features and weights split EXACTLY into three bf16 terms each, the six
+ *                 products with i + j <= 4 on v_mfma_f32_32x32x8_bf16, fp32 accumulate -- measured against the exact
+ *                 (float64) composite it is as accurate as the reference's fp32 multiply-add chain
+ *                 (CR/cuda_rasterizer/forward.cu:355-356), every integer output bit-exact; px1 for the remainder
+ *                 channels; px1 below 128 channels / RGB-D;
+ *  15           = as 0 but the accumulate is the fp32-input MFMA kernel: the feature map is BIT-IDENTICAL to the
+ *                 contract's fp32 fma chain (what SGS_BLEND_EXACT=1 selects in the Python layer);
+ *  14           = round 2's arithmetic: two bf16 terms per operand, three products (<= 3 * 2^-16 of sum |f| w):
+ *                 the fastest, NOT fp32-class;
  *  1/2/3        = single-kernel px1 with 64/128/32 channels per workgroup; 4/5/6 = single-kernel px4
  *                 forms (all bit-identical);
- *  >= 16        = sweep tuning word: bits [3:0] = 8, [7:4] segment length / 8 (0 = adaptive),
- *                 [11:8] development ablations (1 = no stores, 2 = no matrix work, 4 = plain C++ stores).
+ *  >= 16        = sweep tuning word: bits [3:0] accumulate kernel (8 = variant 14's, 9 = its fp32-MFMA form,
+ *                 blend_sweep2.hip: 10 six products with the weights split in the sweep, 11 fp32 MFMA, 13 as 10 block by
+ *                 block, 14 six products with weights pre-split by the pre-pass (the default), 12 / 15 = 10 / 14 on the
+ *                 double-rate v_mfma_f32_32x32x16_bf16 -- EXPERIMENTS ONLY: kernels that issue that instruction densely
+ *                 damage unrelated kernels running beside them on this hardware), [7:4] segment length / 8
+ *                 (0 = adaptive), [11:8] development ablations (1 = no stores, 2 = no matrix work, 4 / 8 = store forms).
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.

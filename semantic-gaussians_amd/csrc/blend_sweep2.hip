@@ -588,6 +588,11 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	unsigned long long* __restrict__ trace, const uint32_t* __restrict__ order, int dealt)
 {
 	if (counter[1] != 0u) return;   // arena overflowed / frame aborted
+#ifdef SGS_SWEEP_EXCLUSIVE
+	// EXPERIMENT: claim accumulator registers up to a[151]: 104 VGPRs + 152 AGPRs = 256 = half a SIMD's file, so nothing
+	// else fits on a SIMD beside two waves of this kernel
+	if (ARITH == S2_X6PW) asm volatile("" : : : "a151");
+#endif
 	const int b = blockIdx.x;
 	int chunk, g, rest;   // 128-channel chunk, row parity, segment (= ty * nseg + sg) of this workgroup
 	if (dealt) {   // segments dealt to the XCDs in serpentine order of their rank (sweep_plan_kernel)

@@ -704,8 +704,14 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	const int variant = cx->option(SGS_OPT_BLEND_VARIANT);
 	// variants 32 / 33: the fused single-kernel blend (split-bf16 / exact fp32), bits [11:8] = segment length / 2
 	// 32-35: the experimental single-kernel blends (contiguous output only)
+#ifdef SGS_WITH_FUSED   // (make FUSED=1: the two single-kernel experiments of round 2, DESIGN.md 5.6 -- evidence, not product)
 	const bool want_fused = !defer && (variant & 0xff) >= 32 && (variant & 0xff) <= 35 &&
 				(out_pitch_opt <= 0 || out_pitch_opt == width);
+#else
+	const bool want_fused = false;
+	if ((variant & 0xff) >= 32 && (variant & 0xff) <= 35 && variant < 0x100)
+		return fail(SGS_EINVAL, "blend variants 32-35 (fused single-kernel experiments) are not in this build (make FUSED=1)");
+#endif
 	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
@@ -815,19 +821,26 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.usage_host = nullptr;
 	a.counter_reset_done = counter_reset_done;
 	if (a.pitch < width) return fail(SGS_EINVAL, "output pitch smaller than the image width");
+#ifdef SGS_WITH_FUSED
 	if (want_fused && (variant & 0xff) >= 34 && sgs::blend_forward_fused_pc_eligible(a)) {
 		tm.mark();
 		e = sgs::launch_blend_forward_fused_pc(st, a, (variant & 0xff) == 35, ((variant >> 8) & 15) * 2, (variant >> 12) & 15);
 	} else if (want_fused && sgs::blend_forward_fused_eligible(a) && (size_t)128 * width * height * 4 < (1ull << 32)) {
 		tm.mark();
 		e = sgs::launch_blend_forward_fused(st, a, (variant & 0xff) == 33, ((variant >> 8) & 15) * 2);
-	} else if (use_split) {
+	} else
+#endif
+	if (use_split) {
 		char* arena = bchunk + bl.arena;
+		// accumulate arithmetic (low nibble of the sweep word, blend_fwd_split.hip): default 14 = six bf16 products of the exact
+		// three-term splits on the x8 MFMA ("f32-equivalent", blend_sweep2.hip); variant 15 = 11 = fp32-input MFMA, bit-identical;
+		// variant 14 = 8 = round 2's two-term split (three products, 3 * 2^-16 per term: the fastest, not fp32-class)
+		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : 14));
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
 		const bool can_report = cx->ensure(cx->usage_host, cx->usage_ev);
 		a.usage_host = can_report ? cx->usage_host : nullptr;
 		bool usage_reported = false;
-		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, variant >= 16 ? variant : (variant == 15 ? 9 : 8), &usage_reported);
+		e = sgs::launch_blend_forward_split(st, a, arena, bl.arena_lay, [](void* u) { static_cast<MarkCtx*>(u)->t->mark(); }, &mctx, split_word, &usage_reported);
 		if (e != hipSuccess) return fail_hip(e, "blend forward (split)");
 		const uint32_t* counter = (const uint32_t*)(arena + bl.arena_lay.counter);
 		const int c_split = (num_channels / 128) * 128;

@@ -7,8 +7,8 @@
         (a width that is not a multiple of 16): integers in full, sampled tile rows against the oracle;
   cfg5  Gaussian sharding as a two-slab depth-ordered composite of HIP (A, T) partials against the single render
         (one GPU; P scaled to 2M -- the 50M x 256 table is a capacity statement, not a different code path);
-  cfg3  the default (split-bf16) arithmetic DIRECTLY against the oracle: all 512 channels on four tile rows, with the
-        element-wise error distribution the north star's "1e-4 relative" is read against.
+  cfg3  the default (six-product, f32-equivalent) arithmetic DIRECTLY against the oracle and against the exact (float64)
+        composite: all 512 channels on four tile rows, element-wise.
 """
 import numpy as np
 import pytest
@@ -176,8 +176,14 @@ def test_cfg5_gaussian_sharding_two_depth_slabs(orc):
 
 
 def test_cfg3_default_arithmetic_directly_against_the_oracle(orc):
-    """All 512 channels on four tile rows of the headline frame, DEFAULT arithmetic vs the oracle, with the
-    element-wise relative error the way a reader of "1e-4 relative" expects it."""
+    """All 512 channels on four tile rows of the headline frame, DEFAULT arithmetic (six bf16 products of exact three-term
+    splits, fp32 accumulate) against the oracle AND against the exact composite (float64 sums of the same fp32 weights).
+
+    Read element-wise -- |err| <= 1e-4 max(|x|, 1e-3 ||pixel||_inf) -- NO fp32 evaluation order but the oracle's own
+    matches the oracle everywhere: elements that cancel to ~1e-3 of their pixel carry the chain's own rounding
+    (K contributions x 2^-24) at the 1e-4 level.  So the test states both halves: (a) against the oracle the default is
+    inside 5e-6 of the pixel's largest channel and the element-wise form fails on <= 1e-5 of the elements; (b) against
+    the exact composite it is AS ACCURATE AS THE ORACLE'S fp32 chain, by the same element-wise measure."""
     from sgs_hip import raster
     from sgs_hip.synthetic import CONFIGS, make_config
     P, C, W, H, fx = CONFIGS["cfg3"]
@@ -187,23 +193,34 @@ def test_cfg3_default_arithmetic_directly_against_the_oracle(orc):
     out = _forward(s, c, s.features, s.bg, W, H)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     feats = scene.features.numpy()
-    worst_pix, worst_elem, q999, q50, frac = 0.0, 0.0, 0.0, 0.0, 0.0
+    worst_pix, worst_elem, frac = 0.0, 0.0, 0.0
+    hip_t = {"max": 0.0, "frac": 0.0, "rms": 0.0}
+    orc_t = {"max": 0.0, "frac": 0.0, "rms": 0.0}
     for row in (3, 20, 41, gy - 1):
         ob = orc.blend_forward(pre, binn, feats, scene.bg.numpy(), W, H, tile_lo=row * gx, tile_hi=(row + 1) * gx)
+        truth = orc.blend_forward_f64(pre, binn, feats, scene.bg.numpy(), W, H, tile_lo=row * gx, tile_hi=(row + 1) * gx)
         rows = slice(row * 16, min(H, row * 16 + 16))
         want = ob["out"][:, rows].astype(np.float64)
         got = out[1][:, rows].cpu().numpy().astype(np.float64)
-        err = np.abs(got - want)
+        tr = truth[:, rows]
         pix_inf = np.abs(want).max(0, keepdims=True)                           # ||pixel||_inf over the channels
-        rel_pix = err / np.maximum(pix_inf, 1e-30)
+        err = np.abs(got - want)
         rel_elem = err / np.maximum(np.abs(want), 1e-3 * pix_inf + 1e-30)      # element-wise, floored at 1e-3 of the pixel
-        worst_pix = max(worst_pix, float(rel_pix.max()))
+        worst_pix = max(worst_pix, float((err / np.maximum(pix_inf, 1e-30)).max()))
         worst_elem = max(worst_elem, float(rel_elem.max()))
-        q999 = max(q999, float(np.quantile(rel_elem, 0.999)))
-        q50 = max(q50, float(np.quantile(rel_elem, 0.5)))
         frac = max(frac, float((rel_elem > 1e-4).mean()))
-    print(f"\\ncfg3 default arithmetic vs oracle, 4 tile rows x 512 channels: max |err| / ||pixel||_inf = {worst_pix:.2e}; "
-          f"element-wise |err| / max(|oracle|, 1e-3 ||pixel||_inf): median {q50:.2e}, 99.9 % quantile {q999:.2e}, "
-          f"max {worst_elem:.2e}, fraction above 1e-4: {frac:.2e}")
-    assert worst_pix <= 1e-4         # every element within 1e-4 of its pixel's largest channel
-    assert worst_elem <= 5e-2        # near-zero elements (cancellation): bounded by the split's absolute error
+        for d, x in ((hip_t, got), (orc_t, want)):
+            re = np.abs(x - tr) / np.maximum(np.abs(tr), 1e-3 * pix_inf + 1e-30)
+            d["max"] = max(d["max"], float(re.max()))
+            d["frac"] = max(d["frac"], float((re > 1e-4).mean()))
+            d["rms"] = max(d["rms"], float(np.sqrt((re ** 2).mean())))
+    print(f"\ncfg3 default arithmetic, 4 tile rows x 512 channels.  vs oracle: max |err| / ||pixel||_inf = {worst_pix:.2e}, "
+          f"element-wise max {worst_elem:.2e}, fraction above 1e-4: {frac:.2e}.  vs the exact composite (element-wise): "
+          f"HIP max {hip_t['max']:.2e} rms {hip_t['rms']:.2e} frac>1e-4 {hip_t['frac']:.2e} | "
+          f"oracle fp32 chain max {orc_t['max']:.2e} rms {orc_t['rms']:.2e} frac>1e-4 {orc_t['frac']:.2e}")
+    assert worst_pix <= 5e-6          # every element within 5e-6 of its pixel's largest channel (round 2's split: 2.4e-5)
+    assert worst_elem <= 1e-3 and frac <= 1e-5
+    # as accurate as the reference's own arithmetic
+    assert hip_t["max"] <= 1.5 * orc_t["max"] + 1e-6
+    assert hip_t["rms"] <= 1.25 * orc_t["rms"] + 1e-9
+    assert hip_t["frac"] <= 1.5 * orc_t["frac"] + 1e-6

@@ -113,8 +113,9 @@ def test_cfg3_feature_map_properties(cfg3, orc):
         ones = _render(s, c, C, W, H, feats=torch.ones_like(s.features), bg=torch.zeros(C, device=DEV))[1]
     finally:
         raster.set_blend_exact(False)
-    # default arithmetic within 5e-5 of the absolute composite of the exact one (north star: 1e-4)
-    assert bool(((out - exact).abs() <= 5e-5 * absc + 1e-30).all())
+    # default (six-product) arithmetic within 4e-6 of the absolute composite of the exact fp32 chain -- the chain's own
+    # rounding; round 2's two-term split needed 5e-5 (north star: 1e-4)
+    assert bool(((out - exact).abs() <= 4e-6 * absc + 1e-30).all())
     # partition of unity: with all features 1 and bg 0 every channel is sum_k w_k = 1 - T_final
     assert float((ones - (1.0 - T)[None]).abs().max()) < 2e-5
     assert torch.equal(ones[0], ones[C - 1])

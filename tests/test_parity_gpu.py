@@ -3,6 +3,8 @@ the same seeded inputs.  Bar (north star): bit-exact on every integer output (ra
 touched, offsets, 64-bit sort keys, sorted Gaussian lists, tile ranges, n_contrib) and
 <= 1e-4 relative on the fp32 feature map -- the arithmetic contract in fact makes the floats
 bit-identical as well, which is what these tests assert first."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,11 +38,13 @@ def _hip_forward(scene, cam, C=None, want_depth=False, colors=None, variant=0, d
     return out
 
 
-def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0, exact=None, **kw):
+def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0, exact=None, two_term=None, **kw):
     from sgs_hip import raster
     if exact is None:   # the C >= 128 default (0) and variants 12-14 accumulate in split bf16; all else is bit-exact
         Cn = 3 if kw.get("shs") is not None else (scene.features.shape[1] if kw.get("colors") is None else kw["colors"].shape[1])
-        bf16 = variant in (0, 14) or (variant >= 16 and (variant & 15) == 8)
+        # C >= 128: 0 (default) = six bf16 products of exact three-term splits ("f32-equivalent"), 14 / nibble 8 = round 2's
+        # two-term split; both differ from the oracle's bits, everything else is bit-exact
+        bf16 = variant in (0, 14) or (variant >= 16 and (variant & 15) in (8, 10, 12, 13, 14))
         exact = not (bf16 and Cn >= 128 and not want_depth)
     fw = oracle_forward(orc, scene, cam, want_depth=want_depth, **kw)
     raster.set_binning_mode(binning_mode)
@@ -86,7 +90,11 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0,
         # 2.1e-5, mean 1.6e-6.  5e-5 is 2x inside the north star's 1e-4.
         sa = scene._replace(features=scene.features.abs(), bg=scene.bg.abs())
         fa = oracle_forward(orc, sa, cam, **kw)["out"]
-        assert (np.abs(out - fw["out"]) <= 5e-5 * fa + 1e-30).all()
+        if two_term is None:
+            two_term = variant == 14 or (variant >= 16 and (variant & 15) == 8)
+        # six products: the difference to the oracle is the ORACLE's own fp32 rounding (tests/test_sweep2_gpu.py compares both
+        # with the exact composite); two-term split: 3 * 2^-16 per term
+        assert (np.abs(out - fw["out"]) <= (5e-5 if two_term else 4e-6) * fa + 1e-30).all()
         assert not np.array_equal(out, fw["out"]) or fa.max() == 0
     if want_depth:
         assert np.array_equal(depth.cpu().numpy().view(np.uint32), fw["depth"].view(np.uint32))
@@ -109,7 +117,7 @@ def test_forward_c128_all_variants(orc, variant):
     assert fw["n_contrib"].max() > 20 and (fw["final_T"] < 1e-3).any()   # early stop exercised
 
 
-@pytest.mark.parametrize("variant", [0, 8 + 16 * 1])
+@pytest.mark.parametrize("variant", [0, 14, 8 + 16 * 1, 14 + 16 * 1])
 @pytest.mark.parametrize("C,W,H", [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64)])
 def test_forward_split_bf16_within_tolerance(orc, variant, C, W, H):
     """Split-bf16 row-sweep accumulate (default, and with forced 8-tile segments): integer state
@@ -565,13 +573,15 @@ def test_backward_worklist_feedback_is_per_stream(orc):
 @pytest.mark.parametrize("variant", [33, 35, 32, 34])
 @pytest.mark.parametrize("C,W,H,P", [(128, 208, 160, 2500), (256, 200, 120, 2500), (512, 192, 100, 2500), (384, 100, 70, 2000)])
 def test_fused_single_kernel_variants(orc, variant, C, W, H, P):
+    if os.environ.get("SGS_WITH_FUSED", "0") != "1":
+        pytest.skip("the fused single-kernel experiments are built only with `make FUSED=1` (set SGS_WITH_FUSED=1 to test them)")
     """The experimental single-kernel forward blends (blend_fused.hip: every wave autonomous, variants 32 / 33;
     blend_fused_pc.hip: one producer wave + C / 64 consumer waves per workgroup, 34 / 35).  Not the default -- both are
     slower than the two-kernel path (DESIGN.md 5.6) -- but they are complete renderers and must stay exact: the
     odd variants use fp32 MFMA and return the oracle's bits, the even ones the split-bf16 products."""
     scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=90.0, seed=C)
     scene = scene._replace(bg=torch.linspace(-1.0, 1.0, C))
-    _check_forward(orc, scene, cam, variant=variant, exact=bool(variant & 1))
+    _check_forward(orc, scene, cam, variant=variant, exact=bool(variant & 1), two_term=True)
 
 
 @pytest.mark.parametrize("C,W,H", [(128, 205, 70), (256, 100, 52), (160, 49, 40), (128, 208, 64)])

@@ -50,6 +50,91 @@ __global__ __launch_bounds__(64) void victim_kernel(const u32x4* __restrict__ sr
 	if (nbad) atomicAdd(&bad[0], nbad);
 }
 
+// A victim with no memory traffic inside its loop: the same 8-register mixing chain evaluated twice in disjoint registers
+// (same operations, the second copy one instruction behind), compared at the end.  A VGPR write that is lost or damaged
+// for some lanes -- by whatever shares the SIMD -- makes the two copies disagree.
+__global__ __launch_bounds__(64) void victim_valu_kernel(int iters, uint32_t salt, uint32_t* bad)
+{
+	const uint32_t t = blockIdx.x * 64u + threadIdx.x + salt * 977u;
+	float a[8], b[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) { a[i] = (float)((t * (2 * i + 3)) & 1023u) * 0.001f + 0.5f; b[i] = a[i]; }
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			a[i] = __builtin_fmaf(a[i], 0.999f, a[(i + 3) & 7] * 0.0007f);
+			asm volatile("" : "+v"(a[i]));
+			b[i] = __builtin_fmaf(b[i], 0.999f, b[(i + 3) & 7] * 0.0007f);
+			asm volatile("" : "+v"(b[i]));
+		}
+	}
+	uint32_t nbad = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++) nbad += (__float_as_uint(a[i]) != __float_as_uint(b[i])) ? 1u : 0u;
+	if (nbad) {
+		atomicAdd(&bad[2], nbad);
+		const uint32_t slot = atomicAdd(&bad[3], 1u);
+		if (slot < 8) { bad[80 + 4 * slot] = threadIdx.x; bad[81 + 4 * slot] = __float_as_uint(a[0]); bad[82 + 4 * slot] = __float_as_uint(b[0]); bad[83 + 4 * slot] = blockIdx.x; }
+	}
+}
+
+// The same with transcendental instructions (v_sqrt_f32 / v_rcp_f32 / v_exp_f32 run on the quarter-rate unit, 16 lanes
+// per pass): the library's victim (its per-Gaussian preprocess) came out with radii that fit a wrong square root in one
+// 16-lane row.
+__global__ __launch_bounds__(64) void victim_trans_kernel(int iters, uint32_t salt, uint32_t* bad)
+{
+	const uint32_t t = blockIdx.x * 64u + threadIdx.x + salt * 977u;
+	float a[4], b[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) { a[i] = (float)((t * (2 * i + 3)) & 1023u) * 0.001f + 0.5f; b[i] = a[i]; }
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			a[i] = __builtin_sqrtf(__builtin_fmaf(a[i], a[(i + 1) & 3], 0.37f)) + __builtin_amdgcn_rcpf(a[(i + 2) & 3] + 1.5f) + __builtin_amdgcn_exp2f(-a[(i + 3) & 3]) * 0.25f;
+			asm volatile("" : "+v"(a[i]));
+			b[i] = __builtin_sqrtf(__builtin_fmaf(b[i], b[(i + 1) & 3], 0.37f)) + __builtin_amdgcn_rcpf(b[(i + 2) & 3] + 1.5f) + __builtin_amdgcn_exp2f(-b[(i + 3) & 3]) * 0.25f;
+			asm volatile("" : "+v"(b[i]));
+		}
+	}
+	uint32_t nbad = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) nbad += (__float_as_uint(a[i]) != __float_as_uint(b[i])) ? 1u : 0u;
+	if (nbad) {
+		atomicAdd(&bad[112], nbad);
+		const uint32_t slot = atomicAdd(&bad[113], 1u);
+		if (slot < 3) { bad[116 + 4 * slot] = threadIdx.x; bad[117 + 4 * slot] = __float_as_uint(a[0]); bad[118 + 4 * slot] = __float_as_uint(b[0]); bad[119 + 4 * slot] = blockIdx.x; }
+	}
+}
+
+// The same with PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): the library's damaged quantity
+// (the first component of the 3-D covariance) is the low half of a packed add in the victim kernel's code.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64) void victim_pk_kernel(int iters, uint32_t salt, uint32_t* bad)
+{
+	const uint32_t t = blockIdx.x * 64u + threadIdx.x + salt * 977u;
+	f32x2 a[4], b[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) { a[i] = f32x2{(float)((t * (2 * i + 3)) & 1023u) * 0.001f + 0.5f, (float)((t * (2 * i + 5)) & 511u) * 0.002f + 0.25f}; b[i] = a[i]; }
+	const f32x2 k0 = {0.999f, 0.998f}, k1 = {0.0007f, 0.0011f};
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			a[i] = __builtin_elementwise_fma(a[i], k0, a[(i + 1) & 3] * k1) + a[(i + 2) & 3].yx * k1;
+			asm volatile("" : "+v"(a[i]));
+			b[i] = __builtin_elementwise_fma(b[i], k0, b[(i + 1) & 3] * k1) + b[(i + 2) & 3].yx * k1;
+			asm volatile("" : "+v"(b[i]));
+		}
+	}
+	uint32_t nbad = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) nbad += (__float_as_uint(a[i].x) != __float_as_uint(b[i].x) ? 1u : 0u) + (__float_as_uint(a[i].y) != __float_as_uint(b[i].y) ? 1u : 0u);
+	if (nbad) {
+		atomicAdd(&bad[96], nbad);
+		const uint32_t slot = atomicAdd(&bad[97], 1u);
+		if (slot < 3) { bad[100 + 4 * slot] = threadIdx.x; bad[101 + 4 * slot] = __float_as_uint(a[0].x); bad[102 + 4 * slot] = __float_as_uint(b[0].x); bad[103 + 4 * slot] = blockIdx.x; }
+	}
+}
+
 // MODE bits: 1 = LDS-DMA ring, 2 = x16 MFMA (else x8 pairs if bit 2), 4 = x8 MFMA, 8 = nt stores, 16 = claim all 256 registers
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void aggressor_kernel(const float* __restrict__ src, size_t nfloat, float* __restrict__ sink, int iters)
@@ -81,7 +166,32 @@ __global__ __launch_bounds__(256, 2) void aggressor_kernel(const float* __restri
 		u32x4 a, b0, b1;
 		asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
 			     : "=&v"(a), "=&v"(b0), "=&v"(b1) : "v"(rd) : "memory");
-		if (MODE & 2) {
+		if (MODE & 32) {   // the shipped six-product stream: 24 back-to-back x16 MFMAs on two accumulator blocks in a[0:31]
+			asm volatile(
+				"s_nop 1\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %0, %2, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %1, %2, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %1, %0, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %2, %0, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %2, %1, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %0, %2, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %1, %2, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %1, %0, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %2, %0, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %2, %1, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %0, %2, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %1, %2, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %1, %0, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %2, %0, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %2, %1, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %0, %2, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %1, %2, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %1, %0, a[16:31]\n\t"
+				"v_mfma_f32_32x32x16_bf16 a[0:15], %2, %0, a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %2, %1, a[16:31]"
+				: : "v"(a), "v"(b0), "v"(b1) : "a127", "memory");
+		} else if (MODE & 64) {   // the same stream on the legacy x8 instruction (48 MFMAs, same duration)
+			const uint64_t a0 = ((uint64_t)a.y << 32) | a.x, c0 = ((uint64_t)b0.y << 32) | b0.x, d0 = ((uint64_t)b1.y << 32) | b1.x;
+#pragma unroll
+			for (int r = 0; r < 8; r++)
+				asm volatile(
+					"v_mfma_f32_32x32x8_bf16 a[0:15], %0, %1, a[0:15]\n\tv_mfma_f32_32x32x8_bf16 a[16:31], %0, %2, a[16:31]\n\t"
+					"v_mfma_f32_32x32x8_bf16 a[0:15], %1, %2, a[0:15]\n\tv_mfma_f32_32x32x8_bf16 a[16:31], %1, %0, a[16:31]\n\t"
+					"v_mfma_f32_32x32x8_bf16 a[0:15], %2, %0, a[0:15]\n\tv_mfma_f32_32x32x8_bf16 a[16:31], %2, %1, a[16:31]"
+					: : "v"(a0), "v"(c0), "v"(d0) : "a127", "memory");
+		} else if (MODE & 2) {
 #pragma unroll
 			for (int b = 0; b < 8; b++) {
 				acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b0), acc[b], 0, 0, 0);
@@ -144,8 +254,11 @@ int main(int argc, char** argv)
 		{"x16 MFMA only (no DMA, no stores)", 2},
 		{"ring only", 1},
 		{"ring + x16 MFMA + stores, all 256 registers claimed", 1 | 2 | 8 | 16},
+		{"24 dense x16 MFMAs per step on AGPRs, no memory at all", 32},
+		{"ring + 24 dense x16 MFMAs per step on AGPRs", 1 | 32},
+		{"ring + 48 dense x8 MFMAs per step on AGPRs", 1 | 64},
 	};
-	printf("%-56s %10s %12s %14s\n", "aggressor", "victims", "aggr launches", "corrupt words");
+	printf("%-56s %10s %12s %s\n", "aggressor", "victims", "aggr launches", "corrupt words (load victim / valu victim)");
 	for (const Config& c : cfgs) {
 		CK(hipMemset(bad, 0, 4096));
 		const auto t0 = std::chrono::steady_clock::now();
@@ -160,20 +273,32 @@ int main(int argc, char** argv)
 				case 2: launch_aggr<2>(sa, asrc, NW, sink, 2000); break;
 				case 1: launch_aggr<1>(sa, asrc, NW, sink, 2000); break;
 				case 1 | 2 | 8 | 16: launch_aggr<1 | 2 | 8 | 16>(sa, asrc, NW, sink, 2000); break;
+				case 32: launch_aggr<32>(sa, asrc, NW, sink, 2000); break;
+				case 1 | 32: launch_aggr<1 | 32>(sa, asrc, NW, sink, 2000); break;
+				case 1 | 64: launch_aggr<1 | 64>(sa, asrc, NW, sink, 2000); break;
 				}
 				na++;
 			}
 			for (int k = 0; k < 8; k++) {
 				hipLaunchKernelGGL(victim_kernel, dim3(16384), dim3(64), 0, sv, (const u32x4*)vsrc, (uint32_t)(NW / 4), 64, salt++, bad);
+				hipLaunchKernelGGL(victim_valu_kernel, dim3(16384), dim3(64), 0, sv, 256, salt++, bad);
+				hipLaunchKernelGGL(victim_trans_kernel, dim3(16384), dim3(64), 0, sv, 96, salt++, bad);
+				hipLaunchKernelGGL(victim_pk_kernel, dim3(16384), dim3(64), 0, sv, 256, salt++, bad);
 				nv++;
 			}
 			CK(hipStreamSynchronize(sv));
 			if ((na & 7) == 0) CK(hipStreamSynchronize(sa));
 		}
 		CK(hipDeviceSynchronize());
-		uint32_t h[72];
+		uint32_t h[128];
 		CK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
-		printf("%-56s %10ld %12ld %14u\n", c.name, nv, na, h[0]);
+		printf("%-56s %10ld %12ld %8u loads %8u valu %8u trans %8u packed\n", c.name, nv, na, h[0], h[2], h[112], h[96]);
+		for (uint32_t i = 0; i < h[97] && i < 3; i++)
+			printf("      packed chain: lane %u block %u a0 %08x b0 %08x\n", h[100 + 4 * i], h[103 + 4 * i], h[101 + 4 * i], h[102 + 4 * i]);
+		for (uint32_t i = 0; i < h[113] && i < 3; i++)
+			printf("      trans chain: lane %u block %u a0 %08x b0 %08x\n", h[116 + 4 * i], h[119 + 4 * i], h[117 + 4 * i], h[118 + 4 * i]);
+		for (uint32_t i = 0; i < h[3] && i < 4; i++)
+			printf("      valu chain: lane %u block %u a0 %08x b0 %08x\n", h[80 + 4 * i], h[83 + 4 * i], h[81 + 4 * i], h[82 + 4 * i]);
 		for (uint32_t i = 0; i < h[1] && i < 6; i++)
 			printf("      word %u: got %08x want %08x (iter %u, block %u)\n", h[4 + 4 * i] * 4, h[5 + 4 * i], h[6 + 4 * i], h[7 + 4 * i] & 4095u, h[7 + 4 * i] >> 12);
 		fflush(stdout);

@@ -28,7 +28,7 @@ def render(c, slot):
     out = raster.rasterize_forward(s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e,
                                    c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy,
                                    128, 208, e, 0, c.camera_center, False, False, 128, False, pool=pool)
-    return out[0], out[2].clone()
+    return out[0], out[2].clone(), out[3].clone()
 
 
 def run(name, variant, rounds):
@@ -38,8 +38,21 @@ def run(name, variant, rounds):
     bad = 0
     for _ in range(rounds):
         piped = sdist.render_views_pipelined(render, cams, in_flight=4)
-        for a, b in zip(serial, piped):
-            bad += int(a[0] != b[0] or not torch.equal(a[1], b[1]))
+        for vi, (a, b) in enumerate(zip(serial, piped)):
+            wrong = a[0] != b[0] or not torch.equal(a[1], b[1])
+            bad += int(wrong)
+            if wrong and bad <= 6:   # what does the damage look like?  (indices, values as int32 and as float bits)
+                d = torch.nonzero(a[1] != b[1]).flatten()
+                got = b[1][d].cpu()
+                ga, gb = raster.geometry_views(a[2], 5000), raster.geometry_views(b[2], 5000)
+                for k in ("depths", "means2D", "cov3D", "conic_opacity", "tiles_touched"):
+                    va, vb = ga[k].reshape(5000, -1), gb[k].reshape(5000, -1)
+                    dd = torch.nonzero((va != vb).any(dim=1)).flatten()
+                    if dd.numel():
+                        i0 = int(dd[0])
+                        print(f"      {k}: {dd.numel()} rows differ, first {i0}: want {va[i0].tolist()} got {vb[i0].tolist()}", flush=True)
+                print(f"  [{name}] view {vi}: num_rendered {a[0]} vs {b[0]}; {d.numel()} radii differ at {d[:24].tolist()}"
+                      f" want {a[1][d][:8].tolist()} got {got[:8].tolist()} as f32 {got[:8].view(torch.float32).tolist()}", flush=True)
     raster.set_blend_variant(0)
     print(f"{name}: {bad} corrupted forwards of {rounds * 6}", flush=True)
     return bad
