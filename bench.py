@@ -7,23 +7,30 @@ Metric (BASELINE.json): Gpixel*channels/s of the FORWARD feature render,
     inputs already resident in HBM, called through the C-ABI.
 
 What one JSON line carries (rank 0):
-  value / ms_per_step   the contract's number: K timed steps between barriers, a step = `--views` (default 4)
-                        views of the scene in flight on as many HIP streams; DEFAULT arithmetic of the C >= 128
-                        blend, which is split-bf16 x3 MFMA products with fp32 accumulation -- `dtype` says so.
-                        The forwards of a step are deferred-count ones (SGS_OPT_DEFER_COUNT: no blocking
-                        num_rendered read-back inside the call; counts checked per step, every num_rendered compared
-                        with the serial render); --blocking-count times the reference's host pattern instead;
-  single_view           one view in flight (SURVEY.md 8(d)'s t_fwd: device time of one forward, hipEvents, median
-                        of >= 20): value, ms_median, ms_mean -- for the default AND the exact fp32 arithmetic;
-  single_view_deferred_count   the same forward without the num_rendered read-back;
-  exact_f32             the bit-exact fp32-MFMA arithmetic (SGS_BLEND_EXACT=1) timed like the headline;
-  backward              cfg3 is "forward+backward": forward+backward device ms of the same scene (N = 1 only);
+  value / ms_per_step   the contract's number: K timed steps between barriers, a step = `--views` (default 4) views of
+                        the scene in flight on as many HIP streams, every forward with the reference's blocking
+                        num_rendered read-back (rasterizer_impl.cu:283) and a different camera every step; DEFAULT
+                        arithmetic of the C >= 128 blend: "f32-equivalent" -- features and weights split exactly into
+                        three bf16 terms, six MFMA products, fp32 accumulate (as accurate as the reference's fp32 chain
+                        against the exact composite: tests/test_configs_gpu.py) -- `dtype` says so.  The default K keeps
+                        >= 2 s of continuous GPU work in the timed region;
+  api_path              what a user of the reference gets: channel_rasterization.GaussianRasterizer called exactly as
+                        model/renderer.py:169-185,228 does (nn.Parameter inputs, torch.no_grad(), debug=True, one view,
+                        blocking count), device ms per forward (hipEvents, median);
+  single_view           one view in flight through the internal entry point (SURVEY.md 8(d)'s t_fwd): value, ms_median;
+  deferred_count        the inference-only mode without the host read-back (SGS_OPT_DEFER_COUNT), V views in flight,
+                        with the number of frames that had to be rendered twice;
+  exact_f32             the bit-exact fp32-MFMA arithmetic (SGS_BLEND_EXACT=1 / variant 15);
+  two_term              round 2's default arithmetic (variant 14: two bf16 terms, three products, 3 * 2^-16 per term --
+                        NOT fp32-class; kept selectable), for continuity with BENCH_r02;
+  backward              cfg3 is "forward+backward": forward+backward device ms of the same scene, the backward alone
+                        and its algorithmic-bytes fraction of the HBM roofline (N = 1 only);
   roofline              the forward blend against the HBM roofline: achieved = SURVEY 8(d)'s algorithmic bytes of
                         the blend / its kernels' live hipEvent durations (one view in flight); plus the secondary
                         ceilings (fp32 FMA, bf16 MFMA) the same work is priced against;
-  cpu_baseline          kind "pytorch": the pure-PyTorch CPU splat the north star names (oracle/torch_splat.py,
-                        torch.set_num_threads(os.cpu_count())): cfg1 in full, cfg3 on a tile sample extrapolated
-                        by the tiles' list work; cpu_baseline_port: the C/OpenMP oracle, as round 1 reported.
+  cpu_baseline          kind "pytorch": the pure-PyTorch CPU splat the north star names (oracle/torch_splat.py): cfg1 in
+                        full, cfg3 on a tile sample extrapolated by the tiles' list work; cpu_baseline_port: the
+                        C/OpenMP oracle.
 
 --gpus N: one process per GPU.  Under torch.distributed.run the ranks are given; a plain `python bench.py --gpus N`
 spawns its own N ranks (127.0.0.1 rendezvous).  Views shard across ranks with no data-path collective (scene
@@ -58,6 +65,8 @@ FP32_FMA_PEAK = 157.3e12  # fp32 vector (= fp32-input MFMA) peak, same table
 BF16_MFMA_PEAK = 2.5e15   # dense bf16 MFMA peak
 STAGES = ["preprocess", "scan_readback", "duplicate", "sort", "ranges", "blend_weights", "blend_accum"]
 EXACT = 15               # blend variant: fp32-input MFMA accumulate, bit-identical to the contract
+TWO_TERM = 14            # blend variant: round 2's two-term split (three products)
+NCAM = 8                 # cameras each view slot cycles through (a different view every step)
 
 
 def log(*a):
@@ -188,8 +197,8 @@ def cpu_baseline_pytorch(scene, cam, C, W, H, n_eff, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--points", type=int, default=None, help="override P (debug)")
     ap.add_argument("--channels", type=int, default=None, help="override C (debug)")
@@ -197,12 +206,17 @@ def main():
     ap.add_argument("--views", type=int, default=4,
                     help="views in flight per GPU: a step renders this many views of the scene, one per HIP "
                          "stream, so one view's front-end and host round trip overlap another view's blend")
-    ap.add_argument("--blocking-count", action="store_true",
-                    help="headline with the reference's blocking num_rendered read-back in every forward "
-                         "(default: deferred counts, SGS_OPT_DEFER_COUNT)")
+    ap.add_argument("--deferred-count", action="store_true",
+                    help="headline with deferred counts (SGS_OPT_DEFER_COUNT, inference only) instead of the reference's "
+                         "blocking num_rendered read-back in every forward")
+    ap.add_argument("--fixed-camera", action="store_true",
+                    help="every step renders the same camera per slot (profiling runs: per-kernel averages of ONE view)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-arithmetic / backward legs")
     args = ap.parse_args()
+    global NCAM
+    if args.fixed_camera:
+        NCAM = 1
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args.gpus)
@@ -224,7 +238,7 @@ def main():
         dist.all_gather_object(names, f"rank{rank}:cuda{local_rank}:{torch.cuda.get_device_name(dev)}")
         rccl = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "devices": names}
 
-    from sgs_hip import raster
+    from sgs_hip import raster, _lib
     from sgs_hip.synthetic import CONFIGS, make_scene
 
     P0, C0, W, H, fx = CONFIGS[args.config]
@@ -233,33 +247,34 @@ def main():
     t0 = time.time()
     scene = make_scene(P, C, W, H, fx, seed=0)
     V = max(1, args.views)
-    cams_host = [view_camera(rank * V + i, W, H, fx) for i in range(V)]
-    cam = cams_host[0]
+    # slot i of rank r cycles through NCAM cameras: camera (slot, k) is view number (r * V + i) * NCAM + k
+    cams_host = [[view_camera((rank * V + i) * NCAM + k, W, H, fx) for k in range(NCAM)] for i in range(V)]
+    cam = cams_host[0][0]
     log(f"[rank {rank}] scene P={P} C={C} {W}x{H} generated in {time.time() - t0:.1f}s")
     s = scene.to(dev)
-    cams = [cm.to(dev) for cm in cams_host]
+    cams = [[cm.to(dev) for cm in row] for row in cams_host]
     empty = torch.Tensor([])
 
     # inference: state buffers stay resident (as under torch.no_grad); one pool and stream per view in flight
     pools = [raster.ScratchPool() for _ in range(V)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(V - 1)]
 
-    def render(i, deferred=False):
-        c = cams[i]
+    def render(i, deferred=False, k=0):
+        c = cams[i][k % NCAM]
         fn = raster.rasterize_forward_deferred if deferred else raster.rasterize_forward
         with torch.cuda.stream(streams[i]):
             return fn(s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, empty,
                       c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, empty, 0,
                       c.camera_center, False, False, C, False, pool=pools[i])
 
-    DEFER = not args.blocking_count
+    DEFER = args.deferred_count
 
-    def step():   # one batch: V views of the scene, all in flight together
-        if not DEFER:   # the reference's host pattern: every forward blocks on its num_rendered read-back
-            return [render(i) for i in range(V)]
+    def step(k=0, defer=None):   # one batch: V views of the scene (camera k of every slot), all in flight together
+        if not (DEFER if defer is None else defer):   # the reference's host pattern: every forward blocks on its num_rendered read-back
+            return [render(i, False, k) for i in range(V)]
         # deferred counts (SGS_OPT_DEFER_COUNT): all V forwards are enqueued without the host waiting for the GPU,
         # then every frame's counts are checked (a frame that outgrew its capacity guess is rendered again there)
-        pending = [render(i, True) for i in range(V)]
+        pending = [render(i, True, k) for i in range(V)]
         return [h.result() for h in pending]
 
     def barrier():
@@ -293,55 +308,112 @@ def main():
                     ms_mean=sum(ms) / len(ms), ms_min=ms[0], forwards=n,
                     stage_ms=dict(zip(STAGES, [round(v, 4) for v in stage]))), stage
 
-    def in_flight(variant, steps, warmup, stage_timing=False):
+    def deferred_retries():
+        n = 0
+        for st in streams:
+            with torch.cuda.stream(st):
+                n += raster.stream_stat(_lib.STAT_DEFERRED_RETRIES, dev)
+        return n
+
+    def in_flight(variant, steps, warmup, stage_timing=False, defer=None):
         raster.set_blend_variant(variant)
         out = None
-        for _ in range(warmup):
-            out = step()   # bound like the timed loop: step n's outputs live while step n + 1 allocates, so the
+        for k in range(warmup):
+            out = step(k, defer)   # bound like the timed loop: step n's outputs live while step n + 1 allocates, so the
             #                caching allocator reaches its steady-state footprint here, not in the timed region
             #                (a 10 GB hipMalloc in timed step 2 was a 240 ms stall, profiles/r02h_bench_default.json)
         if stage_timing:   # deferred per-stage hipEvents for the timed steps only (no extra synchronisation)
             raster.get_stage_ms()
             raster.set_stage_timing(2)
+        retries0 = deferred_retries()
         gc.collect()
         gc.disable()   # a generation-2 collection of the interpreter's heap is a 50 ms host pause (measured)
         barrier()
         t0 = time.perf_counter()
         marks, mism = [], 0
-        for _ in range(steps):
-            out = step()
-            mism += sum(int(o[0] != n) for o, n in zip(out, ref_n))   # host ints, no device work
+        for k in range(steps):
+            out = step(k, defer)
+            mism += sum(int(o[0] != ref_n[i][k % NCAM]) for i, o in enumerate(out))   # host ints, no device work
             marks.append(time.perf_counter())
         barrier()
         t = time.perf_counter() - t0
         gc.enable()
+        retries = deferred_retries() - retries0
         if world > 1:
             tt = torch.tensor([t], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         per = [b - a for a, b in zip([t0] + marks[:-1], marks)]
-        if rank == 0:   # host-side enqueue cadence (diagnostic only; the metric uses t / steps)
-            log(f"variant {variant}: per-step host ms: " + " ".join(f"{x * 1e3:.2f}" for x in per))
         per.sort()
-        return t / steps * 1e3, per[len(per) // 2] * 1e3, mism, out
+        if rank == 0:   # host-side enqueue cadence (diagnostic only; the metric uses t / steps)
+            log(f"variant {variant}: per-step host ms min/median/max: {per[0] * 1e3:.2f} / {per[len(per) // 2] * 1e3:.2f} / {per[-1] * 1e3:.2f}")
+        return t / steps * 1e3, per[len(per) // 2] * 1e3, mism, out, retries
 
     # ---- one view in flight (SURVEY 8(d)'s t_fwd), default arithmetic; its stage times feed the roofline
     sv_default, stage_ms = single_view(args.variant)
-    sv_deferred, _ = single_view(args.variant, deferred=True)
-    # integrity reference: every view's num_rendered, rendered alone (concurrent forwards must reproduce it)
+    # integrity reference: every (slot, camera)'s num_rendered, rendered alone (concurrent forwards must reproduce it)
     ref_n = []
     for i in range(V):
-        ref_n.append(render(i)[0])
-        torch.cuda.synchronize(dev)
+        row = []
+        for k in range(NCAM):
+            row.append(render(i, False, k)[0])
+            torch.cuda.synchronize(dev)
+        ref_n.append(row)
+
+    # ---- what a user of the reference gets: the drop-in module, called as model/renderer.py:169-185,228 calls it
+    def api_path(n=24, debug=True):
+        import channel_rasterization as chn
+        c = cams[0][0]
+        prm = [torch.nn.Parameter(t) for t in (s.means3D, s.features, s.opacities, s.scales, s.rotations)]
+        settings = chn.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=s.bg, scale_modifier=1.0,
+            viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+            prefiltered=False, debug=debug, num_channels=C)
+        ras = chn.GaussianRasterizer(raster_settings=settings)
+        raster.set_blend_variant(args.variant)
+
+        def call():
+            screenspace = torch.zeros_like(prm[0], requires_grad=False)
+            return ras(means3D=prm[0], means2D=screenspace, shs=None, colors_precomp=prm[1], opacities=prm[2],
+                       scales=prm[3], rotations=prm[4], cov3D_precomp=None)
+        with torch.no_grad():
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize(dev)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for a, b in evs:
+                a.record()
+                out_ = call()
+                b.record()
+            torch.cuda.synchronize(dev)
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        med = ms[len(ms) // 2]
+        return dict(value=H * W * C / (med * 1e-3) / 1e9, unit="Gpixel*channels/s", ms_median=med, ms_min=ms[0], forwards=n,
+                    call="channel_rasterization.GaussianRasterizer(settings)(means3D, means2D, opacities, colors_precomp, scales, "
+                         "rotations) under torch.no_grad(), nn.Parameter inputs, debug=True (model/renderer.py:169-185,228), "
+                         "one view, blocking num_rendered read-back, output + radii allocated per call",
+                    out_shape=list(out_[0].shape))
+    api = api_path() if world == 1 or rank == 0 else None
+    if api is not None:
+        api["ratio_to_single_view"] = api["ms_median"] / sv_default["ms_median"]
+        api["ms_median_with_debug_false"] = api_path(debug=False)["ms_median"]
+        api["note"] = ("the events bracket the Python call: the span includes the host's own work before the first launch and "
+                       "after the last (module call, autograd Function, ctypes marshalling, with debug=True one end-of-call "
+                       "synchronisation) during which the GPU idles; single_view brackets the internal entry point")
 
     # ---- the headline: K timed steps, V views in flight, default arithmetic
-    ms_per_step, ms_step_median, mismatches, out = in_flight(args.variant, args.steps, max(2, args.warmup), True)
+    ms_per_step, ms_step_median, mismatches, out, retries = in_flight(args.variant, args.steps, max(2, args.warmup), True)
     raster.set_stage_timing(0)
     stage_ms_timed = raster.get_stage_ms()   # per-stream event spacing inside the timed region (queueing included)
     if rank == 0:
         log(f"torch reserved {torch.cuda.memory_reserved(dev) / 1e9:.2f} GB")
 
-    # ---- workload statistics of this rank's view (every run prints them: bytes depend on them)
+    # ---- workload statistics of this rank's first view (slot 0, camera 0: the view single_view / the roofline time;
+    # every run prints them: bytes depend on them)
+    del out
+    raster.set_blend_variant(args.variant)
+    out = [render(0, False, 0)]
+    torch.cuda.synchronize(dev)
     num_rendered, color, radii, geom, binn, img, _ = out[0]
     iv = raster.image_views(img, W, H)
     gx, gy = (W + 15) // 16, (H + 15) // 16
@@ -362,47 +434,67 @@ def main():
     achieved = bytes_blend / (blend_ms * 1e-3) if blend_ms > 0 else 0.0
     del out, color
 
-    # ---- the exact fp32 arithmetic, the backward (N = 1 extras; skipped under --no-extras)
-    exact = backward = None
-    if not args.no_extras:
-        sv_exact, stage_exact = single_view(EXACT)
-        k = max(4, min(args.steps, 10))
-        ms_e, ms_e_med, mism_e, out_e = in_flight(EXACT, k, 2)
+    # ---- other arithmetics / host patterns, the backward (N = 1 extras; skipped under --no-extras)
+    exact = backward = two_term = deferred = None
+    kx = max(8, min(args.steps, 60))
+
+    def extra_leg(variant, what, defer=None):
+        sv, stg = single_view(variant)
+        ms_e, ms_e_med, mism_e, out_e, retr = in_flight(variant, kx, 3, defer=defer)
         del out_e
-        exact = {"arithmetic": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate: bit-identical to the contract",
-                 "value": world * V * H * W * C / (ms_e * 1e-3) / 1e9, "unit": "Gpixel*channels/s",
-                 "ms_per_step": ms_e, "ms_per_view": ms_e / V, "steps": k, "views_in_flight": V,
-                 "num_rendered_mismatches_vs_serial": mism_e, "single_view": sv_exact,
-                 "roofline_frac": bytes_blend / ((stage_exact[5] + stage_exact[6]) * 1e-3) / HBM_PEAK}
+        return {"arithmetic": what, "value": world * V * H * W * C / (ms_e * 1e-3) / 1e9, "unit": "Gpixel*channels/s",
+                "ms_per_step": ms_e, "ms_per_view": ms_e / V, "steps": kx, "views_in_flight": V,
+                "num_rendered_mismatches_vs_serial": mism_e, "deferred_retries": retr, "single_view": sv,
+                "roofline_frac": bytes_blend / ((stg[5] + stg[6]) * 1e-3) / HBM_PEAK}
+    if not args.no_extras:
+        exact = extra_leg(EXACT, "fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate: bit-identical to the contract")
+        two_term = extra_leg(TWO_TERM, "round 2's default: two bf16 terms per operand, three MFMA products "
+                                       "(<= 3 * 2^-16 of sum |f| w per term): NOT fp32-class, kept selectable (blend variant 14)")
+        deferred = extra_leg(args.variant, "default arithmetic, deferred counts (SGS_OPT_DEFER_COUNT, inference only): no host "
+                                           "read-back inside the forward", defer=True)
         raster.set_blend_variant(args.variant)
     if not args.no_extras and world == 1:
         for p in pools:
             p.clear()
         torch.cuda.empty_cache()
-        c = cams[0]
+        c = cams[0][0]
         dL = torch.randn(C, H, W, device=dev)
+        ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
 
-        def fwd_bwd():
+        def fwd_bwd(marks=None):
             n, col, rad, g_, b_, i_, _ = raster.rasterize_forward(
                 s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, empty,
                 c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, empty, 0,
                 c.camera_center, False, False, C, False)
+            if marks is not None:
+                marks[1].record()
             raster.rasterize_backward(s.bg, s.means3D, rad, s.features, s.scales, s.rotations, 1.0, empty,
                                       c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, dL,
                                       empty, 0, c.camera_center, g_, n, b_, i_, False)
         for _ in range(2):
             fwd_bwd()
         torch.cuda.synchronize(dev)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
-        for a, b in evs:
-            a.record()
-            fwd_bwd()
-            b.record()
+        evs = [(ev(), ev(), ev()) for _ in range(8)]
+        for m in evs:
+            m[0].record()
+            fwd_bwd(m)
+            m[2].record()
         torch.cuda.synchronize(dev)
-        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        ms = sorted(m[0].elapsed_time(m[2]) for m in evs)
+        ms_b = sorted(m[1].elapsed_time(m[2]) for m in evs)
+        # algorithmic bytes of the backward: the gradient read once, the active feature rows read and their gradient
+        # rows written once each, the list data, final_T / n_contrib, the per-Gaussian geometry gradients
+        bytes_bwd = 4 * C * H * W + 2 * (4 * C) * sum_neff + 28 * sum_neff + 8 * H * W + 8 * tiles + (44 + 60) * p_vis
+        t_b = ms_b[len(ms_b) // 2]
         backward = {"workload": "cfg3 forward + backward (dL/dout random), C = 512: the reference's backward is "
                                 "compiled for 3 channels only",
                     "fwd_bwd_ms_median": ms[len(ms) // 2], "fwd_bwd_ms_min": ms[0],
+                    "backward_ms_median": t_b,
+                    "roofline": {"bound": "hbm", "algorithmic_bytes": bytes_bwd, "achieved": bytes_bwd / (t_b * 1e-3) / 1e9,
+                                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_bwd / (t_b * 1e-3) / HBM_PEAK,
+                                 "note": "4 C H W (dL/dpixel once) + 2 x 4 C sum n_t_eff (feature rows in, colour-gradient rows "
+                                         "out) + 28 sum n_t_eff + 8 H W + 104 P_vis; the kernels read the gradient once per 128 "
+                                         "entries of a tile and per product (DESIGN.md 5.5), which is the gap to close"},
                     "includes": "output / gradient allocation through the caching allocator (no resident pool: the "
                                 "state buffers belong to the autograd graph)"}
         del dL
@@ -424,7 +516,8 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:   # noqa: BLE001
                 traffic = None
-        split = C >= 128 and args.variant != EXACT
+        split = C >= 128 and args.variant not in (EXACT,)
+        arith = {0: "f32-equivalent (3-term bf16 splits, 6 MFMA products, f32 accumulate)", TWO_TERM: "bf16x3-split products, f32 accumulate"}.get(args.variant, f"blend variant {args.variant:#x}")
         res = {
             "metric": "Gpixel*channels/s forward render (1M Gauss, C=512, 968x1296)",
             "value": world * V * H * W * C / (ms_per_step * 1e-3) / 1e9,
@@ -436,7 +529,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("bf16x3-split products, f32 accumulate" if split else "f32"),
+            "dtype": (arith if split else "f32"),
             "data": "synthetic",
             "config": {"workload": f"{args.config}: P={P} Gaussians, C={C}, {H}x{W} forward render "
                                    f"(BASELINE.md config 3 generator, seed 0)",
@@ -444,26 +537,33 @@ def main():
                        "parallelism": f"views x{world * V}: {V} in flight per GPU on {V} HIP streams, {world} GPU(s), "
                                       f"scene replicated, no collective",
                        "rccl": rccl,
-                       "num_rendered": ("blocking read-back in every forward (the reference's host pattern)" if not DEFER else
+                       "cameras": f"each of the {V} view slots cycles through {NCAM} cameras: a different view every step",
+                       "num_rendered": ("blocking read-back in every forward (the reference's host pattern, rasterizer_impl.cu:283)" if not DEFER else
                                         "deferred (SGS_OPT_DEFER_COUNT): buffers sized from the stream's previous frame, counts "
                                         "checked on the device and on the host once per step; every step's num_rendered is "
                                         "compared with the serial render (integrity)"),
                        "blend_variant": args.variant,
                        "blend_arithmetic": ("fp32 MFMA, bit-exact" if not split else
-                                            "every weight, decision and integer output in contract fp32; the C >= 128 "
-                                            "weighted sum as split-bf16 x3 MFMA products with fp32 accumulation "
-                                            "(tests: element-wise |out - oracle| <= 1e-4 max(|oracle|, 1e-3 |pixel|_inf)); "
-                                            "exact_f32 below is the bit-identical fp32-MFMA path")},
+                                            "every weight, decision and integer output in contract fp32 (bit-exact); the C >= 128 "
+                                            "weighted sum with features and weights split EXACTLY into three bf16 terms each, the six "
+                                            "products with i + j <= 4 on v_mfma_f32_32x32x8_bf16, fp32 accumulate.  tests: against the "
+                                            "exact (float64) composite it is as accurate as the oracle's fp32 fma chain (max and rms "
+                                            "of the element-wise error |x - exact| / max(|exact|, 1e-3 |pixel|_inf)); against the oracle "
+                                            "itself |out - oracle| <= 5e-6 |pixel|_inf everywhere, and the element-wise form exceeds 1e-4 "
+                                            "on < 1e-5 of the elements -- as the oracle's own chain does against the exact composite "
+                                            "(tests/test_configs_gpu.py); exact_f32 below is the bit-identical fp32-MFMA path")},
             "ms_per_step_median": ms_step_median,
             "ms_per_view": ms_per_step / V,
             "single_view": sv_default,
-            "single_view_deferred_count": {k: sv_deferred[k] for k in ("value", "unit", "ms_median", "ms_min", "forwards")},
+            "api_path": api,
+            "deferred_count": deferred,
             "exact_f32": exact,
+            "two_term": two_term,
             "backward": backward,
             # the forward blend = blend_weights_kernel + blend_accum_sweep_kernel (one launch each);
             # SURVEY 8(d)'s algorithmic bytes are a property of the pair, so the roofline is quoted
             # on the pair; the per-kernel live durations are alongside (rocprof: profiles/).
-            "roofline": {"bound": "hbm", "kernel": "blend_fwd (blend_weights_kernel + blend_accum_sweep_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "blend_fwd (blend_weights_kernel<4> + blend_accum_sweep2_kernel)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "algorithmic_bytes": bytes_blend,
                          "kernel_ms": blend_ms,
@@ -471,10 +571,12 @@ def main():
                          "secondary_ceilings": {
                              "algorithmic_gflop": flops_alg / 1e9,
                              "fp32_fma_frac": flops_alg / (blend_ms * 1e-3) / FP32_FMA_PEAK,
-                             "bf16_mfma_frac_3_products": 3 * 2.0 * C * contributors / (blend_ms * 1e-3) / BF16_MFMA_PEAK,
-                             "note": "algorithmic flops / blend time against the fp32 vector (= fp32 MFMA) peak 157.3 TF "
-                                     "and, x3 for the split products, the dense bf16 MFMA peak 2.5 PF: neither pipe is "
-                                     "the limiter (rocprof PMC: profiles/)"},
+                             "bf16_mfma_x8_frac_6_products": 6 * 2.0 * C * 256 * sum_neff * 0.55 / (blend_ms * 1e-3) / (BF16_MFMA_PEAK / 2),
+                             "note": "algorithmic flops / blend time against the fp32 vector (= fp32 MFMA) peak 157.3 TF; the six "
+                                     "bf16 products (all 256 pixels of every active entry, ~55 % of sum n_t_eff) against HALF the "
+                                     "dense bf16 peak: the legacy 32x32x8 instruction the sweep issues runs at 512 FLOP/clk/SIMD "
+                                     "(the double-rate x16 form is not used, DESIGN.md 5.9) -- the matrix pipe is ~50 % busy "
+                                     "(rocprof PMC: profiles/)"},
                          "measured": f"hipEvents on the launch stream over {sv_default['forwards']} forwards with one view "
                                      f"in flight; the timed region keeps {V} in flight (stage_ms_timed_region)"},
             # bytes_alg of the WHOLE forward (blend + binning front end) over the frame time
@@ -484,7 +586,8 @@ def main():
                               "single_view_frac_of_hbm_peak": (bytes_blend + bytes_front) / (sv_default["ms_median"] * 1e-3) / HBM_PEAK},
             "stage_ms": dict(zip(STAGES, [round(v, 4) for v in stage_ms])),
             "stage_ms_timed_region": dict(zip(STAGES, [round(v, 4) for v in stage_ms_timed])),
-            "integrity": {"forwards_checked": args.steps * V, "num_rendered_mismatches_vs_serial": mismatches},
+            "integrity": {"forwards_checked": args.steps * V, "num_rendered_mismatches_vs_serial": mismatches,
+                          "deferred_retries": retries},
             "workload_stats": {"P_vis": p_vis, "num_rendered": num_rendered, "sum_n_t_eff": sum_neff,
                                "tiles": tiles, "sum_n_contrib": contributors},
         }

@@ -372,10 +372,16 @@ inline uint32_t grow_hint(uint32_t hint, uint32_t used)
 	return (uint32_t)want;
 }
 
+// debug != 0 (the reference's CHECK_CUDA, CR/cuda_rasterizer/auxiliary.h:166-173): launch errors are checked after every
+// stage, and the stream is synchronised and checked at the END of the call -- an asynchronous fault is reported by
+// that call, attributed to "forward" / "backward".  The reference synchronises after EVERY stage; its own render_chn
+// passes debug=True unconditionally (model/renderer.py:182), so that behaviour would put ~8 host round trips into
+// every production frame (+0.15 ms at the headline size).  SGS_DEBUG_SYNC_EVERY_STAGE=1 restores it for fault hunting.
+static const bool g_sync_every_stage = [] { const char* e = getenv("SGS_DEBUG_SYNC_EVERY_STAGE"); return e && *e && *e != '0'; }();
 #define SGS_CHECK_STAGE(what)                                                             \
 	do {                                                                              \
 		hipError_t e_ = hipGetLastError();                                        \
-		if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(st);             \
+		if (e_ == hipSuccess && debug && g_sync_every_stage) e_ = hipStreamSynchronize(st); \
 		if (e_ != hipSuccess) return fail_hip(e_, what);                          \
 	} while (0)
 
@@ -859,6 +865,10 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	}
 	if (e != hipSuccess) return fail_hip(e, "blend forward");
 	SGS_CHECK_STAGE("blend forward");
+	if (debug && !g_sync_every_stage && !defer) {   // one synchronisation for the whole call (see SGS_CHECK_STAGE)
+		const hipError_t es = hipStreamSynchronize(st);
+		if (es != hipSuccess) return fail_hip(es, "forward (debug: asynchronous error; SGS_DEBUG_SYNC_EVERY_STAGE=1 names the stage)");
+	}
 	tm.mark();
 	tm.finish();
 	return (int)L;
@@ -998,6 +1008,10 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 				   tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor,
 				   dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
 	SGS_CHECK_STAGE("preprocess backward");
+	if (debug && !g_sync_every_stage) {
+		const hipError_t es = hipStreamSynchronize(st);
+		if (es != hipSuccess) return fail_hip(es, "backward (debug: asynchronous error; SGS_DEBUG_SYNC_EVERY_STAGE=1 names the stage)");
+	}
 	return 0;
 }
 
