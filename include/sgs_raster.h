@@ -53,9 +53,10 @@ const char *sgs_last_error(void);
  * Replaces CudaRasterizer::Rasterizer::forward
  *   (CR/cuda_rasterizer/rasterizer_impl.cu:198-341, declared rasterizer.h:30-53;
  *    RR/cuda_rasterizer/rasterizer_impl.cu:198-339 when out_depth != NULL).
- * Pipeline (default, binning mode 0): preprocess -> depth presort of the P Gaussians -> span counts + 64-bit
- * scan -> (8-byte D2H: row instances | num_rendered) -> two span partitions that write every tile's
- * depth-ordered list and `ranges` with no sort of the tile instances -> blend.  Binning mode 1 keeps the
+ * Pipeline (default, binning mode 0): preprocess -> depth presort of the P Gaussians (own LSD radix sort; its last
+ * pass also writes the per-rank span counts and adds up their totals) -> (8-byte D2H: row instances | num_rendered)
+ * -> two span partitions that write every tile's depth-ordered list and `ranges` with no sort of the tile instances
+ * -> blend (weights pre-pass + accumulate sweep for num_channels >= 128).  Binning mode 1 keeps the
  * reference's order of operations (inclusive scan -> 4-byte D2H -> duplicateWithKeys -> stable 64-bit radix sort
  * on bits [0, 32+msb(tiles)) -> tile ranges); lists, ranges and (reconstructed) keys are bit-identical in all modes.
  *   P,D,M          #Gaussians, active SH degree, SH coeffs per Gaussian (0 if no shs)
@@ -65,10 +66,13 @@ const char *sgs_last_error(void);
  *   out_color      (C,H,W) written in full
  *   out_depth      (1,H,W) or NULL: the RGB-D median depth of RR/forward.cu:308,368-372,391
  *   radii          (P) int32, or NULL (internal)
- *   debug          !=0: synchronise and check after every stage (CHECK_CUDA,
- *                  CR/cuda_rasterizer/auxiliary.h:166-173)
+ *   debug          !=0: launch errors are checked after every stage and the stream is synchronised and checked once at
+ *                  the end of the call (the reference's CHECK_CUDA synchronises after EVERY stage,
+ *                  CR/cuda_rasterizer/auxiliary.h:166-173; SGS_DEBUG_SYNC_EVERY_STAGE=1 in the environment does
+ *                  the same -- the reference's own render_chn passes debug=True on every production frame)
  * Returns num_rendered (Sum of tiles touched) >= 0, or a negative error code.
- * Blocks the host once (the 4-byte read of num_rendered), like the reference. */
+ * Blocks the host once (the 8-byte read of the instance counts), like the reference (rasterizer_impl.cu:283) --
+ * unless SGS_OPT_DEFER_COUNT is set on the stream (below). */
 int sgs_rasterize_forward(
 	sgs_alloc_fn geometry_buffer, void *geometry_user,
 	sgs_alloc_fn binning_buffer, void *binning_user,
@@ -299,7 +303,7 @@ int sgs_set_blend_variant(int variant);
  * sgs_get_stage_ms returns the number of forwards averaged (0 in mode 1). */
 int sgs_set_stage_timing(int mode);
 /* Binning algorithm: 0 (default) = Gaussians presorted by depth, per-tile lists built from row
- * instances without sorting the tile instances (binning_rows.hip); 1 = the reference's order of
+ * instances without sorting the tile instances (binning_rows.hip; 3 is accepted as an alias); 1 = the reference's order of
  * operations (emit in index order, sort on all 32+msb(tiles) key bits); 2 = depth presort,
  * instances emitted in that order, stable radix sort on the 32-bit tile id.  Lists (point_list),
  * ranges and the (reconstructed) sorted keys are bit-identical in all modes; point_offsets and

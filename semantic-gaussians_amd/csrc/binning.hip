@@ -94,26 +94,6 @@ void launch_duplicate_with_keys(hipStream_t st, int P, const float2* means2D, co
 // 4 passes) is 3x faster here, so the merge-sort limit is set to 0.
 using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
 						   rocprim::default_config, 0>;
-size_t gaussian_sort_temp_bytes(int P)
-{
-	size_t bytes = 0;
-	(void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-					rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr,
-					(size_t)P, 0u, 32u, (hipStream_t)0);
-	return bytes;
-}
-
-// depth_bits: the fp32 view-space depths reinterpreted (positive floats order like integers;
-// culled Gaussians hold garbage but emit nothing).  perm[r] = index of the r-th Gaussian.
-hipError_t launch_gaussian_depth_sort(hipStream_t st, void* temp, size_t temp_bytes,
-				      const uint32_t* depth_bits, uint32_t* keys_out, uint32_t* perm,
-				      int P)
-{
-	return rocprim::radix_sort_pairs<DepthSortConfig>(temp, temp_bytes, depth_bits, keys_out,
-					 rocprim::counting_iterator<uint32_t>(0), perm, (size_t)P, 0u, 32u,
-					 st);
-}
-
 __global__ __launch_bounds__(256) void gather_counts_kernel(int P, const uint32_t* __restrict__ perm,
 							     const uint32_t* __restrict__ tiles_touched,
 							     uint32_t* __restrict__ counts_sorted)

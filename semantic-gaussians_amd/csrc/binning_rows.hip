@@ -24,7 +24,6 @@
 #include "sgs_kernels.h"
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 namespace sgs {
 
@@ -104,26 +103,6 @@ __global__ __launch_bounds__(256) void span_counts_kernel(int P, const uint32_t*
 		c = ((uint64_t)nmaj << 32) | (uint64_t)(nmaj * nmin);
 	}
 	counts64[r] = c;
-}
-
-size_t scan64_temp_bytes(int P)
-{
-	size_t bytes = 0;
-	(void)rocprim::inclusive_scan(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)P,
-				      rocprim::plus<uint64_t>(), (hipStream_t)0);
-	return bytes;
-}
-
-hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes, int P, const uint32_t* perm,
-				  const int* radii, const float2* means2D, int gx, int gy, uint64_t* counts64,
-				  uint64_t* offs64, uint4* rrec, bool counts_done)
-{
-	const int major_x = gx >= gy;
-	if (!counts_done)
-		hipLaunchKernelGGL(span_counts_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, perm, radii, means2D,
-				   gx, gy, major_x, counts64, rrec);
-	return rocprim::inclusive_scan(temp, temp_bytes, (const uint64_t*)counts64, offs64, (size_t)P,
-				       rocprim::plus<uint64_t>(), st);
 }
 
 // chunk0 / grp0 = first chunk / scan group of each segment (segment s = items [segstart[s], segstart[s+1])).

@@ -174,9 +174,9 @@ struct GeomLayout {
 	size_t ds;                     // depth_sort.hip scratch, directly behind trap_flag's 128 bytes (one memset clears both)
 	sgs::DepthSortLayout ds_lay;
 	// depth presort of the Gaussians (binning modes 0 and 2)
-	size_t perm, gkeys, counts_sorted, gsort_temp, gsort_temp_bytes;
+	size_t perm, counts_sorted;
 	// mode 0: rows | tiles counts of the ranked Gaussians and their inclusive scan
-	size_t counts64, offs64, scan64_temp, scan64_temp_bytes, rrec;
+	size_t counts64, rrec;
 };
 
 GeomLayout geom_layout(int P)
@@ -200,14 +200,8 @@ GeomLayout geom_layout(int P)
 	sgs::depth_sort_layout(P, &g.ds_lay);
 	g.ds = c.take(g.ds_lay.total);   // (128-aligned: starts right behind trap_flag; its count matrices come first)
 	g.perm = c.take(p * 4);
-	g.gkeys = c.take(p * 4);
 	g.counts_sorted = c.take(p * 4);
-	g.gsort_temp_bytes = sgs::gaussian_sort_temp_bytes(P);
-	g.gsort_temp = c.take(g.gsort_temp_bytes);
 	g.counts64 = c.take(p * 8);
-	g.offs64 = c.take(p * 8);
-	g.scan64_temp_bytes = sgs::scan64_temp_bytes(P);
-	g.scan64_temp = c.take(g.scan64_temp_bytes);
 	g.rrec = c.take(p * 16);
 	g.total = align_up(c.off, 128) + 128;
 	g.pub.total = g.total;
@@ -591,8 +585,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// binning mode 0: sort the P Gaussians by depth bits and emit instances in that order, so
 	// that the big instance sort only has to be stable on the tile bits (binning.hip)
 	const int bmode = cx->option(SGS_OPT_BINNING_MODE);
-	const bool presort = bmode == 0 || bmode == 2 || bmode == 3;
-	const bool own_sort = presort && bmode != 3;   // depth_sort.hip (3 = mode 0 with the library radix sort, for A/B runs)
+	const bool presort = bmode == 0 || bmode == 2 || bmode == 3;   // (3: round 2's A/B mode with the library sort -- removed, an alias of 0)
+	const bool own_sort = presort;   // depth_sort.hip
 	// one clear: the trap flag and, right behind it, the depth sort's count matrices (filled by preprocess)
 	hipError_t e = hipMemsetAsync(trap_flag, 0, own_sort ? 128 + gl.ds_lay.counts_bytes : 4, st);
 	if (e != hipSuccess) return fail_hip(e, "memset");
@@ -609,26 +603,15 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	tm.mark();
 	// mode 0: per-tile lists from span partitions (binning_rows.hip); its per-wave bin tables live in LDS,
 	// so absurdly long grid axes (> 32k pixels) take the mode-2 path
-	const bool rows = (bmode == 0 || bmode == 3) && gx <= 2048 && gy <= 2048;
+	const bool rows = (bmode == 0 || bmode == 3) && gx <= 2048 && gy <= 2048;   // span partitions (binning_rows.hip)
 	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
-	uint64_t* offs64 = (uint64_t*)(gchunk + gl.offs64);
 	if (presort) {
 		sgs::DepthSortSpanOut span{radii, means2D, gx, gy, gx >= gy, (uint64_t*)(gchunk + gl.counts64),
 					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.trap_flag + 64)};
-		if (own_sort)
-			e = sgs::launch_depth_sort(st, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm,
-						   rows ? &span : nullptr);
-		else
-			e = sgs::launch_gaussian_depth_sort(st, gchunk + gl.gsort_temp, gl.gsort_temp_bytes,
-							    (const uint32_t*)depths, (uint32_t*)(gchunk + gl.gkeys),
-							    perm, P);
+		e = sgs::launch_depth_sort(st, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm, rows ? &span : nullptr);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
 		if (rows) {
-			// own sort: its last pass has written the span counts and their total (behind the trap flag) -- no scan
-			if (!own_sort)
-				e = sgs::launch_row_counts_scan(st, gchunk + gl.scan64_temp, gl.scan64_temp_bytes, P, perm, radii,
-								means2D, gx, gy, (uint64_t*)(gchunk + gl.counts64), offs64,
-								(uint4*)(gchunk + gl.rrec), false);
+			// the sort's last pass has written the span counts and their total (behind the trap flag) -- no scan
 		} else {
 			uint32_t* counts_sorted = (uint32_t*)(gchunk + gl.counts_sorted);
 			sgs::launch_gather_counts(st, P, perm, tiles_touched, counts_sorted);
@@ -650,7 +633,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// thread can keep several streams fed.  The return value is then the CAPACITY the binning buffer was laid out
 	// for, not num_rendered -- such a forward cannot be handed to sgs_rasterize_backward.
 	// sum over the Gaussians of (major instances << 32 | instances): the scan's last element, or the own sort's total
-	const uint64_t* totals64 = (own_sort && rows) ? (const uint64_t*)(gchunk + gl.trap_flag + 64) : offs64 + (P - 1);
+	const uint64_t* totals64 = (const uint64_t*)(gchunk + gl.trap_flag + 64);   // (rows)
 	const int defer_opt = cx->option(SGS_OPT_DEFER_COUNT);
 	if (cx->count_pending && cx->count_ev && hipEventQuery(cx->count_ev) == hipSuccess) {
 		// a deferred frame nobody asked about: still learn from it

@@ -17,7 +17,6 @@
 //    walk almost the same boxes, so box tests are near-uniform branches and leaf reads hit L1.
 #include "sgs_kernels.h"
 #include <cstring>   // rocPRIM's texture iterator calls host memset
-#include <rocprim/rocprim.hpp>
 #include <float.h>
 
 namespace sgs {
@@ -223,8 +222,8 @@ __global__ __launch_bounds__(256) void knn_kernel(int P, const float4* __restric
 }
 
 struct KnnLayout {
-	size_t bb, codes, idx, codes_sorted, idx_sorted, sorted, leaves, supers, sort_temp,
-		sort_temp_bytes, total;
+	size_t bb, codes, idx, idx_sorted, sorted, leaves, supers, ds, total;
+	DepthSortLayout ds_lay;
 };
 
 inline size_t al(size_t x) { return (x + 127) & ~(size_t)127; }
@@ -238,16 +237,12 @@ KnnLayout knn_layout(int P)
 	l.bb = take(6 * 4);
 	l.codes = take(p * 4);
 	l.idx = take(p * 4);
-	l.codes_sorted = take(p * 4);
 	l.idx_sorted = take(p * 4);
 	l.sorted = take(p * 16);
 	l.leaves = take(((p + LEAF - 1) / LEAF) * sizeof(Box));
 	l.supers = take(((p + SUPER - 1) / SUPER) * sizeof(Box));
-	l.sort_temp_bytes = 0;
-	(void)rocprim::radix_sort_pairs(nullptr, l.sort_temp_bytes, (uint32_t*)nullptr,
-					(uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, p,
-					0u, 30u, (hipStream_t)0);
-	l.sort_temp = take(l.sort_temp_bytes);
+	depth_sort_layout(P, &l.ds_lay);   // the Morton sort runs on the forward's own LSD radix sort (depth_sort.hip)
+	l.ds = take(l.ds_lay.total + 128);
 	l.total = al(off);
 	return l;
 }
@@ -265,7 +260,6 @@ hipError_t launch_knn(hipStream_t st, int P, const float* points, float* out, vo
 	uint32_t* bb = (uint32_t*)(s + l.bb);
 	uint32_t* codes = (uint32_t*)(s + l.codes);
 	uint32_t* idx = (uint32_t*)(s + l.idx);
-	uint32_t* codes_sorted = (uint32_t*)(s + l.codes_sorted);
 	uint32_t* idx_sorted = (uint32_t*)(s + l.idx_sorted);
 	float4* sorted = (float4*)(s + l.sorted);
 	Box* leaves = (Box*)(s + l.leaves);
@@ -274,9 +268,8 @@ hipError_t launch_knn(hipStream_t st, int P, const float* points, float* out, vo
 	hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, bb);
 	hipLaunchKernelGGL(bbox_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, st, P, points, bb);
 	hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(256), 0, st, P, points, bb, codes, idx);
-	hipError_t e = rocprim::radix_sort_pairs(s + l.sort_temp, const_cast<size_t&>(l.sort_temp_bytes),
-						 codes, codes_sorted, idx, idx_sorted, (size_t)P, 0u, 30u,
-						 st);
+	// stable (ties by index, like the library sort it replaces): idx_sorted[r] = index of the point with the r-th code
+	hipError_t e = launch_depth_sort_standalone(st, P, l.ds_lay, s + l.ds, codes, idx_sorted);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(256), 0, st, P, points, idx_sorted, sorted);
 	hipLaunchKernelGGL(boxes_kernel, dim3((P + SUPER - 1) / SUPER), dim3(SUPER), 0, st, P, sorted,

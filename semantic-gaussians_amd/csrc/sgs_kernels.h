@@ -49,10 +49,6 @@ hipError_t launch_inclusive_scan(hipStream_t st, void* temp, size_t temp_bytes,
 void launch_duplicate_with_keys(hipStream_t st, int P, const float2* means2D, const float* depths,
 				const uint32_t* offsets, const int* radii, int gx, int gy,
 				uint64_t* keys, uint32_t* vals, uint32_t L, const uint32_t* perm);
-size_t gaussian_sort_temp_bytes(int P);
-hipError_t launch_gaussian_depth_sort(hipStream_t st, void* temp, size_t temp_bytes,
-				      const uint32_t* depth_bits, uint32_t* keys_out, uint32_t* perm,
-				      int P);
 void launch_gather_counts(hipStream_t st, int P, const uint32_t* perm, const uint32_t* tiles_touched,
 			  uint32_t* counts_sorted);
 void launch_emit_tile_keys(hipStream_t st, int P, uint32_t L, const float2* means2D,
@@ -64,11 +60,6 @@ hipError_t launch_sort32_pairs(hipStream_t st, void* temp, size_t temp_bytes, ui
 			       int end_bit);
 void launch_tile_ranges32(hipStream_t st, size_t L, const uint32_t* tiles, uint2* ranges, int ntiles);
 // ---- binning_rows.hip (binning mode 0)
-size_t scan64_temp_bytes(int P);
-// counts_done: counts64 / rrec were already written (depth_sort.hip's last pass) -- only the scan runs
-hipError_t launch_row_counts_scan(hipStream_t st, void* temp, size_t temp_bytes, int P, const uint32_t* perm,
-				  const int* radii, const float2* means2D, int gx, int gy, uint64_t* counts64,
-				  uint64_t* offs64, uint4* rrec, bool counts_done = false);
 void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, size_t* cmat_words,
 			 size_t* gtot_words, size_t* len_words);
 // R may be an upper bound of the major-instance count (grids and scratch are sized from it, the kernels read the

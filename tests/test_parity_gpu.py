@@ -149,7 +149,7 @@ def test_forward_channel_counts(orc, C):
         _check_forward(orc, scene, cam, variant=15)   # SGS_BLEND_EXACT: bit-identical
 
 
-@pytest.mark.parametrize("binning_mode", [0, 1, 2, 3])   # 3 = mode 0 with the library radix sort as the depth presort
+@pytest.mark.parametrize("binning_mode", [0, 1, 2])
 def test_binning_modes_bit_exact(orc, binning_mode):
     """Both binning algorithms give the oracle's sorted keys / lists / ranges; the reference-order
     mode additionally reproduces point_offsets and the emission-order (unsorted) arrays."""
