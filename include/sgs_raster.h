@@ -151,6 +151,18 @@ int sgs_rasterize_backward(
 int sgs_mark_visible(int P, const float *means3D, const float *viewmatrix,
 		     const float *projmatrix, uint8_t *present, void *stream);
 
+/* ---- Gaussian-sharded scenes (BASELINE config 5; no counterpart in the reference) ----------------------
+ * Depth-ordered shard partials (A_s: the (C, rows, W) feature map of shard s rendered with a ZERO background, T_s: its
+ * (rows, W) final transmittance -- what sgs_rasterize_forward + the image buffer's accum_alpha give) combine with the
+ * associative, non-commutative "over" operator; this is the whole front-to-back chain in one pass over memory:
+ *     out[c][px] = sum_s (prod_{s' < s} T_s'[px]) A_s[c][px] + (prod_s T_s[px]) background[c]
+ *     T_out[px]  = prod_s T_s[px]                                                     (optional, may be NULL)
+ * partial_A / partial_T are HOST arrays of num_shards (<= 16) device pointers, front-most shard first; every plane is
+ * contiguous (rows * width floats) and 16-byte aligned; background may be NULL (no background term). */
+int sgs_composite_over(int num_shards, const float *const *partial_A, const float *const *partial_T,
+		       const float *background, float *out, float *T_out, int num_channels, int rows, int width,
+		       void *stream);
+
 /* Replaces SimpleKNN::knn (SK/simple_knn.cu:185-221, simple_knn.h:18): mean squared
  * distance to the three nearest other points.  points (P,3), meanDists (P).
  * Scratch comes from `scratch(scratch_user, bytes)` (one call). */

@@ -1044,6 +1044,26 @@ int sgs_fusion_accumulate(int N, int C, const float* features_hwc, int image_w, 
 	return 0;
 }
 
+int sgs_composite_over(int num_shards, const float* const* partial_A, const float* const* partial_T, const float* background,
+		       float* out, float* T_out, int num_channels, int rows, int width, void* stream)
+{
+	if (num_shards < 1 || num_shards > sgs::SGS_MAX_SHARDS) return fail(SGS_EINVAL, "1 .. 16 shards");
+	if (num_channels < 0 || rows < 0 || width < 0) return fail(SGS_EINVAL, "bad sizes");
+	if (!partial_A || !partial_T || !out) return fail(SGS_EINVAL, "null argument");
+	const size_t npix = (size_t)rows * (size_t)width;
+	if (npix == 0 || num_channels == 0) return 0;
+	uintptr_t align = (uintptr_t)out | (uintptr_t)(npix * 4);
+	for (int s = 0; s < num_shards; s++) {
+		if (!partial_A[s] || !partial_T[s]) return fail(SGS_EINVAL, "null partial");
+		align |= (uintptr_t)partial_A[s] | (uintptr_t)partial_T[s];
+	}
+	if (align & 15u) return fail(SGS_EINVAL, "partials, output and rows * width * 4 must be 16-byte aligned");
+	const hipError_t e = sgs::launch_composite_over((hipStream_t)stream, num_shards, partial_A, partial_T, background, out, T_out,
+							num_channels, npix);
+	if (e != hipSuccess) return fail_hip(e, "composite");
+	return 0;
+}
+
 int sgs_knn_mean_dist2(int P, const float* points, float* meanDists, sgs_alloc_fn scratch,
 		       void* scratch_user, void* stream)
 {

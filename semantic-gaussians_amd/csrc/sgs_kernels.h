@@ -172,6 +172,11 @@ void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* mea
 			   const float* dL_dcolor, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
 			   float* dL_drot);
 
+// ---- composite.hip: the "over" composite of depth-ordered shard partials in one pass
+constexpr int SGS_MAX_SHARDS = 16;
+hipError_t launch_composite_over(hipStream_t st, int S, const float* const* A, const float* const* T, const float* bg,
+				 float* out, float* t_out, int C, size_t npix);
+
 // ---- knn.hip
 size_t knn_scratch_bytes(int P);
 hipError_t launch_knn(hipStream_t st, int P, const float* points, float* out, void* scratch,

@@ -38,22 +38,42 @@ def shard_views(n_views, rank=None, world_size=None):
     return list(range(rank, n_views, world_size))
 
 
-def render_views_sharded(render_fn, views, gather_to=0):
-    """Each rank renders views[rank::world]; results are gathered (as CPU tensors) on
-    `gather_to` in view order (None elsewhere).  No collective touches the render itself."""
+def render_views_sharded(render_fn, views, gather_to=None):
+    """Each rank renders views[rank::world].  No collective touches the render itself.
+
+    gather_to=None (default): results stay on the GPU that produced them -- returns {view index: tensor} of this
+    rank's views (a 3.3 GB feature map per view at BASELINE config 4 has no business crossing PCIe or being pickled).
+    gather_to=r: rank r additionally receives the other ranks' results as TENSORS (grouped point-to-point receives
+    straight into device memory under RCCL; every view must have the same shape and dtype) and returns the list in
+    view order; the other ranks return None."""
     rank, w = world()
     mine = {i: render_fn(views[i]) for i in shard_views(len(views), rank, w)}
+    if gather_to is None:
+        return mine
     if w == 1:
         return [mine[i] for i in range(len(views))]
-    payload = {i: t.detach().cpu() for i, t in mine.items()}
-    gathered = [None] * w if rank == gather_to else None
-    dist.gather_object(payload, gathered, dst=gather_to)
+    # shape / dtype of a view: known to every rank that rendered one; agree on it with one tiny object collective
+    meta = [None] * w
+    first = next(iter(mine.values())) if mine else None
+    dist.all_gather_object(meta, None if first is None else (tuple(first.shape), str(first.dtype).replace("torch.", ""), first.device.type))
+    shape, dtype, devtype = next(m for m in meta if m is not None)
+    ops, recv = [], {}
+    if rank == gather_to:
+        device = first.device if first is not None else (torch.device("cuda", torch.cuda.current_device()) if devtype == "cuda" else torch.device("cpu"))
+        for i in range(len(views)):
+            src = i % w
+            if src != rank:
+                recv[i] = torch.empty(shape, dtype=getattr(torch, dtype), device=device)
+                ops.append(dist.P2POp(dist.irecv, recv[i], src))
+    else:
+        for i, t in sorted(mine.items()):
+            ops.append(dist.P2POp(dist.isend, t.contiguous(), gather_to))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != gather_to:
         return None
-    merged = {}
-    for part in gathered:
-        merged.update(part)
-    return [merged[i] for i in range(len(views))]
+    return [mine[i] if i % w == rank else recv[i] for i in range(len(views))]
 
 
 _SIDE_STREAMS = {}
@@ -137,7 +157,31 @@ def band_rows(H, rank=None, world_size=None):
 
 
 def composite_over(partials, bg=None):
-    """Front-to-back "over" of [(A (C,h,W), T (h,W)), ...]; adds bg*T_total when bg is given."""
+    """Front-to-back "over" of [(A (C,h,W), T (h,W)), ...]; adds bg*T_total when bg is given.  -> (out, T_total).
+    Device tensors: ONE HIP kernel that reads every partial once (C-ABI sgs_composite_over); host tensors (the gloo
+    tests, whose renderer is injected): the same chain in torch."""
+    a0 = partials[0][0]
+    if a0.is_cuda and len(partials) <= 16:
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        S = len(partials)
+        Cn, h, W = a0.shape
+        keep = [(a.contiguous(), t.contiguous()) for a, t in partials]
+        if any(x.dtype != torch.float32 for pair in keep for x in pair):
+            raise RuntimeError("partials must be float32")
+        out = torch.empty((Cn, h, W), dtype=torch.float32, device=a0.device)
+        t_out = torch.empty((h, W), dtype=torch.float32, device=a0.device)
+        if (h * W) % 4 == 0 and all((x.data_ptr() & 15) == 0 for pair in keep for x in pair):
+            pa = (C.c_void_p * S)(*[a.data_ptr() for a, _ in keep])
+            pt = (C.c_void_p * S)(*[t.data_ptr() for _, t in keep])
+            bgc = None if bg is None else bg.to(device=a0.device, dtype=torch.float32).contiguous()
+            with torch.cuda.device(a0.device):
+                rc = lib.sgs_composite_over(S, pa, pt, None if bgc is None else C.c_void_p(bgc.data_ptr()),
+                                            C.c_void_p(out.data_ptr()), C.c_void_p(t_out.data_ptr()), Cn, h, W,
+                                            C.c_void_p(torch.cuda.current_stream(a0.device).cuda_stream))
+            _lib.check(rc, "composite_over failed")
+            return out, t_out
     out = partials[0][0].clone()
     t_acc = partials[0][1].clone()
     for a, t in partials[1:]:

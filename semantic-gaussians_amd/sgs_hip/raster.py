@@ -7,6 +7,7 @@ inside libsgs_hip.so.
 """
 import ctypes as C
 import os
+import threading
 import warnings
 
 import torch
@@ -68,15 +69,17 @@ class _Buffers:
 
     _live = {}
     _next = 1
+    _lock = threading.Lock()   # one host thread per GPU is a legal way to drive several devices: handles must be unique
     KEYS = ("g", "b", "i", "s")
 
     def __init__(self, device, pool=None):
         self.device = device
         self.pool = pool
         self.tensors = {}
-        self.handle = _Buffers._next
-        _Buffers._next += 1
-        _Buffers._live[self.handle] = self
+        with _Buffers._lock:
+            self.handle = _Buffers._next
+            _Buffers._next += 1
+            _Buffers._live[self.handle] = self
 
     def release(self):
         _Buffers._live.pop(self.handle, None)

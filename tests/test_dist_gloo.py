@@ -59,7 +59,9 @@ def _worker(rank, world, port, q):
         views = _views(5)
         # --- view sharding: rank r renders views r, r+2, ...; gathered on rank 0
         assert sd.shard_views(5) == list(range(rank, 5, world))
-        imgs = sd.render_views_sharded(lambda cam: _oracle_render(scene, cam), views)
+        imgs = sd.render_views_sharded(lambda cam: _oracle_render(scene, cam), views, gather_to=0)   # tensors, point to point
+        local = sd.render_views_sharded(lambda cam: _oracle_render(scene, cam), views)                # default: results stay put
+        assert sorted(local) == list(range(rank, 5, world))
         # --- channel sharding: exact, one all_gather
         full = sd.render_channel_sharded(
             lambda f, b: _oracle_render(scene, views[1], f, b), scene.features, scene.bg)
