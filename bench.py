@@ -194,6 +194,115 @@ def cpu_baseline_pytorch(scene, cam, C, W, H, n_eff, budget_s=10.0):
                         f"sum n_t_eff ({work * 100:.2f} % of the frame's list work) -> {t_frame:.1f} s/frame"))
 
 
+def extra_config_legs(rank, world, dev, dist):
+    """BASELINE configs 4 and 5 on this job's ranks.  Returns a dict for the JSON line; never raises."""
+    import traceback
+    from sgs_hip import raster, dist as sdist
+    from sgs_hip.synthetic import CONFIGS, make_scene
+    empty = torch.Tensor([])
+    out = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(t):
+        if world > 1:
+            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return t
+    # ---- config 4: 5M Gaussians x 768 channels, 840x1297, 8 views on a ring sharded round-robin, scene replicated
+    try:
+        P, C, W, H, fx = CONFIGS["cfg4"]
+        scene = make_scene(P, C, W, H, fx, seed=4, features=False)
+        s = scene.to(dev)
+        g = torch.Generator(device=dev).manual_seed(44)
+        feats = torch.empty(P, C, device=dev)
+        for i in range(0, P, 1 << 20):
+            f = torch.randn(min(P, i + (1 << 20)) - i, C, device=dev, generator=g)
+            feats[i:i + f.shape[0]] = f / f.norm(dim=1, keepdim=True)
+        del f
+        bg = torch.zeros(C, device=dev)
+        views = [view_camera(i, W, H, fx).to(dev) for i in range(8)]
+        mine = sdist.shard_views(len(views), rank, world)
+        pool = raster.ScratchPool()
+        raster.OUTPUT_PITCH_ALIGN = 32   # 1297 is not a multiple of 16: rows padded to whole 128-byte lines
+
+        def render4(c):
+            return raster.rasterize_forward(bg, s.means3D, feats, s.opacities, s.scales, s.rotations, 1.0, empty, c.world_view_transform,
+                                            c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, empty, 0, c.camera_center, False,
+                                            False, C, False, pool=pool)[1]
+        o = None
+        for _ in range(2):   # warm exactly like the timed loop (one result alive while the next allocates)
+            for i in mine:
+                o = render4(views[i])
+        passes = 4
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            for i in mine:
+                o = render4(views[i])   # results stay on the GPU that rendered them
+        barrier()
+        t = max_over_ranks(time.perf_counter() - t0)
+        raster.OUTPUT_PITCH_ALIGN = 0
+        nv = passes * len(views)
+        out["cfg4"] = {"workload": f"cfg4: P={P} x C={C}, {H}x{W}, 8 views round-robin over {world} GPU(s), scene replicated, no collective, "
+                                   f"output rows padded to 32 px", "views_per_s": nv / t, "value": nv * H * W * C / t / 1e9,
+                       "unit": "Gpixel*channels/s", "ms_per_view_per_gpu": t / (passes * max(1, len(views) // world)) * 1e3, "seconds": t}
+        del feats, s, o, pool
+        torch.cuda.empty_cache()
+    except Exception:   # noqa: BLE001
+        raster.OUTPUT_PITCH_ALIGN = 0
+        out["cfg4"] = {"error": traceback.format_exc()[-1500:]}
+    # ---- config 5: 50M Gaussians x 256 channels Gaussian-sharded: rank r holds view-space depth slab r; (A, T) partials,
+    # image-partitioned point-to-point exchange over RCCL, one composite kernel per band
+    try:
+        P, C, W, H, fx = CONFIGS["cfg5"]
+        scene = make_scene(P, C, W, H, fx, seed=5, features=False)   # every rank: the same geometry (2.2 GB on the host)
+        order = torch.argsort(scene.means3D[:, 2])                   # camera at the origin looking down +z
+        idx = order[rank * P // world:(rank + 1) * P // world]
+        sh = [t[idx].to(dev) for t in (scene.means3D, scene.opacities, scene.scales, scene.rotations)]
+        del scene, order
+        n_loc = idx.numel()
+        g = torch.Generator(device=dev).manual_seed(500 + rank)
+        feats = torch.empty(n_loc, C, device=dev)
+        for i in range(0, n_loc, 1 << 21):
+            f = torch.randn(min(n_loc, i + (1 << 21)) - i, C, device=dev, generator=g)
+            feats[i:i + f.shape[0]] = f / f.norm(dim=1, keepdim=True)
+        del f
+        bg = torch.linspace(0.0, 1.0, C, device=dev)
+        cam = view_camera(0, W, H, fx).to(dev)
+        pool = raster.ScratchPool()
+
+        def partial():
+            A, T, _ = raster.render_partial(sh[0], feats, sh[1], sh[2], sh[3], cam.world_view_transform, cam.full_proj_transform,
+                                            cam.tanfovx, cam.tanfovy, H, W, cam.camera_center, pool=pool)
+            return A, T
+        band = sdist.render_gaussian_sharded(partial, bg, all_gather=False)
+        frames = 4
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            band = sdist.render_gaussian_sharded(partial, bg, all_gather=False)   # every rank ends up with its band of rows
+        barrier()
+        t = max_over_ranks(time.perf_counter() - t0)
+        lo, hi = sdist.band_rows(H, rank, world)
+        out["cfg5"] = {"workload": f"cfg5: P={P} x C={C}, {H}x{W}, Gaussians sharded into {world} view-space depth slab(s) "
+                                   f"({n_loc} on this rank), (A, T) partials exchanged as grouped RCCL send / recv by image band, "
+                                   f"one composite kernel per band; each rank keeps its band of rows",
+                       "frames_per_s": frames / t, "value": frames * H * W * C / t / 1e9, "unit": "Gpixel*channels/s",
+                       "ms_per_frame": t / frames * 1e3,
+                       "exchange_bytes_sent_per_rank_per_frame": int((C + 1) * 4 * W * (H - (hi - lo))) if world > 1 else 0,
+                       "band_rows_rank0": [lo, hi], "finite": bool(torch.isfinite(band).all())}
+        del feats, sh, band, pool
+        torch.cuda.empty_cache()
+    except Exception:   # noqa: BLE001
+        out["cfg5"] = {"error": traceback.format_exc()[-1500:]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +320,9 @@ def main():
                          "blocking num_rendered read-back in every forward")
     ap.add_argument("--fixed-camera", action="store_true",
                     help="every step renders the same camera per slot (profiling runs: per-kernel averages of ONE view)")
+    ap.add_argument("--extra-configs", action="store_true",
+                    help="also time BASELINE configs 4 (views sharded) and 5 (Gaussians sharded, RCCL exchange); on by default "
+                         "when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-arithmetic / backward legs")
     args = ap.parse_args()
@@ -500,6 +612,16 @@ def main():
         del dL
         torch.cuda.empty_cache()
 
+    extra_cfgs = None
+    if args.extra_configs or world > 1:
+        # free the headline's residents first (scene features 2 GB, pools): configs 4 / 5 bring 15 / 51 GB of their own
+        for p in pools:
+            p.clear()
+        raster.INFERENCE_POOL.clear()
+        torch.cuda.empty_cache()
+        extra_cfgs = extra_config_legs(rank, world, dev, dist if world > 1 else None)
+        if rank == 0:
+            log("extra configs: " + json.dumps(extra_cfgs)[:600])
     if rank == 0:
         log(f"P_vis={p_vis} L={num_rendered} tile-list mean/max={lens.mean().item():.1f}/"
             f"{int(lens.max().item())} sum_n_t_eff={sum_neff} (mean {sum_neff / tiles:.1f}/tile) "
@@ -586,6 +708,7 @@ def main():
                               "single_view_frac_of_hbm_peak": (bytes_blend + bytes_front) / (sv_default["ms_median"] * 1e-3) / HBM_PEAK},
             "stage_ms": dict(zip(STAGES, [round(v, 4) for v in stage_ms])),
             "stage_ms_timed_region": dict(zip(STAGES, [round(v, 4) for v in stage_ms_timed])),
+            "multi_gpu_configs": extra_cfgs,
             "integrity": {"forwards_checked": args.steps * V, "num_rendered_mismatches_vs_serial": mismatches,
                           "deferred_retries": retries},
             "workload_stats": {"P_vis": p_vis, "num_rendered": num_rendered, "sum_n_t_eff": sum_neff,
