@@ -1043,13 +1043,10 @@ hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const 
 			   (uint32_t)ntiles * (uint32_t)ACH);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(blend_weights_kernel<3>, dim3(((ntiles + 7) / 8) * 8), dim3(256), 0, st, ranges,
-			   point_list, means2D, conic_opacity, final_T, n_contrib,
-			   (uint32_t*)(arena + lay.act_id), (uint32_t*)(arena + lay.act_idx),
-			   (float*)(arena + lay.wgt), (uint32_t*)(arena + lay.table),
-			   (uint32_t*)(arena + lay.nbatches), counter, lay.capacity, W, H, gx, (ntiles + 7) / 8,
-			   ntiles, (unsigned long long*)nullptr, (float4*)clear_ptr, (unsigned long long)(clear_floats / 4));
-	return hipGetLastError();
+	return launch_blend_weights2(st, 3, ranges, point_list, means2D, conic_opacity, final_T, n_contrib,
+				     (uint32_t*)(arena + lay.act_id), (uint32_t*)(arena + lay.act_idx), (float*)(arena + lay.wgt),
+				     (uint32_t*)(arena + lay.table), (uint32_t*)(arena + lay.nbatches), counter, lay.capacity, W, H, gx,
+				     ntiles, clear_ptr, clear_floats);
 }
 
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
@@ -1112,7 +1109,19 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		const bool sweep2 = arith_nib >= 10 && arith_nib <= 15;
 		const bool presplit3 = arith_nib >= 14;   // weights handed over as three bf16 terms
 		const bool exact = arith_nib == 9;
-		if (presplit3) SGS_LAUNCH_W(4, st, 0, ntiles);
+		// weights pre-pass.  blend_weights2.hip (lane = two pixels: a third fewer instructions) is used for the fp32-row format
+		// (0.25 -> 0.22 ms at cfg3; the backward's pre-pass is the same kernel).  For the three-term format it is 4 % faster
+		// on its own (0.31 -> 0.30 ms) but the sweep BEHIND it runs 5 % slower (1.19 -> 1.25 ms, reproducibly; the cause was
+		// not found -- same bytes, same slots), so the default path keeps round 2's kernel there.  Bit 14 of the word flips
+		// the choice for A/B runs; a sweep trace needs round 2's kernel (it carries the trace hooks).
+		const bool flip = (split_mode & 0x4000) != 0;
+		const bool w_old = (presplit3 ? !flip : flip) || g_sweep_trace != nullptr;
+		if ((presplit3 || exact || sweep2) && !w_old) {
+			const hipError_t ew = launch_blend_weights2(st, presplit3 ? 4 : 3, a.ranges, a.point_list, a.means2D, a.conic_opacity,
+								    a.final_T, a.n_contrib, act_id, nullptr, wgt, table, nbatches, counter,
+								    lay.capacity, a.W, a.H, a.gx, ntiles, nullptr, 0);
+			if (ew != hipSuccess) return ew;
+		} else if (presplit3) SGS_LAUNCH_W(4, st, 0, ntiles);
 		else if (exact || sweep2) SGS_LAUNCH_W(3, st, 0, ntiles);
 		else SGS_LAUNCH_W(2, st, 0, ntiles);
 		if (mark) mark(mark_user);

@@ -113,6 +113,12 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
 				      int split_mode, bool* usage_reported = nullptr);
 
+// ---- blend_weights2.hip: the weights pre-pass with a lane owning two pixels (mode 3 = fp32 rows, 4 = three bf16 terms)
+hipError_t launch_blend_weights2(hipStream_t st, int mode, const uint2* ranges, const uint32_t* point_list,
+				 const float2* means2D, const float4* conic_opacity, float* final_T, uint32_t* n_contrib,
+				 uint32_t* act_id, uint32_t* act_idx, float* wgt, uint32_t* table, uint32_t* nact, uint32_t* counter,
+				 uint32_t capacity, int W, int H, int gx, int ntiles, float* clear_ptr, size_t clear_floats);
+
 // ---- blend_sweep2.hip: the accumulate sweep in fp32-class arithmetic (arith: 0 = exact fp32 MFMA, 1 = six bf16 products,
 // 2 = the same on the x16 MFMA), LDS-polled DMA arrival, stores spread over the next tile; takes fp32 weight rows
 hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFwdArgs& a, const uint32_t* table,
