@@ -946,6 +946,8 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 	} else if (arith == S2_X6PW) {
 		if (dbg == 1) S2_LAUNCH(S2_X6PW, 1);
 		else if (dbg == 2) S2_LAUNCH(S2_X6PW, 2);
+		else if (dbg == 4) S2_LAUNCH(S2_X6PW, 4);
+		else if (dbg == 8) S2_LAUNCH(S2_X6PW, 8);
 		else S2_LAUNCH(S2_X6PW, 0);
 	} else if (arith == S2_X6P) {
 		if (dbg == 1) S2_LAUNCH(S2_X6P, 1);

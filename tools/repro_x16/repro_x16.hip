@@ -135,6 +135,43 @@ __global__ __launch_bounds__(64) void victim_pk_kernel(int iters, uint32_t salt,
 	}
 }
 
+// The library's real victim arithmetic: the 3-D covariance of a Gaussian from its scale and quaternion
+// (semantic-gaussians_amd/csrc/sgs_device.h, cov3d_from_scale_rot), which hipcc's SLP vectoriser turns into a chain of
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 with op_sel and neg modifiers.  Results are written out and compared, after
+// the aggressor has stopped, with a second evaluation by the same kernel.
+__device__ __forceinline__ void cov3d(float sx, float sy, float sz, float r, float x, float y, float z, float* cov)
+{
+	float R[3][3], M[3][3];
+	R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+	R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+	R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+	const float s[3] = {sx, sy, sz};
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+#pragma unroll
+		for (int i = 0; i < 3; i++) M[k][i] = s[k] * R[i][k];
+#define SIG(i, j) (M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j])
+	cov[0] = SIG(0, 0); cov[1] = SIG(1, 0); cov[2] = SIG(2, 0); cov[3] = SIG(1, 1); cov[4] = SIG(2, 1); cov[5] = SIG(2, 2);
+#undef SIG
+}
+__global__ __launch_bounds__(256) void victim_cov_kernel(int n, const float* __restrict__ scales, const float* __restrict__ rots, float* __restrict__ out)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	float c[6];
+	cov3d(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3], c);
+#pragma unroll
+	for (int k = 0; k < 6; k++) out[6 * (size_t)i + k] = c[k];
+}
+__global__ void compare_kernel(size_t n, const uint32_t* a, const uint32_t* b, uint32_t* bad)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+		if (a[i] != b[i]) {
+			atomicAdd(&bad[120], 1u);
+			if (atomicAdd(&bad[121], 1u) < 2) { bad[122] = (uint32_t)i; bad[123] = a[i]; bad[124] = b[i]; }
+		}
+}
+
 // MODE bits: 1 = LDS-DMA ring, 2 = x16 MFMA (else x8 pairs if bit 2), 4 = x8 MFMA, 8 = nt stores, 16 = claim all 256 registers
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void aggressor_kernel(const float* __restrict__ src, size_t nfloat, float* __restrict__ sink, int iters)
@@ -243,6 +280,19 @@ int main(int argc, char** argv)
 	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, vsrc, NW);
 	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (uint32_t*)asrc, NW);
 	CK(hipDeviceSynchronize());
+	const int NCOV = 1 << 22;
+	float *cscale, *crot, *cout, *cref;
+	CK(hipMalloc(&cscale, (size_t)NCOV * 12)); CK(hipMalloc(&crot, (size_t)NCOV * 16));
+	CK(hipMalloc(&cout, (size_t)NCOV * 24)); CK(hipMalloc(&cref, (size_t)NCOV * 24));
+	{   // scales ~ 0.01 .. 0.03, quaternions of unit-ish norm, from the word pattern
+		std::vector<float> hs((size_t)NCOV * 3), hr((size_t)NCOV * 4);
+		for (size_t i = 0; i < hs.size(); i++) hs[i] = 0.01f + 0.02f * (float)(pattern((uint32_t)i) & 0xffff) / 65536.0f;
+		for (size_t i = 0; i < hr.size(); i++) hr[i] = ((float)(pattern((uint32_t)(i * 7 + 1)) & 0xffff) / 32768.0f - 1.0f) * 0.6f;
+		CK(hipMemcpy(cscale, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+		CK(hipMemcpy(crot, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+	}
+	hipLaunchKernelGGL(victim_cov_kernel, dim3(NCOV / 256), dim3(256), 0, 0, NCOV, cscale, crot, cref);
+	CK(hipDeviceSynchronize());
 	hipStream_t sv, sa;
 	CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
 	CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
@@ -284,6 +334,8 @@ int main(int argc, char** argv)
 				hipLaunchKernelGGL(victim_valu_kernel, dim3(16384), dim3(64), 0, sv, 256, salt++, bad);
 				hipLaunchKernelGGL(victim_trans_kernel, dim3(16384), dim3(64), 0, sv, 96, salt++, bad);
 				hipLaunchKernelGGL(victim_pk_kernel, dim3(16384), dim3(64), 0, sv, 256, salt++, bad);
+				hipLaunchKernelGGL(victim_cov_kernel, dim3(NCOV / 256), dim3(256), 0, sv, NCOV, cscale, crot, cout);
+				hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, sv, (size_t)NCOV * 6, (const uint32_t*)cout, (const uint32_t*)cref, bad);
 				nv++;
 			}
 			CK(hipStreamSynchronize(sv));
@@ -292,7 +344,8 @@ int main(int argc, char** argv)
 		CK(hipDeviceSynchronize());
 		uint32_t h[128];
 		CK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
-		printf("%-56s %10ld %12ld %8u loads %8u valu %8u trans %8u packed\n", c.name, nv, na, h[0], h[2], h[112], h[96]);
+		printf("%-56s %10ld %12ld %8u loads %8u valu %8u trans %8u packed %8u cov3d\n", c.name, nv, na, h[0], h[2], h[112], h[96], h[120]);
+		if (h[120]) printf("      cov3d word %u: got %08x want %08x\n", h[122], h[123], h[124]);
 		for (uint32_t i = 0; i < h[97] && i < 3; i++)
 			printf("      packed chain: lane %u block %u a0 %08x b0 %08x\n", h[100 + 4 * i], h[103 + 4 * i], h[101 + 4 * i], h[102 + 4 * i]);
 		for (uint32_t i = 0; i < h[113] && i < 3; i++)
