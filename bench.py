@@ -565,6 +565,51 @@ def main():
         deferred = extra_leg(args.variant, "default arithmetic, deferred counts (SGS_OPT_DEFER_COUNT, inference only): no host "
                                            "read-back inside the forward", defer=True)
         raster.set_blend_variant(args.variant)
+    consumer = None
+    if not args.no_extras and world == 1 and C % 128 == 0:
+        # what the reference does with the map (eval_segmentation.py:155-157), three ways
+        from sgs_hip import semantic
+        import channel_rasterization as chn
+        c = cams[0][0]
+        n_cls = 21   # ScanNet-20 prompts + "other"
+        text = torch.nn.functional.normalize(torch.randn(n_cls, C, device=dev, generator=torch.Generator(dev).manual_seed(7)), dim=1)
+        settings = chn.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=s.bg, scale_modifier=1.0,
+            viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+            prefiltered=False, debug=False, num_channels=C)
+        proj = semantic.project_features(s.features, text)
+        geo = (s.means3D, s.opacities, s.scales, s.rotations)
+
+        def ref_flow():
+            r = chn.GaussianRasterizer(settings)(means3D=s.means3D, means2D=torch.zeros_like(s.means3D), opacities=s.opacities,
+                                                 colors_precomp=s.features, scales=s.scales, rotations=s.rotations)[0]
+            r = r / (r.norm(dim=0, keepdim=True) + 1e-8)
+            return torch.einsum("cq,qhw->chw", text, r)
+
+        def timed(fn, n=12):
+            with torch.no_grad():
+                for _ in range(2):
+                    o = fn()
+                torch.cuda.synchronize(dev)
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+                for a, b in evs:
+                    a.record()
+                    o = fn()
+                    b.record()
+                torch.cuda.synchronize(dev)
+            ms = sorted(a.elapsed_time(b) for a, b in evs)
+            return ms[len(ms) // 2], o
+        t_ref, sim_ref = timed(ref_flow)
+        t_norm, sim_n = timed(lambda: semantic.render_similarity(settings, *geo, s.features, text, normalised=True, projected=proj))
+        t_log, _ = timed(lambda: semantic.render_similarity(settings, *geo, s.features, text, projected=proj))
+        consumer = {"what": f"per-view similarities with {n_cls} text embeddings (eval_segmentation.py:155-157), cfg3 scene",
+                    "reference_flow_ms": t_ref, "normalised_via_norm_plane_ms": t_norm, "unnormalised_logits_ms": t_log,
+                    "max_abs_diff_normalised_vs_reference_flow": float((sim_n - sim_ref).abs().max().item()),
+                    "note": "reference flow = render the (C,H,W) map with this library, then the reference's two torch lines; "
+                            "norm-plane flow = the n_cls-channel projected render + one more blend whose epilogue adds sum_c out^2 "
+                            "into an (H,W) plane instead of storing the map (SGS_OPT_NORM_PLANE)"}
+        del sim_ref, sim_n, proj, text
+        torch.cuda.empty_cache()
     if not args.no_extras and world == 1:
         for p in pools:
             p.clear()
@@ -682,6 +727,7 @@ def main():
             "exact_f32": exact,
             "two_term": two_term,
             "backward": backward,
+            "semantic_consumer": consumer,
             # the forward blend = blend_weights_kernel + blend_accum_sweep_kernel (one launch each);
             # SURVEY 8(d)'s algorithmic bytes are a property of the pair, so the roofline is quoted
             # on the pair; the per-kernel live durations are alongside (rocprof: profiles/).

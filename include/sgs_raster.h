@@ -258,7 +258,16 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * of the backward -- with this option it is folded into the backward's first kernel (the work-list pre-pass, which
  * is instruction bound and leaves the memory system idle): -0.2 ms at 1M x 512 x 968x1296. */
 #define SGS_OPT_BWD_CLEARS_DCOLOR 6
-#define SGS_OPT_COUNT 7
+/* 1: the NEXT forward on this stream (ONE call, like SGS_OPT_OUT_PITCH) renders the per-pixel squared L2 norm of the
+ * feature map instead of the feature map: out_color is then ONE (H, pitch) plane of floats that receives
+ * sum_c out[c]^2 (the library clears it; summation order over the channel groups is not fixed, so the last bits may
+ * differ between runs).  This is the only quantity the reference's consumer needs from the full map beyond the
+ * similarities themselves (eval_segmentation.py:155: rendering / (rendering.norm(dim=0) + 1e-8)); rendering it this
+ * way saves the C * H * W * 4 bytes of stores (2.57 GB at 512 x 968 x 1296) and the caller's read of them.
+ * Needs num_channels % 128 == 0, no depth plane and the default blend (variants 0 / 15); SGS_EINVAL otherwise.
+ * The work list is laid out for its worst case in such a call (there is no room for the overflow fallback). */
+#define SGS_OPT_NORM_PLANE 7
+#define SGS_OPT_COUNT 8
 /* value < 0 removes the override (the stream follows the process default again).  Returns the previous override,
  * or 0x7fffffff if there was none. */
 int sgs_stream_set_option(void *stream, int option, int value);

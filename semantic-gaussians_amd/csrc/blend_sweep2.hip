@@ -573,6 +573,24 @@ __device__ __forceinline__ void s2_store_single(float* bp, size_t HW, bool ok)
 		if (ok) bp[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = v[r];
 }
 
+// NORM mode (the per-pixel L2 norm the reference's consumer divides by, eval_segmentation.py:155): the
+// feature map is NOT written; every finished accumulator block adds, per pixel, the sum of the squares of this wave's 32
+// channels into an (H, W) plane.  Block register r of lane l is channel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of pixel
+// l & 31: sixteen squares per lane, the two channel halves meet through ds_bpermute, lanes 0-31 issue the atomic.
+template <int BLK>
+__device__ __forceinline__ void s2_norm_block(float* plane, int PW, int W, int H, int x0, int yb, int l31, int lane)
+{
+	float v[16];
+	acc_read<BLK, true>(v);
+	float ss = 0.f;
+#pragma unroll
+	for (int r = 0; r < 16; r++) ss = __builtin_fmaf(v[r], v[r], ss);
+	const float other = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane ^ 32) << 2), __builtin_bit_cast(int, ss)));
+	ss += other;
+	const int x = x0 + (l31 & 15), y = yb + 2 * ((l31 >> 4) & 1);
+	if (lane < 32 && x < W && y < H) atomicAdd(plane + (size_t)y * PW + x, ss);
+}
+
 } // namespace
 
 enum { S2_EXACT = 0, S2_X6 = 1, S2_X6W = 2, S2_X6S = 3, S2_X6P = 4, S2_X6PW = 5 };   // X6PW: X6P on v_mfma_f32_32x32x16_bf16   // X6P: weights pre-split by the weights kernel   // X6S: the six products block by block (the first form; A/B)
@@ -807,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 		}                                                                                            \
 	} while (0)
 
+	constexpr bool NORM = (DBG & 32) != 0;   // sum-of-squares plane instead of the feature map
 	const bool skip_stores = (DBG & 1) != 0;
 	constexpr int SMODE = (DBG & 4) ? 2 : ((DBG & 8) ? 1 : 0);
 	const uint32_t wdelta = (((uint32_t)(lane >> 3) * (uint32_t)HW + 4u * (uint32_t)(lane & 7)) - ((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)l31)) * 4u;
@@ -856,9 +875,18 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	const int hi = (l31 >> 4) & 1;
 
 // the half rows of a tile with no partner in this segment (64-B pieces), blocks b0_..b3_ of tile column tx_
+#define S2_NORM_TILE(b0_, b1_, b2_, b3_, tx_)                                                        \
+	do {                                                                                             \
+		s2_norm_block<b0_>(out, PW, W, H, (tx_) * SGS_TILE, y0, l31, lane);                          \
+		s2_norm_block<b1_>(out, PW, W, H, (tx_) * SGS_TILE, y0 + 4, l31, lane);                      \
+		s2_norm_block<b2_>(out, PW, W, H, (tx_) * SGS_TILE, y0 + 8, l31, lane);                      \
+		s2_norm_block<b3_>(out, PW, W, H, (tx_) * SGS_TILE, y0 + 12, l31, lane);                     \
+	} while (0)
 #define S2_STORE_SINGLE(b0_, b1_, b2_, b3_, tx_)                                                     \
 	do {                                                                                             \
-		if (!skip_stores) {                                                                          \
+		if (NORM) {                                                                                  \
+			S2_NORM_TILE(b0_, b1_, b2_, b3_, tx_);                                                   \
+		} else if (!skip_stores) {                                                                   \
 			const int xs_ = (tx_) * SGS_TILE + (l31 & 15);                                           \
 			float* p_ = out + (size_t)(c0 + 4 * half) * HW + (size_t)(y0 + 2 * hi) * PW + xs_;        \
 			s2_store_single<b0_>(p_, HW, xs_ < W && y0 + 2 * hi < H);                                 \
@@ -878,7 +906,11 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	do {                                                                                             \
 		const int xp_ = ((tx_) - 1) * SGS_TILE + l31;                                                \
 		const bool inside_ = ((tx_) + 1) * SGS_TILE <= W && y0 + 14 < H;   /* (uniform) */           \
-		if (skip_stores) {                                                                           \
+		if (NORM) {                                                                                  \
+			S2_NORM_TILE(LB(M_, 0), LB(M_, 1), LB(M_, 2), LB(M_, 3), (tx_) - 1);                     \
+			S2_NORM_TILE(RB(M_, 0), RB(M_, 1), RB(M_, 2), RB(M_, 3), tx_);                           \
+			S2_ZERO_ALL();                                                                           \
+		} else if (skip_stores) {                                                                    \
 			S2_ZERO_ALL();                                                                           \
 		} else if (inside_) {                                                                        \
 			const uint32_t o0_ = ((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)(y0 * PW + xp_)) * 4u; \
@@ -928,6 +960,19 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	}
 }
 
+__global__ void norm_plane_background_kernel(float* __restrict__ plane, size_t n, const float* __restrict__ bg, int C)
+{
+	float ss = 0.f;
+	for (int c = 0; c < C; c++) ss = __builtin_fmaf(bg[c], bg[c], ss);
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) plane[i] = ss;
+}
+
+hipError_t launch_norm_plane_background(hipStream_t st, float* plane, size_t n, const float* bg, int C)
+{
+	hipLaunchKernelGGL(norm_plane_background_kernel, dim3(1024), dim3(256), 0, st, plane, n, bg, C);
+	return hipGetLastError();
+}
+
 hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
@@ -939,6 +984,7 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 			   pxcd, items, a.pitch, trace, order, dealt)
 	if (arith == S2_EXACT) {
 		if (dbg == 1) S2_LAUNCH(S2_EXACT, 1);
+		else if (dbg == 32) S2_LAUNCH(S2_EXACT, 32);
 		else if (dbg == 2) S2_LAUNCH(S2_EXACT, 2);
 		else S2_LAUNCH(S2_EXACT, 0);
 	} else if (arith == S2_X6W) {
@@ -957,6 +1003,7 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 		else if (dbg == 8) S2_LAUNCH(S2_X6P, 8);
 		else if (dbg == 6) S2_LAUNCH(S2_X6P, 6);
 		else if (dbg == 10) S2_LAUNCH(S2_X6P, 10);
+		else if (dbg == 32) S2_LAUNCH(S2_X6P, 32);
 		else S2_LAUNCH(S2_X6P, 0);
 	} else if (arith == S2_X6S) {
 		if (dbg == 1) S2_LAUNCH(S2_X6S, 1);

@@ -559,6 +559,11 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// stale pitch on a later forward with a contiguous buffer would be an out-of-bounds write)
 	const int out_pitch_opt = cx->option(SGS_OPT_OUT_PITCH);
 	cx->opt[SGS_OPT_OUT_PITCH] = -1;
+	// SGS_OPT_NORM_PLANE, consumed the same way: out_color is ONE (H, pitch) plane that receives sum_c out[c]^2
+	const bool norm_plane = cx->option(SGS_OPT_NORM_PLANE) > 0;
+	cx->opt[SGS_OPT_NORM_PLANE] = -1;
+	if (norm_plane && (num_channels % 128 != 0 || out_depth))
+		return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs a multiple of 128 channels and no depth plane");
 	StageTimer tm(cx->option(SGS_OPT_STAGE_TIMING), st);
 
 	const GeomLayout gl = geom_layout(P);
@@ -726,6 +731,11 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		// a tile can never need more than its list length rounded up to whole chunks
 		arena_max = (uint64_t)L + 128ull * (uint64_t)ntiles;
 		arena_cap = (uint64_t)hint < arena_max ? hint : (uint32_t)arena_max;
+		// the norm plane has no room for the overflow fallback's feature map: lay the work list out for the worst case
+		if (norm_plane) {
+			if (arena_max >> 32) return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE: frame too large for a worst-case work list");
+			arena_cap = (uint32_t)arena_max;
+		}
 	}
 	const BinLayout bl = bin_layout(L, sort_bits, arena_cap, ntiles, Rrows, gx, gy, P);
 	char* bchunk = (char*)binning_buffer(binning_user, bl.total);
@@ -809,6 +819,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.abort = abort_word;
 	a.usage_host = nullptr;
 	a.counter_reset_done = counter_reset_done;
+	a.norm_plane = norm_plane;
 	if (a.pitch < width) return fail(SGS_EINVAL, "output pitch smaller than the image width");
 #ifdef SGS_WITH_FUSED
 	if (want_fused && (variant & 0xff) >= 34 && sgs::blend_forward_fused_pc_eligible(a)) {
@@ -819,12 +830,24 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		e = sgs::launch_blend_forward_fused(st, a, (variant & 0xff) == 33, ((variant >> 8) & 15) * 2);
 	} else
 #endif
-	if (use_split) {
+	if (norm_plane && (!use_split || want_fused)) {
+		// nothing rendered (L == 0) -> every pixel is the background: sum_c bg[c]^2; any other reason is a variant
+		// that has no norm epilogue
+		if (L > 0) return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs the default blend (variants 0 / 15)");
+		tm.mark();
+		e = sgs::launch_norm_plane_background(st, out_color, (size_t)height * a.pitch, background, num_channels);
+	} else if (use_split) {
 		char* arena = bchunk + bl.arena;
 		// accumulate arithmetic (low nibble of the sweep word, blend_fwd_split.hip): default 14 = six bf16 products of the exact
 		// three-term splits on the x8 MFMA ("f32-equivalent", blend_sweep2.hip); variant 15 = 11 = fp32-input MFMA, bit-identical;
 		// variant 14 = 8 = round 2's two-term split (three products, 3 * 2^-16 per term: the fastest, not fp32-class)
 		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : 14));
+		if (norm_plane) {
+			if ((split_word & 15) != 14 && (split_word & 15) != 11)
+				return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs the default blend (variants 0 / 15)");
+			e = hipMemsetAsync(out_color, 0, (size_t)height * a.pitch * sizeof(float), st);
+			if (e != hipSuccess) return fail_hip(e, "memset (norm plane)");
+		}
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
 		const bool can_report = cx->ensure(cx->usage_host, cx->usage_ev);
 		a.usage_host = can_report ? cx->usage_host : nullptr;

@@ -94,6 +94,7 @@ struct BlendFwdArgs {
 	const uint32_t* abort;       // optional device word: != 0 -> every blend kernel exits (deferred-count forward, capi.hip)
 	uint32_t* usage_host;        // optional pinned {work-list slots requested, overflow flag}: written by the sweep plan kernel
 	bool counter_reset_done;     // the work-list counter was already reset (launch_row_binning): no arena_reset_kernel
+	bool norm_plane;             // SGS_OPT_NORM_PLANE: `out` is an (H, pitch) plane that receives sum_c out[c]^2 (atomics), no feature map
 };
 // gate: optional device word; when non-null the 128-channel-aligned kernels exit unless
 // *gate != 0 (used as the arena-overflow fallback of the split path).
@@ -121,6 +122,8 @@ hipError_t launch_blend_weights2(hipStream_t st, int mode, const uint2* ranges, 
 
 // ---- blend_sweep2.hip: the accumulate sweep in fp32-class arithmetic (arith: 0 = exact fp32 MFMA, 1 = six bf16 products,
 // 2 = the same on the x16 MFMA), LDS-polled DMA arrival, stores spread over the next tile; takes fp32 weight rows
+// SGS_OPT_NORM_PLANE with nothing to blend: plane[i] = sum_c bg[c]^2
+hipError_t launch_norm_plane_background(hipStream_t st, float* plane, size_t n, const float* bg, int C);
 hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,

@@ -202,10 +202,12 @@ def rasterize_forward_deferred(*args, **kwargs):
 def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                       image_width, sh, degree, campos, prefiltered, debug, num_channels,
-                      want_depth, pool=None):
+                      want_depth, pool=None, norm_plane=False):
     """RasterizeGaussiansCUDA (CR/rasterize_points.cu:38-121; RR variant returns depth too).
     Returns (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth).
-    pool: optional ScratchPool for the three state buffers (inference; see ScratchPool)."""
+    pool: optional ScratchPool for the three state buffers (inference; see ScratchPool).
+    norm_plane: out_color is the (H,W) plane sum_c render[c]^2 instead of the (C,H,W) render (SGS_OPT_NORM_PLANE,
+    include/sgs_raster.h; C % 128 == 0, inference only)."""
     lib = _lib.load()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -220,15 +222,18 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         depth = None
         if P == 0:
             # reference returns zero-filled outputs without touching bg (rasterize_points.cu:85)
-            color = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
+            color = torch.zeros((H, W) if norm_plane else (Cn, H, W), dtype=torch.float32, device=dev)
             if want_depth:
                 depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
             bufs.release()
             return 0, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
         pitch = W
-        if OUTPUT_PITCH_ALIGN > 1 and W % OUTPUT_PITCH_ALIGN and Cn >= 128 and not want_depth:
+        if norm_plane:
+            if Cn % 128 or want_depth:
+                raise RuntimeError("norm_plane needs a multiple of 128 channels and no depth plane")
+        elif OUTPUT_PITCH_ALIGN > 1 and W % OUTPUT_PITCH_ALIGN and Cn >= 128 and not want_depth:
             pitch = -(-W // OUTPUT_PITCH_ALIGN) * OUTPUT_PITCH_ALIGN
-        color = torch.empty(Cn, H, pitch, dtype=torch.float32, device=dev)   # fully overwritten
+        color = torch.empty((H, W) if norm_plane else (Cn, H, pitch), dtype=torch.float32, device=dev)   # fully overwritten
         if want_depth:
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
 
@@ -252,11 +257,15 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         try:
             if pitch != W:
                 lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, pitch)
+            if norm_plane:
+                lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_NORM_PLANE, 1)
             rc = lib.sgs_rasterize_forward(*args)
         finally:
             bufs.release()
             if pitch != W:
                 lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, -1)
+            if norm_plane:
+                lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_NORM_PLANE, -1)
         if pitch != W:
             color = color[:, :, :W]
         num_rendered = _lib.check(rc, "rasterize_gaussians failed")

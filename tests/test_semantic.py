@@ -67,3 +67,64 @@ def test_render_logits_matches_reference_consumer(orc):
     assert margin.numel() == 0 or float(margin.max()) < 1e-4      # only near-ties can differ
     assert float((sim_norm.cpu() - sim_ref).abs().max()) < 1e-4   # the normalised values path
     assert np.array_equal(radii.cpu().numpy(), oracle_forward(orc, scene, cam)["radii"])
+
+
+def _settings(cr, c, s, W, H, C):
+    return cr.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=s.bg, scale_modifier=1.0,
+        viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+        prefiltered=False, debug=False, num_channels=C)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,W,H,P,exact", [(128, 208, 128, 3000, False), (256, 203, 117, 5000, False),
+                                           (512, 330, 90, 2500, True)])
+def test_norm_plane_is_the_squared_norm_of_the_render(orc, C, W, H, P, exact):
+    """SGS_OPT_NORM_PLANE: the (H,W) plane sum_c render[c]^2 without the render -- vs the oracle's feature map
+    (ragged widths / heights, several channel groups adding into the same pixels, a non-zero background)."""
+    from sgs_hip import raster, semantic
+    import channel_rasterization as cr
+    dev = "cuda:0"
+    scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=170.0, seed=43 + C)
+    scene = scene._replace(bg=torch.linspace(-0.3, 0.4, C))
+    s, c = scene.to(dev), cam.to(dev)
+    settings = _settings(cr, c, s, W, H, C)
+    prev = raster.set_blend_variant(15 if exact else 0)
+    try:
+        n2 = semantic.render_norm2(settings, s.means3D, s.opacities, s.scales, s.rotations, s.features)
+        # the option was consumed: the next forward on the stream renders the map again
+        full_gpu, _ = cr.GaussianRasterizer(settings)(means3D=s.means3D, means2D=torch.zeros_like(s.means3D), opacities=s.opacities,
+                                                      colors_precomp=s.features, scales=s.scales, rotations=s.rotations)
+    finally:
+        raster.set_blend_variant(prev)
+    assert n2.shape == (H, W) and full_gpu.shape == (C, H, W)
+    full = torch.from_numpy(oracle_forward(orc, scene, cam)["out"]).double()
+    want = (full * full).sum(dim=0)
+    got = n2.cpu().double()
+    assert float(((got - want).abs() / (want + 1e-6)).max()) < 2e-5      # fp32 squares and sums of C terms
+    mine = (full_gpu.double() ** 2).sum(dim=0).cpu()
+    assert float(((got - mine).abs() / (mine + 1e-6)).max()) < 2e-6      # the same render, summed here instead
+
+
+@pytest.mark.gpu
+def test_norm_plane_with_nothing_rendered_and_bad_arguments():
+    from sgs_hip import raster, semantic
+    import channel_rasterization as cr
+    dev = "cuda:0"
+    C, W, H = 128, 64, 48
+    scene, cam = small_scene(P=200, C=C, W=W, H=H, fx=60.0, seed=5)
+    scene = scene._replace(bg=torch.linspace(0.1, 0.9, C))
+    s, c = scene.to(dev), cam.to(dev)
+    behind = s.means3D.clone()
+    behind[:, 2] = -5.0 - behind[:, 2].abs()      # nothing in front of the camera: num_rendered == 0
+    far = torch.einsum("ij,nj->ni", c.world_view_transform.t()[:3, :3], behind) + c.world_view_transform.t()[:3, 3]
+    if float(far[:, 2].max()) > 0.2:
+        behind = -s.means3D
+    n2 = semantic.render_norm2(_settings(cr, c, s, W, H, C), behind, s.opacities, s.scales, s.rotations, s.features)
+    want = float((scene.bg.double() ** 2).sum())
+    vis = raster.mark_visible(behind, c.world_view_transform, c.full_proj_transform)
+    if not bool(vis.any()):
+        assert torch.allclose(n2.cpu().double(), torch.full((H, W), want, dtype=torch.float64), rtol=1e-6)
+    with pytest.raises(RuntimeError):
+        semantic.render_norm2(_settings(cr, c, s, W, H, 96), s.means3D, s.opacities, s.scales, s.rotations,
+                              s.features[:, :96].contiguous())
