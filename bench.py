@@ -60,6 +60,7 @@ os.environ.setdefault("PYTORCH_CUDA_ALLOC_CONF", os.environ["PYTORCH_HIP_ALLOC_C
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+EXTRA_TIMEOUT_S = float(os.environ.get("SGS_BENCH_EXTRA_TIMEOUT_S", "240"))   # configs 4 / 5 (bench.py --extra-configs, on by default when --gpus > 1)
 HBM_PEAK = 8.0e12        # MI355X spec (MI355X_MICROARCH.md "Chip-level parameters")
 FP32_FMA_PEAK = 157.3e12  # fp32 vector (= fp32-input MFMA) peak, same table
 BF16_MFMA_PEAK = 2.5e15   # dense bf16 MFMA peak
@@ -657,16 +658,10 @@ def main():
         del dL
         torch.cuda.empty_cache()
 
-    extra_cfgs = None
-    if args.extra_configs or world > 1:
-        # free the headline's residents first (scene features 2 GB, pools): configs 4 / 5 bring 15 / 51 GB of their own
-        for p in pools:
-            p.clear()
-        raster.INFERENCE_POOL.clear()
-        torch.cuda.empty_cache()
-        extra_cfgs = extra_config_legs(rank, world, dev, dist if world > 1 else None)
-        if rank == 0:
-            log("extra configs: " + json.dumps(extra_cfgs)[:600])
+    for p in pools:   # (the headline's residents are no longer needed)
+        p.clear()
+    raster.INFERENCE_POOL.clear()
+    torch.cuda.empty_cache()
     if rank == 0:
         log(f"P_vis={p_vis} L={num_rendered} tile-list mean/max={lens.mean().item():.1f}/"
             f"{int(lens.max().item())} sum_n_t_eff={sum_neff} (mean {sum_neff / tiles:.1f}/tile) "
@@ -754,7 +749,7 @@ def main():
                               "single_view_frac_of_hbm_peak": (bytes_blend + bytes_front) / (sv_default["ms_median"] * 1e-3) / HBM_PEAK},
             "stage_ms": dict(zip(STAGES, [round(v, 4) for v in stage_ms])),
             "stage_ms_timed_region": dict(zip(STAGES, [round(v, 4) for v in stage_ms_timed])),
-            "multi_gpu_configs": extra_cfgs,
+            "multi_gpu_configs": None,
             "integrity": {"forwards_checked": args.steps * V, "num_rendered_mismatches_vs_serial": mismatches,
                           "deferred_retries": retries},
             "workload_stats": {"P_vis": p_vis, "num_rendered": num_rendered, "sum_n_t_eff": sum_neff,
@@ -765,6 +760,27 @@ def main():
             log("cpu_baseline: " + res["cpu_baseline"]["sample"])
             res["cpu_baseline_port"] = cpu_baseline_port(scene, cam, C, W, H, n_eff_host)
             log("cpu_baseline_port: " + res["cpu_baseline_port"]["sample"])
+    if args.extra_configs or world > 1:
+        # BASELINE configs 4 / 5 on this job's ranks, AFTER the line above is complete and under a watchdog: the RCCL band
+        # exchange of config 5 has never run on more than one GPU (this pool hands out single-GPU boxes), and a collective
+        # that hangs must not cost the job its headline -- after EXTRA_TIMEOUT_S rank 0 prints the line without them
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if finished.wait(EXTRA_TIMEOUT_S):
+                return
+            if rank == 0:
+                res["multi_gpu_configs"] = {"error": f"configs 4 / 5 did not finish within {EXTRA_TIMEOUT_S} s; the rest of the line is complete"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        extra_cfgs = extra_config_legs(rank, world, dev, dist if world > 1 else None)
+        finished.set()
+        if rank == 0:
+            log("extra configs: " + json.dumps(extra_cfgs)[:600])
+            res["multi_gpu_configs"] = extra_cfgs
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
