@@ -195,7 +195,7 @@ def cpu_baseline_pytorch(scene, cam, C, W, H, n_eff, budget_s=10.0):
                         f"sum n_t_eff ({work * 100:.2f} % of the frame's list work) -> {t_frame:.1f} s/frame"))
 
 
-def extra_config_legs(rank, world, dev, dist):
+def extra_config_legs(rank, world, dev, dist, red_dev=None):
     """BASELINE configs 4 and 5 on this job's ranks.  Returns a dict for the JSON line; never raises."""
     import traceback
     from sgs_hip import raster, dist as sdist
@@ -210,13 +210,14 @@ def extra_config_legs(rank, world, dev, dist):
 
     def max_over_ranks(t):
         if world > 1:
-            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            tt = torch.tensor([t], device=red_dev if red_dev is not None else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         return t
     # ---- config 4: 5M Gaussians x 768 channels, 840x1297, 8 views on a ring sharded round-robin, scene replicated
     try:
         P, C, W, H, fx = CONFIGS["cfg4"]
+        log(f"[rank {rank}] config 4: generating the scene")
         scene = make_scene(P, C, W, H, fx, seed=4, features=False)
         s = scene.to(dev)
         g = torch.Generator(device=dev).manual_seed(44)
@@ -261,6 +262,7 @@ def extra_config_legs(rank, world, dev, dist):
     # image-partitioned point-to-point exchange over RCCL, one composite kernel per band
     try:
         P, C, W, H, fx = CONFIGS["cfg5"]
+        log(f"[rank {rank}] config 4 done; config 5: generating the scene")
         scene = make_scene(P, C, W, H, fx, seed=5, features=False)   # every rank: the same geometry (2.2 GB on the host)
         order = torch.argsort(scene.means3D[:, 2])                   # camera at the origin looking down +z
         idx = order[rank * P // world:(rank + 1) * P // world]
@@ -281,7 +283,9 @@ def extra_config_legs(rank, world, dev, dist):
             A, T, _ = raster.render_partial(sh[0], feats, sh[1], sh[2], sh[3], cam.world_view_transform, cam.full_proj_transform,
                                             cam.tanfovx, cam.tanfovy, H, W, cam.camera_center, pool=pool)
             return A, T
+        log(f"[rank {rank}] config 5: slab of {n_loc} Gaussians resident, first frame")
         band = sdist.render_gaussian_sharded(partial, bg, all_gather=False)
+        log(f"[rank {rank}] config 5: first frame done")
         frames = 4
         barrier()
         t0 = time.perf_counter()
@@ -340,13 +344,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # SGS_BENCH_TEST_ONE_DEVICE=1 (test hook, never set by the driver): every rank on cuda:0 and gloo for the control
+    # collectives, so that the N > 1 control flow can be exercised on a single-GPU box (RCCL refuses two ranks per device)
+    one_dev = os.environ.get("SGS_BENCH_TEST_ONE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if one_dev else local_rank)
     torch.cuda.set_device(dev)
+    red_dev = torch.device("cpu") if one_dev else dev   # where the scalars of the control collectives live
     rccl = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         names = [None] * world
         dist.all_gather_object(names, f"rank{rank}:cuda{local_rank}:{torch.cuda.get_device_name(dev)}")
         rccl = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "devices": names}
@@ -453,7 +464,7 @@ def main():
         gc.enable()
         retries = deferred_retries() - retries0
         if world > 1:
-            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            tt = torch.tensor([t], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         per = [b - a for a, b in zip([t0] + marks[:-1], marks)]
@@ -775,7 +786,7 @@ def main():
                 print(json.dumps(res), flush=True)
             os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
-        extra_cfgs = extra_config_legs(rank, world, dev, dist if world > 1 else None)
+        extra_cfgs = extra_config_legs(rank, world, dev, dist if world > 1 else None, red_dev)
         finished.set()
         if rank == 0:
             log("extra configs: " + json.dumps(extra_cfgs)[:600])

@@ -41,3 +41,22 @@ def test_gaussian_sharded_render_over_rccl_two_gpus():
                         os.path.join(ROOT, "tools", "run_gaussian_sharded.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GAUSSIAN_SHARDED_OK" in r.stdout
+
+
+def test_bench_two_ranks_control_flow_on_one_device():
+    """bench.py --gpus 2 end to end on ONE device (test hook SGS_BENCH_TEST_ONE_DEVICE: both ranks on cuda:0, gloo for the
+    control collectives): rank spawn, rendezvous on 127.0.0.1, barriers, max-over-ranks timing, the aggregate value, one
+    JSON line from rank 0 -- and the watchdog that prints the line when configs 4 / 5 do not finish in time."""
+    import json
+    env = dict(os.environ, SGS_BENCH_TEST_ONE_DEVICE="1", SGS_BENCH_EXTRA_TIMEOUT_S="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["rccl"]["ranks_seen"] == 2
+    assert d["integrity"]["num_rendered_mismatches_vs_serial"] == 0
+    assert "error" in d["multi_gpu_configs"]      # the 1 s watchdog fired; everything else is complete
+    assert abs(d["value"] - 2 * d["config"]["views_per_step_per_gpu"] * 968 * 1296 * 512 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
