@@ -118,3 +118,19 @@ def test_sweep2_deterministic_under_load(orc):
         bad += int(not torch.equal(out, ref))
     torch.cuda.synchronize()
     assert bad == 0
+
+
+@pytest.mark.parametrize("variant", [0, V_EXACT, V_X6P, 14])
+def test_feature_scale_invariance_is_bit_exact(variant):
+    """A size-independent property of every accumulate arithmetic: scaling the features and the background by a power of two
+    scales the feature map by exactly that power of two (roundings commute with 2^k away from over / underflow) -- for the
+    fp32 chain, for the three-term bf16 splits (split3(2^k x) = 2^k split3(x)) and for the two-term split.  A term that
+    lost bits on the way (a non-exact split, a flushed residual) would break the identity."""
+    scene, cam = small_scene(P=5000, C=256, W=208, H=96, fx=170.0, seed=91)
+    g = torch.Generator().manual_seed(4)
+    scene = scene._replace(bg=torch.randn(256, generator=g))
+    base = _hip_forward(scene, cam, variant=variant)[1]
+    for k in (-60, -7, 9, 70):
+        s2 = scene._replace(features=scene.features * 2.0 ** k, bg=scene.bg * 2.0 ** k)
+        out = _hip_forward(s2, cam, variant=variant)[1]
+        assert torch.equal(out, base * 2.0 ** k), k
