@@ -515,7 +515,8 @@ def main():
         return dict(value=H * W * C / (med * 1e-3) / 1e9, unit="Gpixel*channels/s", ms_median=med, ms_min=ms[0], forwards=n,
                     call="channel_rasterization.GaussianRasterizer(settings)(means3D, means2D, opacities, colors_precomp, scales, "
                          "rotations) under torch.no_grad(), nn.Parameter inputs, debug=True (model/renderer.py:169-185,228), "
-                         "one view, blocking num_rendered read-back, output + radii allocated per call",
+                         "one view, output + radii allocated per call; the host waits for num_rendered before the call returns, after the "
+                         "whole frame was enqueued against the stream's capacity guess (sgs_hip.api.SPECULATIVE_COUNT, inference only)",
                     out_shape=list(out_[0].shape))
     api = api_path() if world == 1 or rank == 0 else None
     if api is not None:
@@ -563,7 +564,7 @@ def main():
     kx = max(8, min(args.steps, 60))
 
     def extra_leg(variant, what, defer=None):
-        sv, stg = single_view(variant)
+        sv, stg = single_view(variant, deferred=bool(defer))
         ms_e, ms_e_med, mism_e, out_e, retr = in_flight(variant, kx, 3, defer=defer)
         del out_e
         return {"arithmetic": what, "value": world * V * H * W * C / (ms_e * 1e-3) / 1e9, "unit": "Gpixel*channels/s",

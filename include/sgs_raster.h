@@ -249,7 +249,8 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * the outputs AND before the next forward on the same stream (the context keeps one pending record per stream):
  * 0 = valid (and the true num_rendered), SGS_ERETRY = render that frame again (the guess has grown).
  * One host thread can so keep several streams full: 1M Gaussians x 512 channels, 4 views in flight:
- * see DESIGN.md 7.  Binning mode 0 only; ignored under debug; not for frames that will be differentiated (the
+ * see DESIGN.md 7.  Binning mode 0 only; under debug the frame is still synchronised once at the end of the call
+ * (ignored altogether with SGS_DEBUG_SYNC_EVERY_STAGE=1); not for frames that will be differentiated (the
  * backward locates the lists from num_rendered).  2: as 1 with a capacity no frame fits (tests). */
 #define SGS_OPT_DEFER_COUNT 5
 /* 1: sgs_rasterize_backward clears dL_dcolor itself (the caller may pass uninitialised memory).  The reference's

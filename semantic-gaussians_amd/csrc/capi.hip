@@ -631,7 +631,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	SGS_CHECK_STAGE("inclusive scan");
 
 	// The instance counts.  Default: the one blocking read-back of the forward (rasterizer_impl.cu:283).
-	// SGS_OPT_DEFER_COUNT (binning mode 0, not under debug): nothing is read back.  The buffers and grids are sized
+	// SGS_OPT_DEFER_COUNT (binning mode 0; not with debug + SGS_DEBUG_SYNC_EVERY_STAGE): nothing is read back.  The buffers and grids are sized
 	// from this stream's capacity guesses (1.25 x what its previous frame needed), the true counts are checked
 	// against them on the device (count_check_kernel: a frame that does not fit aborts itself), copied to a pinned
 	// record and reported by sgs_forward_result().  The host never waits for the GPU inside the call, so one host
@@ -647,7 +647,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		cx->count_pending = false;
 	}
 	(void)hipGetLastError();
-	const bool defer = defer_opt > 0 && rows && !debug && (defer_opt == 2 || (cx->L_hint > 0 && cx->R_hint > 0)) &&
+	const bool defer = defer_opt > 0 && rows && !(debug && g_sync_every_stage) && (defer_opt == 2 || (cx->L_hint > 0 && cx->R_hint > 0)) &&
 			   cx->ensure(cx->count_host, cx->count_ev);
 	uint32_t L = 0, Rrows = 0;
 	const uint32_t* abort_word = nullptr;
@@ -871,7 +871,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	}
 	if (e != hipSuccess) return fail_hip(e, "blend forward");
 	SGS_CHECK_STAGE("blend forward");
-	if (debug && !g_sync_every_stage && !defer) {   // one synchronisation for the whole call (see SGS_CHECK_STAGE)
+	if (debug && !g_sync_every_stage) {   // one synchronisation for the whole call (see SGS_CHECK_STAGE); also of a deferred frame
 		const hipError_t es = hipStreamSynchronize(st);
 		if (es != hipSuccess) return fail_hip(es, "forward (debug: asynchronous error; SGS_DEBUG_SYNC_EVERY_STAGE=1 names the stage)");
 	}

@@ -19,7 +19,13 @@ from typing import NamedTuple
 import torch
 import torch.nn as nn
 
+import os
+
 from . import raster
+
+# no_grad / no input requires grad: enqueue the whole frame before waiting for num_rendered (see _RasterizeGaussians.forward).
+# SGS_SPECULATIVE_COUNT=0 restores the wait in the middle of the frame.
+SPECULATIVE_COUNT = os.environ.get("SGS_SPECULATIVE_COUNT", "1") not in ("", "0")
 
 
 class ChannelRasterizationSettings(NamedTuple):
@@ -86,8 +92,16 @@ def _make_function(with_depth):
             # (fusion.py / eval_segmentation.py pass nn.Parameters under torch.no_grad()).
             pool = None if track else raster.INFERENCE_POOL
             try:
-                (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer,
-                 depth) = raster.rasterize_forward(*call, want_depth=with_depth, pool=pool)
+                if not track and SPECULATIVE_COUNT:
+                    # inference: the host still learns num_rendered before the call returns (the reference's blocking
+                    # read-back, rasterizer_impl.cu:283), but the GPU is not left idle while it does: the frame is
+                    # enqueued in full against the stream's capacity guess, then the host waits for the counts only
+                    # (a frame that outgrew the guess is rendered again; bit-identical results)
+                    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth) = \
+                        raster.rasterize_forward_deferred(*call, want_depth=with_depth, pool=pool).result()
+                else:
+                    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer,
+                     depth) = raster.rasterize_forward(*call, want_depth=with_depth, pool=pool)
             except Exception:
                 if s.debug and _snapshot(call, "snapshot_fw.dump"):
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")

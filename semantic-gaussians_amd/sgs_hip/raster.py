@@ -186,9 +186,13 @@ class DeferredForward:
 def rasterize_forward_deferred(*args, **kwargs):
     """rasterize_forward without the host waiting for the GPU: -> DeferredForward.  The first frame of a stream is an
     ordinary (blocking) forward -- it is where the capacity guesses come from."""
+    lib = _lib.load()
+    if args[1].ndimension() != 2 or args[1].size(1) != 3:   # (rasterize_forward's own checks, in its order)
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not args[1].is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor (there is no CPU path)")
     dev = args[1].device
     stream = torch.cuda.current_stream(dev)
-    lib = _lib.load()
     sp = C.c_void_p(stream.cuda_stream)
     with torch.cuda.device(dev):
         prev = lib.sgs_stream_set_option(sp, _lib.OPT_DEFER_COUNT, int(kwargs.pop("_defer_mode", 1)))

@@ -491,6 +491,42 @@ def test_no_grad_with_parameters_uses_the_resident_pool():
     assert feats.grad is not None
 
 
+def test_inference_calls_enqueue_the_frame_before_waiting_for_the_count(orc):
+    """sgs_hip.api.SPECULATIVE_COUNT: under no_grad the drop-in module enqueues the whole frame against the stream's
+    capacity guess and only then waits for num_rendered.  Same results as the tracked (classic) path bit for bit --
+    also for a frame that outgrew the guess (rendered again) and with debug=True (model/renderer.py:181)."""
+    import channel_rasterization as chn
+    from sgs_hip import raster, api, _lib
+    assert api.SPECULATIVE_COUNT
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        small, cam = small_scene(P=300, C=128, W=160, H=96, fx=120.0, seed=3)
+        big, _ = small_scene(P=9000, C=128, W=160, H=96, fx=120.0, seed=4)
+        big = big._replace(scales=big.scales * 2.5)
+        c = cam.to(DEV)
+        for debug in (False, True):
+            settings = chn.GaussianRasterizationSettings(
+                image_height=96, image_width=160, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=small.bg.to(DEV), scale_modifier=1.0,
+                viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+                prefiltered=False, debug=debug, num_channels=128)
+            rast = chn.GaussianRasterizer(settings)
+            retries0 = raster.stream_stat(_lib.STAT_DEFERRED_RETRIES)
+            deferred0 = raster.stream_stat(_lib.STAT_DEFERRED_FORWARDS)
+            for scene in (small, small, big, big, small):
+                s = scene.to(DEV)
+                kw = dict(means3D=s.means3D, means2D=torch.zeros_like(s.means3D), opacities=s.opacities,
+                          colors_precomp=s.features, scales=s.scales, rotations=s.rotations)
+                with torch.no_grad():
+                    color, radii = rast(**kw)
+                tracked = dict(kw, colors_precomp=s.features.clone().requires_grad_(True))
+                color_t, radii_t = rast(**tracked)
+                assert torch.equal(color, color_t.detach()) and torch.equal(radii, radii_t)
+                assert np.array_equal(radii.cpu().numpy(), oracle_forward(orc, scene, cam)["radii"])
+            assert raster.stream_stat(_lib.STAT_DEFERRED_FORWARDS) - deferred0 >= 3      # the path was really taken
+            assert raster.stream_stat(_lib.STAT_DEFERRED_RETRIES) - retries0 >= 1        # small -> big outgrew the guess
+    torch.cuda.synchronize()
+
+
 def test_options_and_state_are_per_stream(orc):
     """Two callers in one process: stream A renders with the exact fp32 arithmetic and binning mode 1, stream B
     with the defaults, interleaved.  Each gets its own result and its own work-list state."""
