@@ -1110,10 +1110,10 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		const bool presplit3 = arith_nib >= 14;   // weights handed over as three bf16 terms
 		const bool exact = arith_nib == 9;
 		// weights pre-pass.  blend_weights2.hip (lane = two pixels: a third fewer instructions) is used for the fp32-row format
-		// (0.25 -> 0.22 ms at cfg3; the backward's pre-pass is the same kernel).  For the three-term format it is 4 % faster
-		// on its own (0.31 -> 0.30 ms) but the sweep BEHIND it runs 5 % slower (1.19 -> 1.25 ms, reproducibly; the cause was
-		// not found -- same bytes, same slots), so the default path keeps round 2's kernel there.  Bit 14 of the word flips
-		// the choice for A/B runs; a sweep trace needs round 2's kernel (it carries the trace hooks).
+		// (0.25 -> 0.22 ms at cfg3; the backward's pre-pass is the same kernel).  For the three-term format it is no faster
+		// (0.31-0.32 vs 0.30-0.31 ms, order-balanced A/B: 96 VGPRs, the flush through LDS), so the default path keeps round
+		// 2's kernel there.  Bit 14 of the word flips the choice for A/B runs; a sweep trace needs round 2's kernel (it
+		// carries the trace hooks).
 		const bool flip = (split_mode & 0x4000) != 0;
 		const bool w_old = (presplit3 ? !flip : flip) || g_sweep_trace != nullptr;
 		if ((presplit3 || exact || sweep2) && !w_old) {
