@@ -411,8 +411,15 @@ def main():
         stream) and the per-stage times (deferred resolution: no extra synchronisation).  deferred: the forward
         without the num_rendered read-back (each frame's counts are checked before the next one is enqueued)."""
         raster.set_blend_variant(variant)
-        for _ in range(3):
+        # warm up for 0.4 s, not for 3 frames: the same kernel runs 5-7 % slower in the first ~0.2 s of GPU activity of a
+        # process than in steady state (clock ramp; tools/exp_r03_sweep2.py with a repeated variant shows the drift)
+        t_w = time.perf_counter()
+        nw = 0
+        while nw < 3 or time.perf_counter() - t_w < 0.4:
             render(0)
+            nw += 1
+            if nw % 8 == 0:
+                torch.cuda.synchronize(dev)
         torch.cuda.synchronize(dev)
         raster.get_stage_ms()
         raster.set_stage_timing(2)

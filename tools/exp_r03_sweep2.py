@@ -22,8 +22,11 @@ res = {}
 names = {0x6E: "sweep2 x6 pre-split", 0x16E: "sweep2 x6p no stores", 0x26E: "sweep2 x6p no mfma", 0x36E: "sweep2 x6p ring only", 0: "r2 bf16x3 sweep", 15: "r2 exact sweep", 0x6B: "sweep2 exact", 0x6A: "sweep2 x6 interleaved", 0x6D: "sweep2 x6 block by block", 0x6C: "sweep2 x6 wide(x16)",
          0x16A: "sweep2 x6 ilv no stores", 0x16D: "sweep2 x6 bbb no stores", 0x26A: "sweep2 x6 no mfma", 0x36A: "sweep2 x6 ring only", 0x16B: "sweep2 exact no stores", 0x26B: "sweep2 exact no mfma"}
 TIMING_ONLY = len(sys.argv) > 1
-if TIMING_ONLY: names = {int(a, 0): a for a in sys.argv[1:]}
-for v in list(names):
+order = list(names)
+if TIMING_ONLY:
+    order = [int(a, 0) for a in sys.argv[1:]]   # (repeats allowed: the first measurement of a process runs 3-8 % slow)
+    names = {v: hex(v) for v in order}
+for v in order:
     try:
         for _ in range(3): fwd(v)
         torch.cuda.synchronize(); raster.get_stage_ms(); raster.set_stage_timing(2)
