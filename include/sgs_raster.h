@@ -266,7 +266,7 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * similarities themselves (eval_segmentation.py:155: rendering / (rendering.norm(dim=0) + 1e-8)); rendering it this
  * way saves the C * H * W * 4 bytes of stores (2.57 GB at 512 x 968 x 1296) and the caller's read of them.
  * Needs num_channels % 128 == 0, no depth plane and the default blend (variants 0 / 15); SGS_EINVAL otherwise.
- * The work list is laid out for its worst case in such a call (there is no room for the overflow fallback). */
+ * A frame whose work list overflows is rendered by the same gated fallback as always; its epilogue adds the squares. */
 #define SGS_OPT_NORM_PLANE 7
 #define SGS_OPT_COUNT 8
 /* value < 0 removes the override (the stream follows the process default again).  Returns the previous override,

@@ -731,11 +731,6 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		// a tile can never need more than its list length rounded up to whole chunks
 		arena_max = (uint64_t)L + 128ull * (uint64_t)ntiles;
 		arena_cap = (uint64_t)hint < arena_max ? hint : (uint32_t)arena_max;
-		// the norm plane has no room for the overflow fallback's feature map: lay the work list out for the worst case
-		if (norm_plane) {
-			if (arena_max >> 32) return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE: frame too large for a worst-case work list");
-			arena_cap = (uint32_t)arena_max;
-		}
 	}
 	const BinLayout bl = bin_layout(L, sort_bits, arena_cap, ntiles, Rrows, gx, gy, P);
 	char* bchunk = (char*)binning_buffer(binning_user, bl.total);

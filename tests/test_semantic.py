@@ -128,3 +128,27 @@ def test_norm_plane_with_nothing_rendered_and_bad_arguments():
     with pytest.raises(RuntimeError):
         semantic.render_norm2(_settings(cr, c, s, W, H, 96), s.means3D, s.opacities, s.scales, s.rotations,
                               s.features[:, :96].contiguous())
+
+
+@pytest.mark.gpu
+def test_norm_plane_through_the_overflow_fallback(orc):
+    """A fresh stream's first frame of a dense scene outgrows the initial work-list capacity: the sweep exits and the gated
+    single-kernel fallback renders the frame -- in norm mode it must add the squares into the plane, not write a feature map."""
+    from sgs_hip import raster, semantic, _lib
+    import channel_rasterization as cr
+    dev = "cuda:0"
+    C, W, H = 128, 784, 32      # 98 tiles with ~900 active entries each: more than the 64k slots a fresh stream starts with
+    scene, cam = small_scene(P=120000, C=C, W=W, H=H, fx=600.0, seed=77)
+    scene = scene._replace(scales=scene.scales * 3.0, opacities=scene.opacities * 0.02, bg=torch.linspace(-0.2, 0.2, C))
+    s, c = scene.to(dev), cam.to(dev)
+    full = torch.from_numpy(oracle_forward(orc, scene, cam)["out"]).double()
+    want = (full * full).sum(dim=0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        n2_first = semantic.render_norm2(_settings(cr, c, s, W, H, C), s.means3D, s.opacities, s.scales, s.rotations, s.features)
+        n2_second = semantic.render_norm2(_settings(cr, c, s, W, H, C), s.means3D, s.opacities, s.scales, s.rotations, s.features)
+        overflows = raster.stream_stat(_lib.STAT_FWD_OVERFLOWS)
+    torch.cuda.synchronize()
+    assert overflows >= 1      # the first frame really took the fallback (reported when the second frame read the feedback)
+    for n2 in (n2_first, n2_second):
+        assert float(((n2.cpu().double() - want).abs() / (want + 1e-6)).max()) < 2e-5
