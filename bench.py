@@ -572,7 +572,7 @@ def main():
 
     def extra_leg(variant, what, defer=None):
         sv, stg = single_view(variant, deferred=bool(defer))
-        ms_e, ms_e_med, mism_e, out_e, retr = in_flight(variant, kx, max(3, NCAM), defer=defer)   # every (slot, camera) seen once: buffers at their steady size
+        ms_e, ms_e_med, mism_e, out_e, retr = in_flight(variant, kx, max(3, NCAM + 2), defer=defer)   # every camera of a slot and the wrap-around seen once: buffers at their steady size
         del out_e
         return {"arithmetic": what, "value": world * V * H * W * C / (ms_e * 1e-3) / 1e9, "unit": "Gpixel*channels/s",
                 "ms_per_step": ms_e, "ms_per_view": ms_e / V, "steps": kx, "views_in_flight": V,
