@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 
 	// ---- one batch: table entry, bundle arrival, barrier, next bundle; returns the entry word of batch j
 	Bundle nb;   // the bundle this step issues (j + LA)
+	uint32_t late = 0;   // (trace) steps of this wave whose bundle had not landed when the step began
 	auto batch_head = [&]() __attribute__((always_inline)) -> uint32_t {
 		if (j + 2 * S2_LA >= wbase + S2_JMAX) {   // (uniform, long segments only) slide the table window
 			__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
@@ -787,6 +788,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 			: "v"(a), "v"(pa), "v"(ia), "n"(S2_LA * 8), "n"(2 * S2_LA * 8)
 			: "memory");
 		if (__builtin_amdgcn_ballot_w64(wv == S2_SENT) != 0ull) {   // not landed yet: poll (no vmcnt: stores may be outstanding in any number)
+			if (trace) late++;   // (tools/sweep_trace.py: how often a step finds its bundle still in flight)
 			int spins = 0;
 			do {
 				if (++spins > (1 << 22)) __builtin_trap();   // (a lost bundle must not hang the device)
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 		trace[4 * (size_t)b + 1] = wall_clock64();
 		trace[4 * (size_t)b + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
 					   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-		trace[4 * (size_t)b + 3] = (unsigned long long)J | ((unsigned long long)nt << 32);
+		trace[4 * (size_t)b + 3] = (unsigned long long)J | ((unsigned long long)nt << 32) | ((unsigned long long)late << 40);
 	}
 }
 

@@ -47,13 +47,16 @@ b, e = (b - t0) / 100.0, (e - t0) / 100.0   # us
 span = e.max()
 dur = e - b
 J = t[:, 3] & 0xFFFFFFFF
-nt = t[:, 3] >> 32
+nt = (t[:, 3] >> 32) & 0xFF
+late = t[:, 3] >> 40   # (blend_sweep2: steps of wave 0 that found their bundle still in flight)
 hw = t[:, 2] & 0xFFFFFFFF
 xcc = (t[:, 2] >> 32) & 0xF
 cu = (hw >> 8) & 0xF
 se = (hw >> 13) & 0x7
 sh = (hw >> 12) & 1
 print(f"workgroups {len(t)}, kernel span {span:.1f} us, sum of durations {dur.sum():.0f} us = {dur.sum() / span:.1f} slots busy on average")
+if late.sum() > 0 or True:
+    print(f"steps that began before their bundle had landed (wave 0 of each workgroup): {int(late.sum())} of {int(J.sum())} = {late.sum() / max(1, J.sum()):.3f}")
 print(f"duration us: min {dur.min():.1f} median {np.median(dur):.1f} max {dur.max():.1f}; batches/WG median {np.median(J):.0f} max {J.max()}")
 k = np.polyfit(J, dur, 1)
 print(f"duration ~ {k[0]:.3f} us/batch * J + {k[1]:.1f} us;  residual std {np.std(dur - np.polyval(k, J)):.1f} us")
