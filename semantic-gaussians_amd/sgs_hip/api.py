@@ -96,7 +96,9 @@ def _make_function(with_depth):
                     # inference: the host still learns num_rendered before the call returns (the reference's blocking
                     # read-back, rasterizer_impl.cu:283), but the GPU is not left idle while it does: the frame is
                     # enqueued in full against the stream's capacity guess, then the host waits for the counts only
-                    # (a frame that outgrew the guess is rendered again; bit-identical results)
+                    # (a frame that outgrew the guess is rendered again; bit-identical results).
+                    # Frames that will be differentiated keep the classic order: measured, a training step gains nothing
+                    # from it (the optimiser's kernels keep the queue full) and the state buffers would be 1.25 x larger.
                     (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth) = \
                         raster.rasterize_forward_deferred(*call, want_depth=with_depth, pool=pool).result()
                 else:

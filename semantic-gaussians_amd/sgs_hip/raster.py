@@ -194,6 +194,9 @@ def rasterize_forward_deferred(*args, **kwargs):
     dev = args[1].device
     stream = torch.cuda.current_stream(dev)
     sp = C.c_void_p(stream.cuda_stream)
+    if args[1].size(0) == 0:   # nothing to render: the library is not called at all, there is no count to wait for
+        kwargs.pop("_defer_mode", None)
+        return DeferredForward(None, None, stream, rasterize_forward(*args, **kwargs))
     with torch.cuda.device(dev):
         prev = lib.sgs_stream_set_option(sp, _lib.OPT_DEFER_COUNT, int(kwargs.pop("_defer_mode", 1)))
         try:
