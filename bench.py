@@ -15,8 +15,9 @@ What one JSON line carries (rank 0):
                         against the exact composite: tests/test_configs_gpu.py) -- `dtype` says so.  The default K keeps
                         >= 2 s of continuous GPU work in the timed region;
   api_path              what a user of the reference gets: channel_rasterization.GaussianRasterizer called exactly as
-                        model/renderer.py:169-185,228 does (nn.Parameter inputs, torch.no_grad(), debug=True, one view,
-                        blocking count), device ms per forward (hipEvents, median);
+                        model/renderer.py:169-185,228 does (nn.Parameter inputs, torch.no_grad(), debug=True, one view;
+                        the host waits for num_rendered before the call returns, after the whole frame was enqueued),
+                        device ms per forward (hipEvents, median);
   single_view           one view in flight through the internal entry point (SURVEY.md 8(d)'s t_fwd): value, ms_median;
   deferred_count        the inference-only mode without the host read-back (SGS_OPT_DEFER_COUNT), V views in flight,
                         with the number of frames that had to be rendered twice;
@@ -28,6 +29,11 @@ What one JSON line carries (rank 0):
   roofline              the forward blend against the HBM roofline: achieved = SURVEY 8(d)'s algorithmic bytes of
                         the blend / its kernels' live hipEvent durations (one view in flight); plus the secondary
                         ceilings (fp32 FMA, bf16 MFMA) the same work is priced against;
+  semantic_consumer     SURVEY 8(f) N1: per-view text similarities three ways (the reference's flow on this rasteriser, the
+                        normalised values via the norm-plane epilogue, the unnormalised logits), N = 1 only;
+  multi_gpu_configs     BASELINE configs 4 (views sharded) and 5 (Gaussians sharded, RCCL band exchange) on this job's
+                        ranks: with --extra-configs, and by default when N > 1 (after the line is complete, under a
+                        watchdog);
   cpu_baseline          kind "pytorch": the pure-PyTorch CPU splat the north star names (oracle/torch_splat.py): cfg1 in
                         full, cfg3 on a tile sample extrapolated by the tiles' list work; cpu_baseline_port: the
                         C/OpenMP oracle.
