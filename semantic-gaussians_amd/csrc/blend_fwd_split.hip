@@ -1106,7 +1106,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// fp32-input MFMA; blend_sweep2.hip: 10 = f32-equivalent (six bf16 products), 11 = exact fp32 MFMA, 12 = six
 		// products on the double-rate MFMA (experiment).  All but 8 take fp32 weight rows.
 		const int arith_nib = split_mode & 15;
-		const bool sweep2 = arith_nib >= 10 && arith_nib <= 15;
+		const bool sweep2 = (arith_nib >= 10 && arith_nib <= 15) || arith_nib == 7;   // 7 = six products, fp32 hand-over, split once per workgroup (S2_X6C)
 		const bool presplit3 = arith_nib >= 14;   // weights handed over as three bf16 terms
 		const bool exact = arith_nib == 9;
 		// weights pre-pass.  blend_weights2.hip (lane = two pixels: a third fewer instructions) is used for the fp32-row format
@@ -1145,7 +1145,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
 		if (sweep2) {
-			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : (arith_nib == 15 ? 5 : 1)))), a.norm_plane ? 32 : ((split_mode >> 8) & 15), a, table,
+			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 7 ? 6 : arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : (arith_nib == 15 ? 5 : 1)))), a.norm_plane ? 32 : ((split_mode >> 8) & 15), a, table,
 								  nbatches, act_id, (const char*)wgt, counter, nc, seg, nseg, pxcd, items,
 								  g_sweep_trace, order_arg, dealt);
 			if (e2 != hipSuccess) return e2;

@@ -46,9 +46,11 @@ constexpr int S2_JMAX = 1024;
 // ring geometry by weights format: fp32 rows (8 KB per batch and parity, 4 stages) | three bf16 terms (12 KB, 3 stages:
 // two workgroups of 4 x 21 KB do not fit a CU's 160 KB).  Stage = features | this parity's weights | ids of the batch
 // LA bundles on.
-template <bool PRE> struct RingCfg {
-	static constexpr int NST = PRE ? 3 : 4, LA = NST - 1;
-	static constexpr int WBYTES = PRE ? 12288 : 8192;
+// KIND 0: fp32 weight rows, 4 stages; 1: pre-split weights (three bf16 terms), 3 stages; 2: fp32 weight rows, 3 stages + a
+// 12-KB buffer the four waves split the batch's weights into (S2_X6C)
+template <int KIND> struct RingCfg {
+	static constexpr int NST = KIND == 0 ? 4 : 3, LA = NST - 1;
+	static constexpr int WBYTES = KIND == 1 ? 12288 : 8192;
 	static constexpr int STAGE = 8192 + WBYTES + 1024;
 };
 
@@ -379,10 +381,10 @@ __device__ __forceinline__ void mfma_dense_wide(const u32x4 (&a)[3], const u32x4
 // the NP pieces of the next bundle's DMA (`piece`) go between the second pair's statements, where their issue slots
 // (~60 cycles each) hide behind 64 cycles of matrix work.
 template <bool WIDE, int B0, int B1, int B2, int B3, int NP, typename F>
-__device__ __forceinline__ void s2_compute_x6p(uint32_t st, int cg, int half, int l31, F piece)
+__device__ __forceinline__ void s2_compute_x6p(uint32_t st, uint32_t wb, int cg, int half, int l31, F piece)
 {
 	const uint32_t fa = st + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;
-	const uint32_t wa = st + 8192u + (uint32_t)half * 6144u + (uint32_t)l31 * 16u;   // + term * 2048 + pb * 512
+	const uint32_t wa = wb + (uint32_t)half * 6144u + (uint32_t)l31 * 16u;   // + term * 2048 + pb * 512  (wb: the stage's weight area / the split buffer)
 	float f[8];
 	u32x4 x[3], y[3], x2[3], y2[3];
 	S2_READ8(f, fa);
@@ -434,6 +436,33 @@ __device__ __forceinline__ void s2_compute_x6p(uint32_t st, int cg, int half, in
 #undef S2_HALF2
 #undef S2_RDB
 #undef S2_WTB
+}
+
+// S2_X6C: the batch's fp32 weights -> the three bf16 terms in the pre-split operand layout ([group of 8 entries][term]
+// [128 px'][8 x bf16], 12 KB).  Wave w converts pixels 32 w .. 32 w + 31 and FETCHES exactly those (its two weight DMAs
+// gather the 128-byte pieces [entry][32 px'] of the 16 entries into its own 2 KB of the stage), so the arrival of its own
+// bundle is all it needs: the split runs before the step's barrier, which then covers "every bundle landed" and "the split
+// buffer is complete" at once.  The buffer is double: a wave may be a step ahead of the slowest reader of the other half.
+// The weights kernel hands over 1 KB per entry instead of 1.5 KB and does no splitting; the sweep splits every weight once
+// per workgroup instead of once per wave (S2_X6).  Results are bit-identical to S2_X6P (the same split3).
+__device__ __forceinline__ void s2_split_coop(uint32_t st, uint32_t split_a, int wave, int half, int l31)
+{
+	float w[8];
+	const uint32_t ra = st + 8192u + (uint32_t)wave * 2048u + (uint32_t)(8 * half) * 128u + (uint32_t)l31 * 4u;
+	asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:128\n\tds_read_b32 %2, %8 offset:256\n\t"
+		     "ds_read_b32 %3, %8 offset:384\n\tds_read_b32 %4, %8 offset:512\n\tds_read_b32 %5, %8 offset:640\n\t"
+		     "ds_read_b32 %6, %8 offset:768\n\tds_read_b32 %7, %8 offset:896"
+		     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+		     : "v"(ra) : "memory");
+	S2_WAIT8(w);
+	Op3 X;
+	split8(w, X);
+	const uint32_t da = split_a + (uint32_t)half * 6144u + (uint32_t)(32 * wave + l31) * 16u;
+	const u32x4 t0 = {X.t[0][0].x, X.t[0][0].y, X.t[0][1].x, X.t[0][1].y};
+	const u32x4 t1 = {X.t[1][0].x, X.t[1][0].y, X.t[1][1].x, X.t[1][1].y};
+	const u32x4 t2 = {X.t[2][0].x, X.t[2][0].y, X.t[2][1].x, X.t[2][1].y};
+	asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:2048\n\tds_write_b128 %0, %3 offset:4096\n\ts_waitcnt lgkmcnt(0)"
+		     : : "v"(da), "v"(t0), "v"(t1), "v"(t2) : "memory");
 }
 
 // The same batch as an exact k-ordered fp32 fma chain: one v_mfma_f32_32x32x2_f32 per pair of entries and pixel block
@@ -593,7 +622,7 @@ __device__ __forceinline__ void s2_norm_block(float* plane, int PW, int W, int H
 
 } // namespace
 
-enum { S2_EXACT = 0, S2_X6 = 1, S2_X6W = 2, S2_X6S = 3, S2_X6P = 4, S2_X6PW = 5 };   // X6PW: X6P on v_mfma_f32_32x32x16_bf16   // X6P: weights pre-split by the weights kernel   // X6S: the six products block by block (the first form; A/B)
+enum { S2_EXACT = 0, S2_X6 = 1, S2_X6W = 2, S2_X6S = 3, S2_X6P = 4, S2_X6PW = 5, S2_X6C = 6 };   // X6C: fp32 weights handed over, split ONCE per workgroup (each wave a quarter) into LDS   // X6PW: X6P on v_mfma_f32_32x32x16_bf16   // X6P: weights pre-split by the weights kernel   // X6S: the six products block by block (the first form; A/B)
 
 // DBG (development ablations, 0 in production): 1 = no stores, 2 = no matrix work, 4 / 8 = store ablations (s2_store4).
 template <int ARITH, int DBG>
@@ -641,10 +670,14 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	const int c0 = cbase + cg * 32;
 	const size_t HW = (size_t)H * PW;
 
-	constexpr bool PRE = ARITH == S2_X6P || ARITH == S2_X6PW;
-	constexpr int S2_NST = RingCfg<PRE>::NST, S2_LA = RingCfg<PRE>::LA, S2_STAGE = RingCfg<PRE>::STAGE;
+	constexpr bool PRE = ARITH == S2_X6P || ARITH == S2_X6PW;   // the ARENA holds three bf16 terms per weight
+	constexpr bool COOP = ARITH == S2_X6C;
+	constexpr int KIND = PRE ? 1 : (COOP ? 2 : 0);
+	constexpr int S2_NST = RingCfg<KIND>::NST, S2_LA = RingCfg<KIND>::LA, S2_STAGE = RingCfg<KIND>::STAGE;
 	__shared__ float4 s_ring[S2_NST * S2_STAGE / 16];
-	__shared__ uint2 s_bt[S2_JMAX];   // .x = first arena slot of the batch, .y = entries | tile in segment << 8 | last of tile << 16
+	__shared__ float4 s_split[COOP ? 2 * 12288 / 16 : 1];
+	constexpr int JMAX = COOP ? 384 : S2_JMAX;   // (the double split buffer takes the room of 5 KB of table)
+	__shared__ uint2 s_bt[JMAX];   // .x = first arena slot of the batch, .y = entries | tile in segment << 8 | last of tile << 16
 	__shared__ uint32_t s_tot[S2_SEGMAX], s_cb[S2_SEGMAX], s_pref[S2_SEGMAX + 1];
 
 	// ---- prologue: the segment's batches as one flat table (ordinary accesses: nothing is in flight yet)
@@ -673,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 				const uint32_t q = qb + (threadIdx.x & 31);
 				if (t < nt) {
 					const uint32_t p0 = s_pref[t], nb = s_pref[t + 1] - p0;
-					if (q < nb && p0 + q >= wbase && p0 + q < wbase + S2_JMAX) {
+					if (q < nb && p0 + q >= wbase && p0 + q < wbase + JMAX) {
 						const uint32_t tot = s_tot[t], first = q * AB;
 						const uint32_t slot = sgs_chunk_start(table, s_cb[t], (uint32_t)(ty * gx + tx0 + t), first >> 7) + (first & 127u);
 						const uint32_t n = (tot - first) < (uint32_t)AB ? (tot - first) : (uint32_t)AB;
@@ -681,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 					}
 				}
 			}
-		if (threadIdx.x < 2 * S2_LA && J + threadIdx.x >= wbase && J + threadIdx.x - wbase < S2_JMAX)
+		if (threadIdx.x < 2 * S2_LA && J + threadIdx.x >= wbase && J + threadIdx.x - wbase < JMAX)
 			s_bt[J + threadIdx.x - wbase] = make_uint2((uint32_t)(ty * gx + tx0 + nt - 1) * 128u, 1u | ((uint32_t)(nt - 1) << 8));
 	};
 	fill_table(0);
@@ -689,8 +722,9 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 
 	const uint32_t ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_ring;
 	const uint32_t bt_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_bt;
+	const uint32_t split_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_split;
 	const uint32_t sub = (uint32_t)(4 * wave + half);   // this lane fetches the feature rows of entries sub and sub + 2
-	const uint32_t my_ids = 8192u + (uint32_t)RingCfg<PRE>::WBYTES + (uint32_t)wave * 256u;   // this wave's id words inside a stage
+	const uint32_t my_ids = 8192u + (uint32_t)RingCfg<KIND>::WBYTES + (uint32_t)wave * 256u;   // this wave's id words inside a stage
 	// bundle = features + this parity's weights of the batch at `slot` into stage st, then the ids of the batch
 	// (slot2, n2) into the wave's id words -- LAST, so that their arrival means the wave's whole bundle arrived.
 	// The id words hold the sentinel at that point: a wave writes it right after it has read a stage's ids (one step
@@ -718,6 +752,12 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 					   (size_t)g * 2048 + (size_t)(pc % 2) * 1024 + (size_t)lane * 16;
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
 							 (__attribute__((address_space(3))) void*)(size_t)(bd.st + 8192u + (uint32_t)pc * 1024u), 16, 0, 0);
+		} else if constexpr (COOP) {
+			// fp32 weight rows of 1 KB per entry: the 128 bytes [32 wave .. 32 wave + 31] px' of this parity, entries
+			// 8 (i - 2) + (lane >> 3), as 16-byte pieces -> this wave's [entry][32 px'] block of the stage
+			const char* wsrc = wgt + (size_t)(bd.slot + 8 * (i - 2) + (lane >> 3)) * 1024 + (size_t)g * 512 + (size_t)wave * 128 + (size_t)(lane & 7) * 16;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
+							 (__attribute__((address_space(3))) void*)(size_t)(bd.st + 8192u + (uint32_t)wave * 2048u + (uint32_t)(i - 2) * 1024u), 16, 0, 0);
 		} else {
 			// fp32 weight rows of 1 KB per entry: this parity's 512 B of entries 4 wave .. 4 wave + 3
 			const char* wsrc = wgt + (size_t)(bd.slot + 4 * wave + (lane >> 5)) * 1024 + (size_t)g * 512 + (size_t)(lane & 31) * 16;
@@ -763,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	Bundle nb;   // the bundle this step issues (j + LA)
 	uint32_t late = 0;   // (trace) steps of this wave whose bundle had not landed when the step began
 	auto batch_head = [&]() __attribute__((always_inline)) -> uint32_t {
-		if (j + 2 * S2_LA >= wbase + S2_JMAX) {   // (uniform, long segments only) slide the table window
+		if (j + 2 * S2_LA >= wbase + JMAX) {   // (uniform, long segments only) slide the table window
 			__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
 			__syncthreads();
 			wbase = j;
@@ -806,6 +846,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 		nb.id0 = id0;
 		nb.id1 = id1;
 		nb.st = stI;   // the stage batch j - 1 was computed from
+		if constexpr (COOP && !(DBG & 2)) s2_split_coop(st0, split_a + (j & 1u) * 12288u, wave, half, l31);   // (this wave's bundle has landed)
 		__builtin_amdgcn_s_barrier();
 		return e0y;
 	};
@@ -819,11 +860,13 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 // between its MFMA statements; the others issue the bundle first.
 #define S2_COMPUTE(b0_, b1_, b2_, b3_)                                                               \
 	do {                                                                                             \
-		if ((DBG & 2) || !PRE) issue_all(nb);                                                        \
+		if ((DBG & 2) || !(PRE || COOP)) issue_all(nb);                                              \
 		if (!(DBG & 2)) {                                                                            \
 			if (ARITH == S2_EXACT) s2_compute_exact<b0_, b1_, b2_, b3_>(st0, cg, half, l31);          \
-			else if (PRE) s2_compute_x6p<ARITH == S2_X6PW, b0_, b1_, b2_, b3_, NPIECE>(st0, cg, half, l31, [&](auto I) __attribute__((always_inline)) { dma_piece(I, nb); }); \
-			else s2_compute_x6<ARITH == S2_X6W, ARITH == S2_X6, b0_, b1_, b2_, b3_>(st0, cg, half, l31); \
+			else if (PRE) s2_compute_x6p<ARITH == S2_X6PW, b0_, b1_, b2_, b3_, NPIECE>(st0, st0 + 8192u, cg, half, l31, [&](auto I) __attribute__((always_inline)) { dma_piece(I, nb); }); \
+			else if (COOP) {                                                                         \
+				s2_compute_x6p<false, b0_, b1_, b2_, b3_, NPIECE>(st0, split_a + (j & 1u) * 12288u, cg, half, l31, [&](auto I) __attribute__((always_inline)) { dma_piece(I, nb); }); \
+			} else s2_compute_x6<ARITH == S2_X6W, ARITH == S2_X6, b0_, b1_, b2_, b3_>(st0, cg, half, l31); \
 		}                                                                                            \
 	} while (0)
 
@@ -1007,6 +1050,11 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 		else if (dbg == 10) S2_LAUNCH(S2_X6P, 10);
 		else if (dbg == 32) S2_LAUNCH(S2_X6P, 32);
 		else S2_LAUNCH(S2_X6P, 0);
+	} else if (arith == S2_X6C) {
+		if (dbg == 1) S2_LAUNCH(S2_X6C, 1);
+		else if (dbg == 2) S2_LAUNCH(S2_X6C, 2);
+		else if (dbg == 3) S2_LAUNCH(S2_X6C, 3);
+		else S2_LAUNCH(S2_X6C, 0);
 	} else if (arith == S2_X6S) {
 		if (dbg == 1) S2_LAUNCH(S2_X6S, 1);
 		else S2_LAUNCH(S2_X6S, 0);

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 V_X6, V_EXACT, V_X6W, V_X6S, V_X6P, V_X6PW = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E, 0x6F
+V_X6C = 0x67      # six products, fp32 weights handed over, split once per workgroup into LDS: bit-identical to V_X6P
 # Against the fp32 ORACLE the difference is dominated by the oracle's own roundings: its multiply-add chain rounds once
 # per contribution (<= 2^-24 |partial sum| each, K ~ 50-300 contributions), the six-product path drops
 # F2 W3 + F3 W2 + F3 W3 <= 2^-23 |f w| per term and rounds once per MFMA.  4e-6 of the ABSOLUTE composite
@@ -56,7 +57,7 @@ def check(orc, scene, cam, variant, seg=None, **kw):
 SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64), (128, 336, 48)]
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6W, V_X6S, V_X6P, V_X6PW])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6W, V_X6S, V_X6P, V_X6PW, V_X6C])
 @pytest.mark.parametrize("C,W,H", SHAPES)
 def test_sweep2_shapes(orc, variant, C, W, H):
     """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
@@ -66,7 +67,7 @@ def test_sweep2_shapes(orc, variant, C, W, H):
     check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW, V_X6C])
 def test_sweep2_background_and_short_lists(orc, variant):
     """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
     scene, cam = small_scene(P=60, C=128, W=208, H=96, fx=170.0, seed=5)
@@ -77,7 +78,7 @@ def test_sweep2_background_and_short_lists(orc, variant):
     assert (r[:, 0] == r[:, 1]).any()   # empty tiles exist
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW, V_X6C])
 def test_sweep2_long_lists(orc, variant):
     """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
     deferred stores ride along tiles of very different lengths."""
@@ -89,7 +90,7 @@ def test_sweep2_long_lists(orc, variant):
     check(orc, scene, cam, variant, seg=6)   # one 49-tile segment: ~2900 batches
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW, V_X6C])
 def test_sweep2_padded_pitch(orc, variant):
     """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
     from sgs_hip import raster
@@ -134,3 +135,15 @@ def test_feature_scale_invariance_is_bit_exact(variant):
         s2 = scene._replace(features=scene.features * 2.0 ** k, bg=scene.bg * 2.0 ** k)
         out = _hip_forward(s2, cam, variant=variant)[1]
         assert torch.equal(out, base * 2.0 ** k), k
+
+
+def test_cooperative_split_equals_presplit_bitwise():
+    """V_X6C and V_X6P evaluate the same six products of the same three-term splits (split3 in the sweep / in the weights
+    pre-pass): the feature maps are bit-identical."""
+    for (P, C, W, H, seed) in ((4000, 256, 208, 96, 1), (30000, 128, 400, 64, 2), (500, 512, 48, 40, 3)):
+        scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=170.0, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        scene = scene._replace(bg=torch.randn(C, generator=g))
+        a = _hip_forward(scene, cam, variant=V_X6P)[1]
+        b = _hip_forward(scene, cam, variant=V_X6C)[1]
+        assert torch.equal(a, b)
