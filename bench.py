@@ -34,7 +34,8 @@ What one JSON line carries (rank 0):
   multi_gpu_configs     BASELINE configs 4 (views sharded) and 5 (Gaussians sharded, RCCL band exchange) on this job's
                         ranks: with --extra-configs, and by default when N > 1 (after the line is complete, under a
                         watchdog);
-  cpu_baseline          kind "pytorch": the pure-PyTorch CPU splat the north star names (oracle/torch_splat.py): cfg1 in
+  cpu_baseline          kind "port" (a restatement, not the reference itself, which cannot run here), implementation pure
+                        PyTorch: the CPU splat the north star names (oracle/torch_splat.py): cfg1 in
                         full, cfg3 on a tile sample extrapolated by the tiles' list work; cpu_baseline_port: the
                         C/OpenMP oracle.
 
@@ -196,7 +197,7 @@ def cpu_baseline_pytorch(scene, cam, C, W, H, n_eff, budget_s=10.0):
         n *= 2
     work = float(n_eff[lo:lo + done].sum()) / max(1.0, float(n_eff.sum()))
     t_frame = t_front + t_blend / work
-    return dict(value=H * W * C / t_frame / 1e9, unit="Gpixel*channels/s", cores=nthreads, kind="pytorch",
+    return dict(value=H * W * C / t_frame / 1e9, unit="Gpixel*channels/s", cores=nthreads, kind="port", implementation="pure PyTorch (oracle/torch_splat.py): the CPU baseline BASELINE.md names",
                 host_cpus=ncores, thread_calibration_ms={str(k): round(v * 1e3, 2) for k, v in calib.items()},
                 cfg1={"workload": "cfg1: 10k Gaussians, 256x256, C=3, full frame", "seconds": cfg1_s,
                       "value": 256 * 256 * 3 / cfg1_s / 1e9, "unit": "Gpixel*channels/s"},
