@@ -325,12 +325,17 @@ static void launch_px1(hipStream_t st, const BlendFwdArgs& a, int c_begin, int n
 			   nchunks, write_aux, per_xcd, total, a.pitch, a.abort);
 }
 
+// workgroups of the GATED instance (it exits at once unless the split path's work list overflowed): every one of them
+// has to be scheduled -- behind other views' sweeps with several views in flight -- before the stream moves on
+#ifndef SGS_GATED_GRID
+#define SGS_GATED_GRID 2048
+#endif
 template <int CW, int BATCH>
 static void launch_px4(hipStream_t st, const BlendFwdArgs& a, int nchunks, const uint32_t* gate)
 {
 	const int total = a.gx * a.gy * nchunks;
 	const int per_xcd = (total + 7) / 8;
-	const int grid = gate && per_xcd * 8 > 2048 ? 2048 : per_xcd * 8;   // (gated fallback: see the kernel)
+	const int grid = gate && per_xcd * 8 > SGS_GATED_GRID ? SGS_GATED_GRID : per_xcd * 8;   // (gated fallback: see the kernel)
 	hipLaunchKernelGGL((blend_fwd_px4_kernel<CW, BATCH>), dim3(grid), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.bg,
 			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate, a.pitch, a.abort, a.norm_plane ? 1 : 0);
