@@ -55,7 +55,7 @@ cu = (hw >> 8) & 0xF
 se = (hw >> 13) & 0x7
 sh = (hw >> 12) & 1
 print(f"workgroups {len(t)}, kernel span {span:.1f} us, sum of durations {dur.sum():.0f} us = {dur.sum() / span:.1f} slots busy on average")
-if late.sum() > 0 or True:
+if which == "sweep":
     print(f"steps that began before their bundle had landed (wave 0 of each workgroup): {int(late.sum())} of {int(J.sum())} = {late.sum() / max(1, J.sum()):.3f}")
 print(f"duration us: min {dur.min():.1f} median {np.median(dur):.1f} max {dur.max():.1f}; batches/WG median {np.median(J):.0f} max {J.max()}")
 k = np.polyfit(J, dur, 1)
