@@ -43,6 +43,19 @@ def test_gaussian_sharded_render_over_rccl_two_gpus():
     assert "GAUSSIAN_SHARDED_OK" in r.stdout
 
 
+def test_gaussian_sharded_render_two_ranks_on_one_device_over_gloo():
+    """The same script as the RCCL test with both ranks on cuda:0 and gloo as the transport (test hook): HIP partials of two
+    depth slabs, the band exchange as grouped point-to-point operations on device tensors, the HIP composite, the gathered
+    map against rank 0's single render -- everything but RCCL itself, on a one-GPU box."""
+    env = dict(os.environ, SGS_TEST_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29300 + os.getpid() % 200),
+                        os.path.join(ROOT, "tools", "run_gaussian_sharded.py"), "60000", "128"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GAUSSIAN_SHARDED_OK" in r.stdout
+
+
 def test_bench_two_ranks_control_flow_on_one_device():
     """bench.py --gpus 2 end to end on ONE device (test hook SGS_BENCH_TEST_ONE_DEVICE: both ranks on cuda:0, gloo for the
     control collectives): rank spawn, rendezvous on 127.0.0.1, barriers, max-over-ranks timing, the aggregate value, one

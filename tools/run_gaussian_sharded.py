@@ -12,9 +12,15 @@ import torch.distributed as dist
 
 def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local)
+    # SGS_TEST_ONE_DEVICE=1 (test hook): every rank on cuda:0 and gloo instead of RCCL (which refuses two ranks per device) --
+    # the same code path (HIP partials, band exchange as grouped point-to-point operations, HIP composite) on a 1-GPU box
+    one_dev = os.environ.get("SGS_TEST_ONE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if one_dev else local)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev)
+    if one_dev:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     from sgs_hip import raster, dist as sdist
     from sgs_hip.synthetic import make_scene
     from sgs_hip.camera import pinhole
@@ -47,7 +53,7 @@ def main():
         slack = T_whole[None] * (float(bg.abs().max()) + float(s.features.abs().max())) * 1.001 + 1e-4 * scale
         ok = full.shape == whole.shape and bool(((full - whole).abs() <= slack).all())
         print(f"world {world}: max |sharded - single| = {float((full - whole).abs().max()):.3e} (scale {scale:.3f})", flush=True)
-    flag = torch.tensor([1 if ok else 0], device=dev)
+    flag = torch.tensor([1 if ok else 0], device="cpu" if one_dev else dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0 and int(flag.item()) == 1:
         print("GAUSSIAN_SHARDED_OK", flush=True)
