@@ -33,6 +33,7 @@
 // rows of this parity (8 KB) + ids (1 KB), three bundles in flight.
 #include "sgs_kernels.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace sgs {
 
@@ -1023,8 +1024,11 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
 			       const uint32_t* order, int dealt)
 {
+	// (development) SGS_DEBUG_SWEEP_DYNLDS=<bytes>: unused dynamic LDS on top of the kernel's own, to pin the sweep at ONE
+	// workgroup per CU for occupancy experiments (is a stage of the kernel bound by per-workgroup latency or by the chip?)
+	static const int dyn_lds = getenv("SGS_DEBUG_SWEEP_DYNLDS") ? atoi(getenv("SGS_DEBUG_SWEEP_DYNLDS")) : 0;
 #define S2_LAUNCH(A_, D_)                                                                            \
-	hipLaunchKernelGGL((blend_accum_sweep2_kernel<A_, D_>), dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
+	hipLaunchKernelGGL((blend_accum_sweep2_kernel<A_, D_>), dim3(pxcd * 8), dim3(256), dyn_lds, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt)
 	if (arith == S2_EXACT) {

@@ -530,6 +530,17 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 			  void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
+	// The one-shot stream options (output pitch, norm plane) belong to THIS call whatever becomes of it: they are consumed
+	// before the first early return -- bad arguments, P == 0 -- so that a call that does nothing cannot leave them armed
+	// for the next forward on the stream (a stale pitch on a contiguous buffer would be an out-of-bounds write, a stale
+	// norm-plane flag would render a plane where a feature map is expected).
+	const std::shared_ptr<StreamCtx> cx_owner = ctx_of(stream);
+	StreamCtx* const cx = cx_owner.get();
+	std::lock_guard<std::mutex> ctx_lock(cx->mu);
+	const int out_pitch_opt = cx->option(SGS_OPT_OUT_PITCH);
+	cx->opt[SGS_OPT_OUT_PITCH] = -1;
+	const bool norm_plane = cx->option(SGS_OPT_NORM_PLANE) > 0;   // out_color is ONE (H, pitch) plane that receives sum_c out[c]^2
+	cx->opt[SGS_OPT_NORM_PLANE] = -1;
 	if (P < 0 || width <= 0 || height <= 0 || num_channels <= 0)
 		return fail(SGS_EINVAL, "bad sizes");
 	if (!geometry_buffer || !binning_buffer || !image_buffer || !out_color)
@@ -550,18 +561,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	const int gx = (width + SGS_TILE - 1) / SGS_TILE, gy = (height + SGS_TILE - 1) / SGS_TILE;
 	const int ntiles = gx * gy;
 
-	const std::shared_ptr<StreamCtx> cx_owner = ctx_of(stream);
-	StreamCtx* const cx = cx_owner.get();
-	std::lock_guard<std::mutex> ctx_lock(cx->mu);
 	cx->stat[SGS_STAT_FORWARDS]++;
 	cx->any_forward = true;
-	// the output pitch is consumed by the forward it was set for (a per-stream override never outlives one call: a
-	// stale pitch on a later forward with a contiguous buffer would be an out-of-bounds write)
-	const int out_pitch_opt = cx->option(SGS_OPT_OUT_PITCH);
-	cx->opt[SGS_OPT_OUT_PITCH] = -1;
-	// SGS_OPT_NORM_PLANE, consumed the same way: out_color is ONE (H, pitch) plane that receives sum_c out[c]^2
-	const bool norm_plane = cx->option(SGS_OPT_NORM_PLANE) > 0;
-	cx->opt[SGS_OPT_NORM_PLANE] = -1;
 	if (norm_plane && (num_channels % 128 != 0 || out_depth))
 		return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs a multiple of 128 channels and no depth plane");
 	StageTimer tm(cx->option(SGS_OPT_STAGE_TIMING), st);

@@ -84,3 +84,33 @@ def test_argument_contract_errors_match_reference():
     from simple_knn._C import distCUDA2
     with pytest.raises(RuntimeError, match="no CPU path"):
         distCUDA2(torch.zeros(5, 3))
+
+
+def test_one_shot_stream_options_do_not_survive_a_call_that_returns_early():
+    """SGS_OPT_OUT_PITCH / SGS_OPT_NORM_PLANE belong to the NEXT forward on the stream whatever becomes of it.
+    A forward that returns early -- P == 0 (rasterize_points.cu:85-120: the caller returns zeros) or an argument error --
+    must consume them too, or the following forward would write a contiguous buffer with a stale pitch.  Host-only: the
+    early returns happen before any device work."""
+    from sgs_hip import _lib
+    lib = _lib.load()
+    NONE = 0x7fffffff   # sgs_stream_set_option's "there was no override"
+
+    @_lib.ALLOC_FN
+    def alloc(user, n):
+        return None
+    out = (C.c_float * 4)()
+
+    def forward(P, with_callbacks):
+        cb = alloc if with_callbacks else _lib.ALLOC_FN()
+        return lib.sgs_rasterize_forward(cb, None, cb, None, cb, None, P, 0, 0, None, 16, 16, None, None, C.addressof(out), None, None,
+                                         1.0, None, None, None, None, None, 1.0, 1.0, 0, 128, C.addressof(out), None, None,
+                                         0, None)
+
+    for P, with_callbacks, want_rc in ((0, True, 0), (5, False, "error"), (-1, True, "error")):
+        assert lib.sgs_stream_set_option(None, _lib.OPT_OUT_PITCH, 1312) == NONE
+        assert lib.sgs_stream_set_option(None, _lib.OPT_NORM_PLANE, 1) == NONE
+        rc = forward(P, with_callbacks)
+        assert (rc == 0) if want_rc == 0 else (rc < 0), (P, with_callbacks, rc)
+        # clearing returns the previous override: there must be none left
+        assert lib.sgs_stream_set_option(None, _lib.OPT_OUT_PITCH, -1) == NONE, "stale output pitch survived an early return"
+        assert lib.sgs_stream_set_option(None, _lib.OPT_NORM_PLANE, -1) == NONE, "stale norm-plane flag survived an early return"
