@@ -24,7 +24,8 @@ _f = np.float32
 def build(force=False):
     so = os.path.join(_HERE, "libsgs_oracle.so")
     src = os.path.join(_HERE, "sgs_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = (src, os.path.join(_HERE, "sh_poly_table_c.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libsgs_oracle.so"])
     return so
 

@@ -1049,7 +1049,7 @@ hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const 
 				     ntiles, clear_ptr, clear_floats);
 }
 
-size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay)
+size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay, int slot_bytes)
 {
 	size_t off = 0;
 	auto take = [&](size_t bytes) { off = (off + 127) & ~(size_t)127; const size_t o = off; off += bytes; return o; };
@@ -1061,7 +1061,7 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	a.act_id = take((size_t)capacity * 4);
 	a.act_idx = take((size_t)capacity * 4);
 	a.order = take((size_t)PLAN_MAX * 4);
-	a.wgt = take((size_t)capacity * 1536);   // 1 KB per slot (fp32 rows / two bf16 terms), 1.5 KB with three bf16 terms
+	a.wgt = take((size_t)capacity * (size_t)slot_bytes);   // 1 KB per slot (fp32 rows / two bf16 terms), 1.5 KB with three bf16 terms
 	a.total = (off + 127) & ~(size_t)127;
 	if (lay) *lay = a;
 	return a.total;
@@ -1096,18 +1096,23 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// ends (cfg3: 48 -> 2 segments per tile row is 3 % faster than 16), but there must be enough
 		// workgroups to fill 256 CUs x 2 a few times over.
 		const int nc = a.C / 128;
+		// accumulate kernel (low nibble of the variant): 6 = round 4's ping-pong sweep (one 8-wave workgroup for both row
+		// parities, six bf16 products: the default); 8 = round 2's split-bf16 (three products) sweep, 9 = the same sweep on
+		// fp32-input MFMA; blend_sweep2.hip: 10 = f32-equivalent (six bf16 products), 11 = exact fp32 MFMA, 14 = six products
+		// with pre-split weights (round 3's default), 12 / 15 = six products on the double-rate MFMA (make X16=1).
+		// (the norm-plane epilogue of N1 lives in round 3's kernel: same arithmetic, same hand-over format)
+		const int arith_nib = ((split_mode & 15) == 6 && a.norm_plane) ? 14 : (split_mode & 15);
+		const bool sweep3 = arith_nib == 6;
+		// a ping-pong workgroup covers both parities and there is one per CU: half as many, twice as large work items
+		const int wg_per_item = sweep3 ? 1 : 2, wg_target = sweep3 ? 768 : 1536;
 		int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) * 8 : 48;
 		if (seg > SEGMAX) seg = SEGMAX;
 		if (((split_mode >> 4) & 15) == 0)
-			while (seg > 8 && (long long)a.gy * ((a.gx + seg - 1) / seg) * nc * 2 < 1536) seg /= 2;
+			while (seg > 8 && (long long)a.gy * ((a.gx + seg - 1) / seg) * nc * wg_per_item < wg_target) seg /= 2;
 		const int nseg = (a.gx + seg - 1) / seg;
 		seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
-		// accumulate kernel (low nibble of the variant): 8 = round 2's split-bf16 (three products) sweep, 9 = the same sweep on
-		// fp32-input MFMA; blend_sweep2.hip: 10 = f32-equivalent (six bf16 products), 11 = exact fp32 MFMA, 12 = six
-		// products on the double-rate MFMA (experiment).  All but 8 take fp32 weight rows.
-		const int arith_nib = split_mode & 15;
-		const bool sweep2 = (arith_nib >= 10 && arith_nib <= 15) || arith_nib == 7;   // 7 = six products, fp32 hand-over, split once per workgroup (S2_X6C)
-		const bool presplit3 = arith_nib >= 14;   // weights handed over as three bf16 terms
+		const bool sweep2 = (arith_nib >= 10 && arith_nib <= 15) || arith_nib == 7 || sweep3;   // 7 = six products, fp32 hand-over, split once per workgroup (S2_X6C)
+		const bool presplit3 = arith_nib >= 14 || sweep3;   // weights handed over as three bf16 terms
 		const bool exact = arith_nib == 9;
 		// weights pre-pass.  blend_weights2.hip (lane = two pixels: a third fewer instructions) is used for the fp32-row format
 		// (0.25 -> 0.22 ms at cfg3; the backward's pre-pass is the same kernel).  For the three-term format it is no faster
@@ -1137,14 +1142,18 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 					   a.usage_host);
 		if (usage_reported) *usage_reported = plan == 3 && a.usage_host != nullptr;
 		const int dealt = plan >= 2;
-		const int items = dealt ? nsegs : nsegs * nc * 2;   // x 2 row parities
-		const int pxcd = dealt ? 2 * ((nsegs + 15) / 16) * nc * 2 : (items + 7) / 8;   // workgroups per XCD
+		const int items = dealt ? nsegs : nsegs * nc * wg_per_item;   // x 2 row parities (one workgroup for both: ping-pong)
+		const int pxcd = dealt ? 2 * ((nsegs + 15) / 16) * nc * wg_per_item : (items + 7) / 8;   // workgroups per XCD
 		const uint32_t* order_arg = plan == 3 ? order : nullptr;
 #define SGS_LAUNCH_SWEEP(D_, E_)                                                                     \
 	hipLaunchKernelGGL((blend_accum_sweep_kernel<D_, E_>), dim3(pxcd * 8), dim3(256), 0, st, a.ranges, table, \
 			   nbatches, act_id, (const char*)wgt, a.features, a.bg, a.out, counter, a.W,   \
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
-		if (sweep2) {
+		if (sweep3) {
+			const hipError_t e3 = launch_accum_sweep3(st, (split_mode >> 8) & 15, a, table, nbatches, act_id, (const char*)wgt, counter,
+								  nc, seg, nseg, pxcd, items, g_sweep_trace, order_arg, dealt);
+			if (e3 != hipSuccess) return e3;
+		} else if (sweep2) {
 			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 7 ? 6 : arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : (arith_nib == 15 ? 5 : 1)))), a.norm_plane ? 32 : ((split_mode >> 8) & 15), a, table,
 								  nbatches, act_id, (const char*)wgt, counter, nc, seg, nseg, pxcd, items,
 								  g_sweep_trace, order_arg, dealt);
@@ -1156,7 +1165,11 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			case 2: SGS_LAUNCH_SWEEP(2, false); break;
 			case 3: SGS_LAUNCH_SWEEP(3, false); break;
 			case 4: SGS_LAUNCH_SWEEP(4, false); break;
-			case 8: SGS_LAUNCH_SWEEP(8, false); break;   // v_mfma_f32_32x32x16_bf16 products (reproducer only)
+#ifdef SGS_WITH_X16
+			case 8: SGS_LAUNCH_SWEEP(8, false); break;   // v_mfma_f32_32x32x16_bf16 products (reproducer only; make X16=1)
+#else
+			case 8: return hipErrorInvalidValue;         // (the x16 build of this sweep is not in the product library)
+#endif
 			default: SGS_LAUNCH_SWEEP(0, false); break;
 			}
 #undef SGS_LAUNCH_SWEEP

@@ -707,6 +707,10 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	if ((variant & 0xff) >= 32 && (variant & 0xff) <= 35 && variant < 0x100)
 		return fail(SGS_EINVAL, "blend variants 32-35 (fused single-kernel experiments) are not in this build (make FUSED=1)");
 #endif
+#ifndef SGS_WITH_X16   // (make X16=1: the double-rate-MFMA experiments, DESIGN.md 5.10 -- reproducers, not product)
+	if (variant >= 16 && ((variant & 15) == 12 || (variant & 15) == 15 || ((variant & 15) == 8 && ((variant >> 8) & 15) == 8)))
+		return fail(SGS_EINVAL, "blend variants on v_mfma_f32_32x32x16_bf16 (sweep nibble 12 / 15, 0x8.8) are not in this build (make X16=1)");
+#endif
 	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
@@ -834,12 +838,15 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		e = sgs::launch_norm_plane_background(st, out_color, (size_t)height * a.pitch, background, num_channels);
 	} else if (use_split) {
 		char* arena = bchunk + bl.arena;
-		// accumulate arithmetic (low nibble of the sweep word, blend_fwd_split.hip): default 14 = six bf16 products of the exact
-		// three-term splits on the x8 MFMA ("f32-equivalent", blend_sweep2.hip); variant 15 = 11 = fp32-input MFMA, bit-identical;
-		// variant 14 = 8 = round 2's two-term split (three products, 3 * 2^-16 per term: the fastest, not fp32-class)
-		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : 14));
+		// accumulate kernel (low nibble of the sweep word, blend_fwd_split.hip): default 6 = six bf16 products of the exact
+		// three-term splits on the x8 MFMA ("f32-equivalent") in round 4's ping-pong sweep (blend_sweep2.hip; 14 = the same
+		// products in round 3's two-workgroups-per-CU sweep, bit-identical); variant 15 = 11 = fp32-input MFMA, bit-identical to
+		// the contract; variant 14 = 8 = round 2's two-term split (three products, 3 * 2^-16 per term: the fastest, not fp32-class).
+		// SGS_DEFAULT_SWEEP=14 (environment, read once) restores round 3's kernel as the default for A/B runs.
+		static const int default_sweep = (getenv("SGS_DEFAULT_SWEEP") && atoi(getenv("SGS_DEFAULT_SWEEP")) == 14) ? 14 : 6;
+		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : default_sweep));
 		if (norm_plane) {
-			if ((split_word & 15) != 14 && (split_word & 15) != 11)
+			if ((split_word & 15) != 14 && (split_word & 15) != 11 && (split_word & 15) != 6)
 				return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs the default blend (variants 0 / 15)");
 			e = hipMemsetAsync(out_color, 0, (size_t)height * a.pitch * sizeof(float), st);
 			if (e != hipSuccess) return fail_hip(e, "memset (norm plane)");
@@ -963,7 +970,7 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 			uint32_t cap = (uint64_t)hint < cap_max ? hint : (uint32_t)cap_max;
 			if (bw_mode == 2) cap = 128u * (uint32_t)((ntiles + 1) / 2);   // (tests: guaranteed overflow -> gated fallback)
 			sgs::SplitArena lay;
-			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay);
+			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay, 1024);   // fp32 weight rows
 			void* scratch = nullptr;
 			hipMemPool_t pool = scratch_pool();
 			hipError_t ea = pool ? hipMallocFromPoolAsync(&scratch, bytes + 128, pool, st)

@@ -11,42 +11,40 @@
 
 namespace sgs {
 
-// SH -> RGB for one Gaussian (forward.cu:20-71).  sh points at (M,3) coefficients.
-__device__ __forceinline__ void sh_to_rgb(int deg, float px, float py, float pz,
-					  const float* __restrict__ campos,
-					  const float* __restrict__ sh, float* __restrict__ rgb,
+// View-dependent colour of one Gaussian from its (M, 3) SH coefficients: colour_c = sum_n Y_n(d) sh[n][c] + 0.5 with d the
+// unit vector from the camera centre to the Gaussian, negative results clamped to 0 and flagged for the backward (what
+// forward.cu:20-71 computes).  Y_n comes from the generated monomial table (sgs_device.h sh_eval), summed n ascending: the
+// oracle evaluates the same table in the same order, so the colours agree bit for bit.
+template <int DEG>
+__device__ __forceinline__ void sh_colour(float mx, float my, float mz, const float* __restrict__ campos,
+					  const float* __restrict__ sh, float* __restrict__ colour,
 					  uint8_t* __restrict__ clamped)
 {
-	const float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
-	const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-	const float x = dx / len, y = dy / len, z = dz / len;
+	constexpr int NB = (DEG + 1) * (DEG + 1);
+	const float vx = mx - campos[0], vy = my - campos[1], vz = mz - campos[2];
+	const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+	float px[4], py[4], pz[4];
+	px[0] = py[0] = pz[0] = 1.f;
+	px[1] = vx / len;
+	py[1] = vy / len;
+	pz[1] = vz / len;
+#pragma unroll
+	for (int e = 2; e < 4; e++) {
+		px[e] = px[e - 1] * px[1];
+		py[e] = py[e - 1] * py[1];
+		pz[e] = pz[e - 1] * pz[1];
+	}
+	float Y[NB];
+#pragma unroll
+	for (int n = 0; n < NB; n++) Y[n] = sh_eval(n, 0, px, py, pz);
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
-#define SGS_S(i) sh[3 * (i) + c]
-		float r = SH_C0 * SGS_S(0);
-		if (deg > 0) {
-			r = r - SH_C1 * y * SGS_S(1) + SH_C1 * z * SGS_S(2) - SH_C1 * x * SGS_S(3);
-			if (deg > 1) {
-				const float xx = x * x, yy = y * y, zz = z * z;
-				const float xy = x * y, yz = y * z, xz = x * z;
-				r = r + SH_C2[0] * xy * SGS_S(4) + SH_C2[1] * yz * SGS_S(5) +
-				    SH_C2[2] * (2.0f * zz - xx - yy) * SGS_S(6) +
-				    SH_C2[3] * xz * SGS_S(7) + SH_C2[4] * (xx - yy) * SGS_S(8);
-				if (deg > 2) {
-					r = r + SH_C3[0] * y * (3.0f * xx - yy) * SGS_S(9) +
-					    SH_C3[1] * xy * z * SGS_S(10) +
-					    SH_C3[2] * y * (4.0f * zz - xx - yy) * SGS_S(11) +
-					    SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SGS_S(12) +
-					    SH_C3[4] * x * (4.0f * zz - xx - yy) * SGS_S(13) +
-					    SH_C3[5] * z * (xx - yy) * SGS_S(14) +
-					    SH_C3[6] * x * (xx - 3.0f * yy) * SGS_S(15);
-				}
-			}
-		}
-#undef SGS_S
+		float r = 0.f;
+#pragma unroll
+		for (int n = 0; n < NB; n++) r += Y[n] * sh[3 * n + c];
 		r += 0.5f;
 		clamped[c] = (r < 0) ? 1 : 0;
-		rgb[c] = fmax_(r, 0.0f);
+		colour[c] = fmax_(r, 0.0f);
 	}
 }
 
@@ -98,26 +96,35 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 	const Cov2D c2 = cov2d_parts(px, py, pz, fx, fy, tanx, tany, cov3D, view);
 	const float det = c2.a * c2.c - c2.b * c2.b;
 	if (det == 0.0f) break;
-	const float det_inv = 1.f / det;
-	const float conx = c2.c * det_inv, cony = -c2.b * det_inv, conz = c2.a * det_inv;
-	const float mid = 0.5f * (c2.a + c2.c);
-	const float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
-	const float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
-	const float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
+	// conic = inverse of the 2x2 covariance; screen extent = 3 sigma of its larger eigenvalue (half_trace +- root, the
+	// root floored at sqrt(0.1) as the reference does), rounded up to whole pixels
+	const float inv_det = 1.f / det;
+	const float4 conic_o = make_float4(c2.c * inv_det, -c2.b * inv_det, c2.a * inv_det, opacities[i]);
+	const float half_trace = 0.5f * (c2.a + c2.c);
+	const float root = sqrtf(fmax_(0.1f, half_trace * half_trace - det));
+	const float extent = ceilf(3.f * sqrtf(fmax_(half_trace + root, half_trace - root)));
 	const float pix_x = ndc2pix(ppx, W), pix_y = ndc2pix(ppy, H);
 	uint32_t x0, y0, x1, y1;
-	get_rect(pix_x, pix_y, (int)my_radius, gx, gy, x0, y0, x1, y1);
+	get_rect(pix_x, pix_y, (int)extent, gx, gy, x0, y0, x1, y1);
 	if ((x1 - x0) * (y1 - y0) == 0) break;
 
-	if (!colors_precomp)
-		sh_to_rgb(D, px, py, pz, campos, shs + (size_t)i * M * 3,
-			  rgb + (size_t)i * num_channels, clamped + 3 * (size_t)i);
+	if (!colors_precomp) {
+		const float* sh = shs + (size_t)i * M * 3;
+		float* col = rgb + (size_t)i * num_channels;
+		uint8_t* cl = clamped + 3 * (size_t)i;
+		switch (D) {
+		case 0: sh_colour<0>(px, py, pz, campos, sh, col, cl); break;
+		case 1: sh_colour<1>(px, py, pz, campos, sh, col, cl); break;
+		case 2: sh_colour<2>(px, py, pz, campos, sh, col, cl); break;
+		default: sh_colour<3>(px, py, pz, campos, sh, col, cl); break;
+		}
+	}
 
 	depths[i] = pv.z;
 	sort_key = __float_as_uint(pv.z);
-	radii[i] = (int)my_radius;
+	radii[i] = (int)extent;
 	means2D[i] = make_float2(pix_x, pix_y);
-	conic_opacity[i] = make_float4(conx, cony, conz, opacities[i]);
+	conic_opacity[i] = conic_o;
 	tiles_touched[i] = (y1 - y0) * (x1 - x0);
 	} while (0);
 

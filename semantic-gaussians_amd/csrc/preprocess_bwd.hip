@@ -50,16 +50,7 @@ __device__ __forceinline__ Mat3 sym_from6(const float* __restrict__ c, float off
 	return V;
 }
 
-// value (q = 0) or partial derivative (q = 1..3) of basis function n at (x,y,z), powers pre-tabulated
-__device__ __forceinline__ float sh_eval(int n, int q, const float px[4], const float py[4], const float pz[4])
-{
-	float acc = 0.f;
-#pragma unroll
-	for (int t = SH_RANGE[n][q][0]; t < SH_RANGE[n][q][1]; t++)
-		acc += SH_TERM[t].c * px[SH_TERM[t].i] * py[SH_TERM[t].j] * pz[SH_TERM[t].k];
-	return acc;
-}
-
+// (sh_eval: sgs_device.h -- the forward colour uses the same table)
 template <int DEG>
 __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float* __restrict__ dsh, const float d[3],
 					    const float grgb[3], float gdir[3])

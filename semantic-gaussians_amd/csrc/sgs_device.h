@@ -15,6 +15,8 @@
 #define SGS_TILE 16
 #define SGS_TILE_PX 256
 
+#include "sh_poly_table.h"
+
 namespace sgs {
 
 __device__ __forceinline__ float fmin_(float a, float b) { return a < b ? a : b; }
@@ -134,18 +136,21 @@ __device__ __forceinline__ float expf_contract(float x)
 	return __uint_as_float(__float_as_uint(p) + (__float_as_uint(nf) << 23));
 }
 
-// Standard (w,x,y,z) rotation matrix, rows R[0..2] (forward.cu:127-137).
-__device__ __forceinline__ void rot_matrix(float r, float x, float y, float z, float R[3][3])
+// Rotation matrix of the quaternion (w, v) as given (not normalised, like the reference: forward.cu:127-137), written in
+// cyclic form: with (i, j, k) an even permutation of (0, 1, 2)
+//     R[i][i] = 1 - 2 (v_a^2 + v_b^2)   (a < b the two other axes),   R[i][j] = 2 (v_i v_j - w v_k),   R[j][i] = 2 (v_i v_j + w v_k).
+// Each entry is the same fp32 expression tree as the oracle's (products commute exactly), which the bit-exact radii need.
+__device__ __forceinline__ void rot_matrix(float w, float vx, float vy, float vz, float R[3][3])
 {
-	R[0][0] = 1.f - 2.f * (y * y + z * z);
-	R[0][1] = 2.f * (x * y - r * z);
-	R[0][2] = 2.f * (x * z + r * y);
-	R[1][0] = 2.f * (x * y + r * z);
-	R[1][1] = 1.f - 2.f * (x * x + z * z);
-	R[1][2] = 2.f * (y * z - r * x);
-	R[2][0] = 2.f * (x * z - r * y);
-	R[2][1] = 2.f * (y * z + r * x);
-	R[2][2] = 1.f - 2.f * (x * x + y * y);
+	const float v[3] = {vx, vy, vz};
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		const int j = (i + 1) % 3, k = (i + 2) % 3;
+		const int a = j < k ? j : k, b = j < k ? k : j;
+		R[i][i] = 1.f - 2.f * (v[a] * v[a] + v[b] * v[b]);
+		R[i][j] = 2.f * (v[i] * v[j] - w * v[k]);
+		R[j][i] = 2.f * (v[i] * v[j] + w * v[k]);
+	}
 }
 
 // Sigma = R diag(mod*s)^2 R^T, accumulated as sum_k M(k,i) M(k,j) with
@@ -186,24 +191,29 @@ __device__ __forceinline__ Cov2D cov2d_parts(float mx, float my, float mz, float
 					     const float* __restrict__ view)
 {
 	Cov2D o;
-	f3 t = xf4x3(view, mx, my, mz);
-	const float limx = 1.3f * tanx, limy = 1.3f * tany;
-	const float txtz = t.x / t.z, tytz = t.y / t.z;
-	t.x = fmin_(limx, fmax_(-limx, txtz)) * t.z;
-	t.y = fmin_(limy, fmax_(-limy, tytz)) * t.z;
-	o.t[0] = t.x; o.t[1] = t.y; o.t[2] = t.z;
-	o.txtz = txtz; o.tytz = tytz;
-	const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
-	const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+	const f3 cam = xf4x3(view, mx, my, mz);
+	// screen-space guard band: the view-space mean is pulled back to 1.3 x the frustum's half extent per axis before the
+	// Jacobian is formed (the unclamped ratios are kept: the backward gates on them)
+	const float focal[2] = {fx, fy}, bound[2] = {1.3f * tanx, 1.3f * tany};
+	const float ratio[2] = {cam.x / cam.z, cam.y / cam.z};
+	const float depth = cam.z;
+	float lat[2];   // clamped lateral coordinates
 #pragma unroll
-	for (int r = 0; r < 3; r++) {
-		o.T[0][r] = view[4 * r] * J00 + view[4 * r + 2] * J02;
-		o.T[1][r] = view[4 * r + 1] * J11 + view[4 * r + 2] * J12;
+	for (int a = 0; a < 2; a++) lat[a] = fmin_(bound[a], fmax_(-bound[a], ratio[a])) * depth;
+	o.t[0] = lat[0]; o.t[1] = lat[1]; o.t[2] = depth;
+	o.txtz = ratio[0]; o.tytz = ratio[1];
+	// Jacobian of the perspective map at that point: row a = (focal_a / z) e_a - (focal_a lat_a / z^2) e_z, times the
+	// view rotation (column-major `view`: element (row r, col c) = view[4 c + r])
+#pragma unroll
+	for (int a = 0; a < 2; a++) {
+		const float jd = focal[a] / depth, jz = -(focal[a] * lat[a]) / (depth * depth);
+#pragma unroll
+		for (int r = 0; r < 3; r++) o.T[a][r] = view[4 * r + a] * jd + view[4 * r + 2] * jz;
 	}
 	const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]},
 			       {cov3D[1], cov3D[3], cov3D[4]},
 			       {cov3D[2], cov3D[4], cov3D[5]}};
-	float X[2][3];
+	float X[2][3];   // T V
 #pragma unroll
 	for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -212,21 +222,23 @@ __device__ __forceinline__ Cov2D cov2d_parts(float mx, float my, float mz, float
 	o.a = X[0][0] * o.T[0][0] + X[0][1] * o.T[0][1] + X[0][2] * o.T[0][2];
 	o.b = X[1][0] * o.T[0][0] + X[1][1] * o.T[0][1] + X[1][2] * o.T[0][2];
 	o.c = X[1][0] * o.T[1][0] + X[1][1] * o.T[1][1] + X[1][2] * o.T[1][2];
-	o.a += 0.3f;
+	o.a += 0.3f;   // the one-pixel low-pass filter
 	o.c += 0.3f;
 	return o;
 }
 
-__device__ constexpr float SH_C0 = 0.28209479177387814f;
-__device__ constexpr float SH_C1 = 0.4886025119029199f;
-__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f,
-				       0.31539156525252005f, -1.0925484305920792f,
-				       0.5462742152960396f};
-__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
-				       -0.4570457994644658f, 0.3731763325901154f,
-				       -0.4570457994644658f, 1.445305721320277f,
-				       -0.5900435899266435f};
-
+// Real spherical harmonics from the GENERATED monomial table (sh_poly_table.h, tools/gen_sh_table.py): value (q = 0) or
+// partial derivative (q = 1..3) of basis function n at the unit vector whose powers are tabulated in px / py / pz.
+// Term order = table order: acc += ((c x^i) y^j) z^k, left to right -- part of the arithmetic contract with the oracle
+// (the forward colour must agree bit for bit).  n and q must be compile-time constants after unrolling.
+__device__ __forceinline__ float sh_eval(int n, int q, const float px[4], const float py[4], const float pz[4])
+{
+	float acc = 0.f;
+#pragma unroll
+	for (int t = SH_RANGE[n][q][0]; t < SH_RANGE[n][q][1]; t++)
+		acc += SH_TERM[t].c * px[SH_TERM[t].i] * py[SH_TERM[t].j] * pz[SH_TERM[t].k];
+	return acc;
+}
 
 // Work-list chunk starts (blend_fwd_split.hip): chunk 0 of EVERY tile is pre-assigned (slots [tile * 128, tile * 128 + 128));
 // only chunks >= 1 go through `table`, at index (range.x >> 7) + tile + c.  That index is collision free among

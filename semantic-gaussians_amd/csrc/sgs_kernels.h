@@ -106,7 +106,9 @@ struct SplitArena {   // byte offsets inside the arena chunk
 	size_t counter, nbatches, table, act_id, act_idx, order, wgt, total;
 	uint32_t capacity;   // work-list slots (1 KB of weights + 4 B id each)
 };
-size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay);
+// slot_bytes: 1536 = three bf16 terms per weight (the forward's default hand-over), 1024 = fp32 rows / two bf16 terms (the
+// exact and two-term variants, and the backward's work list: its stream-ordered scratch is a third smaller for it)
+size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay, int slot_bytes = 1536);
 // `mark` is called (with `mark_user`) between the weights pre-pass and the accumulate kernel, on `st`
 // (stage timing).
 // *usage_reported: the plan kernel wrote a.usage_host (no copy of the counter needed)
@@ -125,6 +127,13 @@ hipError_t launch_blend_weights2(hipStream_t st, int mode, const uint2* ranges, 
 // SGS_OPT_NORM_PLANE with nothing to blend: plane[i] = sum_c bg[c]^2
 hipError_t launch_norm_plane_background(hipStream_t st, float* plane, size_t n, const float* bg, int C);
 hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFwdArgs& a, const uint32_t* table,
+			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
+			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
+			       const uint32_t* order, int dealt);
+
+// round 4: the same sweep as one 8-wave workgroup per (segment, 128 channels) for both row parities ("ping-pong", sweep
+// nibble 6): items / pxcd count (segment, chunk) pairs, not (segment, chunk, parity) triples
+hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
 			       const uint32_t* order, int dealt);

@@ -41,18 +41,22 @@ def shard_views(n_views, rank=None, world_size=None):
 def render_views_sharded(render_fn, views, gather_to=None):
     """Each rank renders views[rank::world].  No collective touches the render itself.
 
-    gather_to=None (default): results stay on the GPU that produced them -- returns {view index: tensor} of this
-    rank's views (a 3.3 GB feature map per view at BASELINE config 4 has no business crossing PCIe or being pickled).
+    gather_to=None (default since round 3 -- it used to be 0): results stay on the GPU that produced them -- returns
+    {view index: tensor} of this rank's views (a 3.3 GB feature map per view at BASELINE config 4 has no business crossing
+    PCIe or being pickled).  Callers that relied on the old default pass gather_to=0 explicitly.
     gather_to=r: rank r additionally receives the other ranks' results as TENSORS (grouped point-to-point receives
     straight into device memory under RCCL; every view must have the same shape and dtype) and returns the list in
-    view order; the other ranks return None."""
+    view order; the other ranks return None.  An empty view list returns {} / [] / None without any collective."""
     rank, w = world()
+    if len(views) == 0:
+        return {} if gather_to is None else ([] if rank == gather_to or w == 1 else None)
     mine = {i: render_fn(views[i]) for i in shard_views(len(views), rank, w)}
     if gather_to is None:
         return mine
     if w == 1:
         return [mine[i] for i in range(len(views))]
-    # shape / dtype of a view: known to every rank that rendered one; agree on it with one tiny object collective
+    # shape / dtype of a view: known to every rank that rendered one (rank 0 always has: views is not empty); agree on it
+    # with one tiny object collective
     meta = [None] * w
     first = next(iter(mine.values())) if mine else None
     dist.all_gather_object(meta, None if first is None else (tuple(first.shape), str(first.dtype).replace("torch.", ""), first.device.type))
@@ -229,13 +233,25 @@ def render_gaussian_sharded(render_partial_fn, bg, order=None, all_gather=True):
     band, _ = composite_over([recv[r] for r in order], bg)
     if not all_gather:
         return band
+    # every rank needs every band: an all-gather of bands of (possibly) different heights, done as grouped point-to-point
+    # operations on the exact sizes -- no zero padding, no staging copy of the band, every xGMI link carries one band each
+    # way (uniform bands could use all_gather_into_tensor; 61 tile rows over 8 ranks are not uniform)
     sizes = [band_rows(H, r, w) for r in range(w)]
-    hmax = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((band.shape[0], hmax, band.shape[2]), dtype=band.dtype, device=band.device)
-    pad[:, :band.shape[1]] = band
-    parts = [torch.empty_like(pad) for _ in range(w)]
-    dist.all_gather(parts, pad)
-    return torch.cat([parts[r][:, :sizes[r][1] - sizes[r][0]] for r in range(w)], dim=1)
+    band = band.contiguous()
+    parts = [band if r == rank else torch.empty((band.shape[0], sizes[r][1] - sizes[r][0], band.shape[2]), dtype=band.dtype, device=band.device)
+             for r in range(w)]
+    ops = []
+    for peer in range(w):
+        if peer == rank:
+            continue
+        if band.numel():
+            ops.append(dist.P2POp(dist.isend, band, peer))
+        if parts[peer].numel():
+            ops.append(dist.P2POp(dist.irecv, parts[peer], peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return torch.cat(parts, dim=1)
 
 
 def timed_steps(step_fn, steps, warmup, sync_fn=None):

@@ -156,7 +156,10 @@ def test_cfg5_gaussian_sharding_two_depth_slabs(orc):
     # pixel can keep T as large as 0.01.  Per shard the rule restarts (the back slab begins at T = 1), so the sharded
     # picture additionally holds whatever lies behind the global stop, weighted by at most the T the single render
     # stopped with.  Everything else is fp32 rounding.
-    slack = T_whole[None] * (float(bg.abs().max()) + float(s.features.abs().max())) * 1.001 + 1e-4 * scale
+    # beyond fp32 rounding the renders may differ only where the single render took the T < 1e-4 stop (such a pixel ends
+    # with 1e-4 <= T < 1e-2); elsewhere the composite must agree to rounding (no O(1) slack for unsaturated pixels)
+    slack = torch.where(T_whole < 1e-2, T_whole * (float(bg.abs().max()) + float(s.features.abs().max())) * 1.001,
+                        torch.zeros_like(T_whole))[None] + 1e-5 * scale
     assert bool(((comp - whole).abs() <= slack).all())
     # ... and where no pixel ever reaches the stop rule (thin scene) the composite IS the single render, to rounding
     thin = s._replace(opacities=s.opacities * 0.02)
@@ -272,7 +275,7 @@ def test_cfg5_full_size_on_one_gpu():
         partials.append((A, T))
     comp, t_total = sdist.composite_over(partials, bg)
     scale = float(whole.abs().max())
-    slack = T_whole[None] * (float(bg.abs().max()) + 1.0) * 1.001 + 1e-4 * scale
+    slack = torch.where(T_whole < 1e-2, T_whole * (float(bg.abs().max()) + 1.0) * 1.001, torch.zeros_like(T_whole))[None] + 1e-5 * scale
     for row in (2, 30, 59):
         rows = slice(row * 16, row * 16 + 16)
         assert bool(((comp[:, rows] - whole[:, rows]).abs() <= slack[:, rows]).all())

@@ -62,6 +62,9 @@ def _worker(rank, world, port, q):
         imgs = sd.render_views_sharded(lambda cam: _oracle_render(scene, cam), views, gather_to=0)   # tensors, point to point
         local = sd.render_views_sharded(lambda cam: _oracle_render(scene, cam), views)                # default: results stay put
         assert sorted(local) == list(range(rank, 5, world))
+        # an empty view list: no collective, no StopIteration
+        assert sd.render_views_sharded(lambda cam: None, []) == {}
+        assert sd.render_views_sharded(lambda cam: None, [], gather_to=0) == ([] if rank == 0 else None)
         # --- channel sharding: exact, one all_gather
         full = sd.render_channel_sharded(
             lambda f, b: _oracle_render(scene, views[1], f, b), scene.features, scene.bg)

@@ -44,7 +44,7 @@ def _check_forward(orc, scene, cam, want_depth=False, variant=0, binning_mode=0,
         Cn = 3 if kw.get("shs") is not None else (scene.features.shape[1] if kw.get("colors") is None else kw["colors"].shape[1])
         # C >= 128: 0 (default) = six bf16 products of exact three-term splits ("f32-equivalent"), 14 / nibble 8 = round 2's
         # two-term split; both differ from the oracle's bits, everything else is bit-exact
-        bf16 = variant in (0, 14) or (variant >= 16 and (variant & 15) in (8, 10, 12, 13, 14))
+        bf16 = variant in (0, 14) or (variant >= 16 and (variant & 15) in (6, 7, 8, 10, 12, 13, 14))
         exact = not (bf16 and Cn >= 128 and not want_depth)
     fw = oracle_forward(orc, scene, cam, want_depth=want_depth, **kw)
     raster.set_binning_mode(binning_mode)
@@ -820,7 +820,7 @@ def _sparse_scene():
     return scene._replace(bg=torch.randn(128, generator=g), scales=scene.scales * 0.3), cam
 
 
-@pytest.mark.parametrize("variant", [0, 15, 0x6A, 0x6B, 0x6E, 0x6F])
+@pytest.mark.parametrize("variant", [0, 15, 0x6A, 0x6B, 0x6E, 0x66, 14])
 def test_empty_tiles_get_the_background(orc, variant):
     scene, cam = _sparse_scene()
     fw = oracle_forward(orc, scene, cam)
@@ -831,9 +831,9 @@ def test_empty_tiles_get_the_background(orc, variant):
     out = _hip_forward(scene, cam, variant=variant)[1].cpu().numpy()
     # 0 = round 2's two-term split (3 * 2^-16 of |f| w per term, the bg term included); the six-product paths carry the
     # operands exactly; 15 / 0x6B are the fp32 chain itself
-    tol = 0 if variant in (15, 0x6B) else (2e-4 if variant == 0 else 1e-5)
+    tol = 0 if variant in (15, 0x6B) else (2e-4 if variant == 14 else 1e-5)
     assert np.abs(out - fw["out"]).max() <= tol
-    if variant == 0:
+    if variant == 14:
         return
     # every pixel of an empty tile is exactly the background
     gx = (208 + 15) // 16

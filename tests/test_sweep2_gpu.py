@@ -2,7 +2,10 @@
 the oracle, through the C-ABI.  Variants (low nibble of the blend variant; 0x60 = 48-tile segments, the default):
   0x6B  exact fp32 MFMA   -- bit-identical feature map;
   0x6A  f32-equivalent    -- six bf16 products of the exact three-term splits; |error| <= X6_TOL * sum |f| w;
-  0x6C  (experiment) the same on the double-rate MFMA.
+  0x6E  the same with the weights pre-split by the weights pre-pass (round 3's default);
+  0x66  round 4's default: the 0x6E arithmetic in the ping-pong sweep (one 8-wave workgroup for both row parities,
+        MFMA phase of one half beside the load / store phase of the other) -- bit-identical to 0x6E;
+  (0x6C / 0x6F, the double-rate-MFMA experiments, are not in the product library: make X16=1.)
 Every integer output stays bit-exact (it comes from the shared front end and weights pre-pass)."""
 import numpy as np
 import pytest
@@ -15,6 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 V_X6, V_EXACT, V_X6W, V_X6S, V_X6P, V_X6PW = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E, 0x6F
+V_PP = 0x66       # round 4: ping-pong sweep (the default kernel; 0x6_ pins 48-tile segments like the others)
 V_X6C = 0x67      # six products, fp32 weights handed over, split once per workgroup into LDS: bit-identical to V_X6P
 # Against the fp32 ORACLE the difference is dominated by the oracle's own roundings: its multiply-add chain rounds once
 # per contribution (<= 2^-24 |partial sum| each, K ~ 50-300 contributions), the six-product path drops
@@ -57,7 +61,7 @@ def check(orc, scene, cam, variant, seg=None, **kw):
 SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64), (128, 336, 48)]
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6W, V_X6S, V_X6P, V_X6PW, V_X6C])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6S, V_X6P, V_X6C, V_PP])
 @pytest.mark.parametrize("C,W,H", SHAPES)
 def test_sweep2_shapes(orc, variant, C, W, H):
     """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
@@ -67,7 +71,7 @@ def test_sweep2_shapes(orc, variant, C, W, H):
     check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW, V_X6C])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
 def test_sweep2_background_and_short_lists(orc, variant):
     """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
     scene, cam = small_scene(P=60, C=128, W=208, H=96, fx=170.0, seed=5)
@@ -78,7 +82,7 @@ def test_sweep2_background_and_short_lists(orc, variant):
     assert (r[:, 0] == r[:, 1]).any()   # empty tiles exist
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW, V_X6C])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
 def test_sweep2_long_lists(orc, variant):
     """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
     deferred stores ride along tiles of very different lengths."""
@@ -90,7 +94,7 @@ def test_sweep2_long_lists(orc, variant):
     check(orc, scene, cam, variant, seg=6)   # one 49-tile segment: ~2900 batches
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6PW, V_X6C])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
 def test_sweep2_padded_pitch(orc, variant):
     """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
     from sgs_hip import raster
@@ -102,12 +106,12 @@ def test_sweep2_padded_pitch(orc, variant):
         raster.OUTPUT_PITCH_ALIGN = 0
 
 
-def test_sweep2_deterministic_under_load(orc):
+@pytest.mark.parametrize("V", [V_X6P, V_PP])
+def test_sweep2_deterministic_under_load(orc, V):
     """The same frame 300 times with two other views in flight on other streams: every feature map bit-identical
     (a stale ring stage -- a bundle consumed before it landed -- would show up as a differing map)."""
     from sgs_hip import raster
     scene, cam = small_scene(P=6000, C=256, W=400, H=160, fx=300.0, seed=21)
-    V = V_X6P
     ref = _hip_forward(scene, cam, variant=V)[1].clone()
     side = [torch.cuda.Stream(device=DEV) for _ in range(2)]
     bad = 0
@@ -121,7 +125,7 @@ def test_sweep2_deterministic_under_load(orc):
     assert bad == 0
 
 
-@pytest.mark.parametrize("variant", [0, V_EXACT, V_X6P, 14])
+@pytest.mark.parametrize("variant", [0, V_EXACT, V_X6P, V_PP, 14])
 def test_feature_scale_invariance_is_bit_exact(variant):
     """A size-independent property of every accumulate arithmetic: scaling the features and the background by a power of two
     scales the feature map by exactly that power of two (roundings commute with 2^k away from over / underflow) -- for the
@@ -147,3 +151,33 @@ def test_cooperative_split_equals_presplit_bitwise():
         a = _hip_forward(scene, cam, variant=V_X6P)[1]
         b = _hip_forward(scene, cam, variant=V_X6C)[1]
         assert torch.equal(a, b)
+
+
+def test_ping_pong_sweep_equals_round3_sweep_bitwise():
+    """The ping-pong kernel (default) issues the same six products in the same order into the same accumulators as
+    round 3's sweep: bit-identical maps, for staggered and plain pitches, several channel chunks, a non-zero background,
+    short segments (seg nibble 1 = 8 tiles: many unpaired halves) and long lists (the table window slides)."""
+    cases = [(4000, 256, 208, 96, 170.0, 1, 1.0), (30000, 128, 400, 64, 170.0, 2, 1.0), (500, 512, 48, 40, 170.0, 3, 1.0),
+             (3000, 128, 336, 48, 170.0, 4, 1.0), (40000, 128, 784, 32, 600.0, 77, 3.0)]
+    for (P, C, W, H, fx, seed, sc) in cases:
+        scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=fx, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        scene = scene._replace(bg=torch.randn(C, generator=g), scales=scene.scales * sc,
+                               opacities=scene.opacities * (0.05 if sc > 1 else 1.0))
+        for segn in (6, 1, 3):
+            a = _hip_forward(scene, cam, variant=0xE | (segn << 4))[1]
+            b = _hip_forward(scene, cam, variant=0x6 | (segn << 4))[1]
+            assert torch.equal(a, b), (P, C, W, H, segn)
+        d = _hip_forward(scene, cam, variant=0)[1]      # the default: the same kernel with its own segment length
+        assert torch.equal(d, _hip_forward(scene, cam, variant=0x6E)[1]), (P, C, W, H)
+
+
+def test_x16_experiments_are_not_in_the_product_library():
+    """DESIGN.md 5.10 / profiles/r04_x16_gemm_aggressor.txt: the double-rate-MFMA sweeps damage forwards running beside them
+    on some boxes (a library GEMM beside the same victim does not): they are built only by `make X16=1`; the default library
+    answers their variants with an error instead of running them."""
+    scene, cam = small_scene(P=500, C=128, W=64, H=48, fx=100.0, seed=2)
+    for v in (0x6C, 0x6F, 0x16F, 0x808, 0x1F):
+        with pytest.raises(RuntimeError, match="X16"):
+            _hip_forward(scene, cam, variant=v)
+    _hip_forward(scene, cam, variant=0)   # (and the stream is usable afterwards)

@@ -50,7 +50,12 @@ def main():
                                                              cam.tanfovy, H, W, e, 0, cam.camera_center, False, False, C, False)
         T_whole = raster.image_views(img, W, H)["final_T"]
         scale = float(whole.abs().max())
-        slack = T_whole[None] * (float(bg.abs().max()) + float(s.features.abs().max())) * 1.001 + 1e-4 * scale
+        # The two renders may only differ beyond fp32 rounding where the SINGLE render took the reference's T < 1e-4 stop
+        # (it acts per shard in the sharded render): such a pixel ends with 1e-4 <= T < 1e-2 (alpha <= 0.99), and what lies
+        # behind the stop is at most T * (|bg| + max |f|).  Everywhere else (T >= 1e-2: no stop in either render) the
+        # composite must agree to rounding -- a wrong shard order or operator there must not hide in an O(1) slack.
+        slack = torch.where(T_whole < 1e-2, T_whole * (float(bg.abs().max()) + float(s.features.abs().max())) * 1.001,
+                            torch.zeros_like(T_whole))[None] + 1e-5 * scale
         ok = full.shape == whole.shape and bool(((full - whole).abs() <= slack).all())
         print(f"world {world}: max |sharded - single| = {float((full - whole).abs().max()):.3e} (scale {scale:.3f})", flush=True)
     flag = torch.tensor([1 if ok else 0], device="cpu" if one_dev else dev)
