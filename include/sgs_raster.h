@@ -335,8 +335,8 @@ int sgs_set_binning_mode(int mode);
 /* Backward blend: 0 (default) = for num_channels >= 32 with num_channels % 32 == 0 the channel work runs
  * as two matrix products over the forward's work list (blend_bwd_mfma.hip; scratch comes from a
  * stream-ordered pool on `stream`), the per-chunk kernel otherwise; the products are split-bf16 x 3 MFMA
- * products with fp32 accumulation (<= 3 * 2^-16 of sum |a||b| per product, the forward's default
- * arithmetic); 3 = the same with exact fp32 products (v_mfma_f32_32x32x2_f32), ~1.5 ms slower at
+ * products with fp32 accumulation (two bf16 terms per operand: <= 3 * 2^-16 of sum |a||b| per product -- round 2's
+ * forward arithmetic, NARROWER than the forward's current default of three exact terms / six products); 3 = the same with exact fp32 products (v_mfma_f32_32x32x2_f32), ~1.5 ms slower at
  * 1M x 512 x 968x1296; 1 = always the per-chunk VALU kernel (blend_bwd.hip); 2 = as 0 with a deliberately
  * undersized work-list arena (exercises the overflow fallback; tests only).  All within 1e-4 of the largest
  * gradient entry of the float64 oracle (tests).  Returns the previous mode. */

@@ -8,7 +8,7 @@
 //
 //  * bounding box by order-preserving integer atomics, kept ON DEVICE (the reference does
 //    two blocking D2H copies, simple_knn.cu:197,200);
-//  * 30-bit Morton codes + rocPRIM radix sort of (code, index) on the caller's stream;
+//  * 30-bit Morton codes, sorted with this library's own LSD radix sort (depth_sort.hip) on the caller's stream;
 //  * points gathered into Morton order as float4 (coalesced 16-B reads);
 //  * a two-level box hierarchy: 64-point leaves (one wave of Morton-consecutive points) under
 //    1024-point super boxes -- the reference has the 1024-point level only, so a surviving
@@ -16,7 +16,7 @@
 //  * one lane per query in Morton order: the 64 lanes of a wave are spatial neighbours and
 //    walk almost the same boxes, so box tests are near-uniform branches and leaf reads hit L1.
 #include "sgs_kernels.h"
-#include <cstring>   // rocPRIM's texture iterator calls host memset
+#include <cstring>
 #include <float.h>
 
 namespace sgs {

@@ -5,8 +5,9 @@
         colour + median depth on sampled tile rows, bit for bit;
   cfg4  5M Gaussians x 768 channels (P * C > 2^31: the reference's int index overflows, CR/forward.cu:356), 840x1297
         (a width that is not a multiple of 16): integers in full, sampled tile rows against the oracle;
-  cfg5  Gaussian sharding as a two-slab depth-ordered composite of HIP (A, T) partials against the single render
-        (one GPU; P scaled to 2M -- the 50M x 256 table is a capacity statement, not a different code path);
+  cfg5  Gaussian sharding as a depth-ordered composite of HIP (A, T) partials against the single render on one GPU: a
+        two-slab composite at P = 2M, and cfg5 at its stated 50M Gaussians x 256 channels as eight depth slabs through the
+        HIP composite kernel (test_cfg5_full_size_on_one_gpu);
   cfg3  the default (six-product, f32-equivalent) arithmetic DIRECTLY against the oracle and against the exact (float64)
         composite: all 512 channels on four tile rows, element-wise.
 """

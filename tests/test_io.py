@@ -1,5 +1,6 @@
 """Gaussian PLY and fusion .pt I/O (model/gaussian_model.py:250-344, fusion.py:234-257).
-Parity unpinned (the reference's reader / writer needs `plyfile`): header text against the PLY 1.0 layout the
+Parity unpinned against a reference-WRITTEN file (the reference's reader / writer needs `plyfile`, absent here); the layout its
+code defines is pinned by a hand-derived byte fixture (tests/golden/gaussians_deg1.ply): header text against the PLY 1.0 layout the
 reference's attribute list implies, round trips, and reading by NAME like load_ply."""
 import struct
 
@@ -100,3 +101,21 @@ def test_ascii_ply_is_read_too(tmp_path):
     back = sio.read_gaussian_ply(path, max_sh_degree=0)
     for k in ("xyz", "features_dc", "opacity", "scaling", "rotation"):
         assert torch.equal(back[k], m[k]), k
+
+
+def test_hand_derived_ply_fixture_reads_and_rewrites_byte_for_byte(tmp_path):
+    """tests/golden/gaussians_deg1.ply was written with `struct` alone by tests/golden/gen_ply_fixture.py from the reference's
+    save_ply / construct_list_of_attributes (model/gaussian_model.py:250-281: attribute order, f4 everywhere, zero normals,
+    transpose(1, 2).flatten of the SH blocks) -- it pins the LAYOUT that code defines; it is NOT a file the reference wrote
+    (plyfile is not in this image).  The reader must return the values the generator put in (load_ply's reshape,
+    :288-344), and the writer must reproduce the file byte for byte."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = np.load(os.path.join(gold, "gaussians_deg1_values.npz"))
+    path = os.path.join(gold, "gaussians_deg1.ply")
+    back = sio.read_gaussian_ply(path, max_sh_degree=1)
+    for k in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
+        assert back[k].dtype == torch.float32 and np.array_equal(back[k].numpy(), want[k]), k
+    out = str(tmp_path / "again.ply")
+    sio.write_gaussian_ply(out, **{k: torch.from_numpy(want[k]) for k in want.files})
+    assert open(out, "rb").read() == open(path, "rb").read()
