@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	uint32_t* __restrict__ act_id, uint32_t* __restrict__ act_idx, float* __restrict__ wgt,
 	uint32_t* __restrict__ table, uint32_t* __restrict__ nact, uint32_t* __restrict__ counter,
 	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles, unsigned long long* __restrict__ trace,
-	float4* __restrict__ clear_ptr, unsigned long long clear_n4)
+	float4* __restrict__ clear_ptr, unsigned long long clear_n4, const uint32_t* __restrict__ tile_order)
 {
 	const int b = blockIdx.x;
 	const unsigned long long t_begin = trace ? wall_clock64() : 0ull;   // (debug timeline, tools/sweep_trace.py)
@@ -91,8 +91,20 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	constexpr bool BF = MODE == 2 || MODE == 4;   // weights as bf16 terms, k-major groups of 8 (else fp32 rows of 256)
 	constexpr int GROUP_BYTES = MODE == 4 ? 12288 : 8192;   // 8 entries x 256 px x (2 | 3) terms x 2 B
 	constexpr bool SWEEP = true;     // parity-major pixel order, closing T * bg pseudo entry, zero padding to 16
-	const int tile = (b & 7) * per_xcd + (b >> 3);
-	if (tile >= ntiles) return;
+	// Which tile: by default XCD b % 8 owns a contiguous band of tiles.  A tile's work (its number of ACTIVE list entries)
+	// cannot be predicted from its list (round 2: r = 0.006 with the list length), so in that order the kernel ends with
+	// a long tail (1 206 of 1 536 workgroup slots busy on average at cfg3).  Round 4: when this stream has rendered a frame
+	// of the same tile grid before, the tiles are taken longest-first by the work-list length they had in THAT frame
+	// (tile_order, written by the previous frame's sweep_plan_kernel): consecutive views of a scene have nearly the same
+	// per-tile work, and a stale order is only a worse schedule, never a different result.
+	int tile;
+	if (tile_order && tile_order[0] == (uint32_t)ntiles) {
+		if (b >= ntiles) return;
+		tile = (int)tile_order[1 + b];
+	} else {
+		tile = (b & 7) * per_xcd + (b >> 3);
+		if (tile >= ntiles) return;
+	}
 	if (counter[1] == 2u) return;   // aborted frame (arena_reset_kernel): the lists do not exist
 	const int tx = tile % gx, ty = tile / gx;
 	const int lane = threadIdx.x & 63;
@@ -448,7 +460,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int PLAN_MAX = 4096;   // segments (beyond: row-major order)
 __global__ __launch_bounds__(1024) void sweep_plan_kernel(const uint32_t* __restrict__ nact, uint32_t* __restrict__ order,
 							   const uint32_t* __restrict__ counter, int gx, int gy, int seg, int nseg,
-							   volatile uint32_t* usage_host)
+							   volatile uint32_t* usage_host, uint32_t* __restrict__ tile_order)
 {
 	if (usage_host && threadIdx.x == 0) {   // the work-list usage feedback, straight into the stream's pinned words
 		usage_host[0] = counter[0];         // (a device-to-host copy at the end of the frame would be one more launch)
@@ -457,6 +469,29 @@ __global__ __launch_bounds__(1024) void sweep_plan_kernel(const uint32_t* __rest
 	}
 	if (counter[1] != 0u) return;
 	__shared__ uint32_t key[PLAN_MAX];
+	if (tile_order) {   // the NEXT frame's tile order for the weights pre-pass: a counting sort by work-list length, longest first
+		uint32_t* hist = key;   // (1024 bins; the segment keys below reuse the array afterwards)
+		const int ntiles = gx * gy, tid = (int)threadIdx.x;
+		hist[tid] = 0u;
+		__syncthreads();
+		for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[1023u - (nact[t] < 1023u ? nact[t] : 1023u)], 1u);
+		__syncthreads();
+		const uint32_t mine = hist[tid];
+		for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan over the bins
+			const uint32_t add = tid >= off ? hist[tid - off] : 0u;
+			__syncthreads();
+			hist[tid] += add;
+			__syncthreads();
+		}
+		const uint32_t first = hist[tid] - mine;
+		__syncthreads();
+		hist[tid] = first;   // from here on: the next free position of each bin
+		__syncthreads();
+		for (int t = tid; t < ntiles; t += 1024)
+			tile_order[1u + atomicAdd(&hist[1023u - (nact[t] < 1023u ? nact[t] : 1023u)], 1u)] = (uint32_t)t;
+		if (tid == 0) tile_order[0] = (uint32_t)ntiles;
+		__syncthreads();
+	}
 	const int n = gy * nseg;
 	int np2 = 1;
 	while (np2 < n) np2 <<= 1;
@@ -1089,7 +1124,8 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 	hipLaunchKernelGGL(blend_weights_kernel<M_>, dim3((((NT_) + 7) / 8) * 8), dim3(256), 0, ST_,    \
 			   a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, \
 			   act_id, (uint32_t*)nullptr, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, \
-			   ((NT_) + 7) / 8, NT_, g_sweep_trace ? g_sweep_trace + 4 * 4096 : nullptr, (float4*)nullptr, 0ull)
+			   ((NT_) + 7) / 8, NT_, g_sweep_trace ? g_sweep_trace + 4 * 4096 : nullptr, (float4*)nullptr, 0ull, \
+			   (const uint32_t*)a.tile_order)
 	{
 		// ---- row-sweep path (default)
 		// segment length: long sweeps amortise the prologue and leave few half-line stores at segment
@@ -1139,7 +1175,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		uint32_t* order = (uint32_t*)(arena + lay.order);
 		if (plan == 3)
 			hipLaunchKernelGGL(sweep_plan_kernel, dim3(1), dim3(1024), 0, st, nbatches, order, counter, a.gx, a.gy, seg, nseg,
-					   a.usage_host);
+					   a.usage_host, a.tile_order);
 		if (usage_reported) *usage_reported = plan == 3 && a.usage_host != nullptr;
 		const int dealt = plan >= 2;
 		const int items = dealt ? nsegs : nsegs * nc * wg_per_item;   // x 2 row parities (one workgroup for both: ping-pong)

@@ -1178,6 +1178,23 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	uint32_t j = 0;
 	uint32_t late = 0;   // (trace) polls of this wave that found its pieces still in flight
 
+	// (development, DBG & 4) phase clocks: shader cycles this wave spent, summed over its steps, in
+	//   0 table words | 1 DMA issue | 2 deferred stores | 3 operand wait + feature split | 4 arrival check | 5 barrier 1 |
+	//   6 the 48 MFMAs (issue) | 7 arrival check | 8 barrier 2 | 9 between steps (pair stores, tile bookkeeping)
+	// written behind the workgroup trace (12 words per wave).  s_memtime is an SMEM access: reading it waits for lgkmcnt(0),
+	// i.e. also for LDS reads in flight -- the stamps behind the operand reads see them land (a small distortion).
+	constexpr bool PH = (DBG & 4) != 0;
+	uint32_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t ph_prev = PH ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
+#define S3_STAMP(k_)                                                                                 \
+	do {                                                                                             \
+		if constexpr (PH) {                                                                          \
+			const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();                            \
+			ph[k_] += now_ - ph_prev;                                                                \
+			ph_prev = now_;                                                                          \
+		}                                                                                            \
+	} while (0)
+
 	// "my pieces of the bundle in stage st have landed" (the wave's id words no longer hold the sentinel); returns the id of
 	// the feature row this lane fetches for the bundle LA ahead of it, and re-arms the words for the stage's next bundle
 	auto poll = [&](uint32_t st) __attribute__((always_inline)) -> uint32_t {
@@ -1258,7 +1275,9 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 // [first half: arrival check of bundle j + 1]; barrier.
 #define S3_STEP(b0_, b1_, b2_, b3_, DEF_)                                                            \
 	do {                                                                                             \
+		S3_STAMP(9);                                                                                 \
 		e_ = step_head();                                                                            \
+		S3_STAMP(0);                                                                                 \
 		float f_[8];                                                                                 \
 		u32x4 x_[3], y_[3], x2_[3], y2_[3];                                                          \
 		Op3 A_;                                                                                      \
@@ -1270,7 +1289,9 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			S3_RDB(y_, 1);                                                                           \
 		}                                                                                            \
 		issue_all(nb);                                                                               \
+		S3_STAMP(1);                                                                                 \
 		DEF_;                                                                                        \
+		S3_STAMP(2);                                                                                 \
 		if (!(DBG & 2)) {                                                                            \
 			asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f_[0]), "+v"(f_[1]), "+v"(f_[2]), "+v"(f_[3]), "+v"(f_[4]), "+v"(f_[5]), "+v"(f_[6]), "+v"(f_[7]) : : "memory"); \
 			__builtin_amdgcn_sched_barrier(0);                                                       \
@@ -1282,14 +1303,20 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			__builtin_amdgcn_sched_barrier(0);                                                       \
 		}                                                                                            \
 		const uint32_t stn_ = st0 + S3_STAGE == ring + S3_NST * S3_STAGE ? ring : st0 + S3_STAGE;     \
+		S3_STAMP(3);                                                                                 \
 		if (g) nid = poll(stn_);                                                                     \
+		S3_STAMP(4);                                                                                 \
 		__builtin_amdgcn_s_barrier();                                                                \
+		S3_STAMP(5);                                                                                 \
 		if (!(DBG & 2)) {                                                                            \
 			mfma_dense<b0_, b1_>(A_, x_, y_);                                                        \
 			mfma_dense<b2_, b3_>(A_, x2_, y2_);                                                      \
 		}                                                                                            \
+		S3_STAMP(6);                                                                                 \
 		if (!g) nid = poll(stn_);                                                                    \
+		S3_STAMP(7);                                                                                 \
 		__builtin_amdgcn_s_barrier();                                                                \
+		S3_STAMP(8);                                                                                 \
 		step_tail();                                                                                 \
 	} while (0)
 
@@ -1343,6 +1370,16 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 					   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 		trace[4 * (size_t)b + 3] = (unsigned long long)J | ((unsigned long long)nt << 32) | ((unsigned long long)late << 40);
 	}
+	if constexpr (PH) {
+		if (trace && lane == 0) {
+			unsigned long long* q = trace + 4 * (4096 + 8192) + 12 * ((size_t)b * 8 + wave);
+#pragma unroll
+			for (int k = 0; k < 10; k++) q[k] = ph[k];
+			q[10] = J;
+			q[11] = (unsigned long long)wave;
+		}
+	}
+#undef S3_STAMP
 #undef S3_STEP
 #undef S3_LEFT_TILE
 #undef S3_RIGHT_TILE
@@ -1374,6 +1411,7 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	if (dbg == 1) S3_LAUNCH(1);        // (development ablations) no stores
 	else if (dbg == 2) S3_LAUNCH(2);   // no matrix work
 	else if (dbg == 3) S3_LAUNCH(3);   // ring only
+	else if (dbg == 4) S3_LAUNCH(4);   // phase clocks (tools/sweep_phases.py)
 	else S3_LAUNCH(0);
 #undef S3_LAUNCH
 	return hipGetLastError();

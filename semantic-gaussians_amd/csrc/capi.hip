@@ -43,6 +43,10 @@ struct StreamCtx {
 	uint32_t* usage_host = nullptr;   // pinned {slots requested, overflow flag} of this stream's last split forward
 	hipEvent_t usage_ev = nullptr;    // recorded behind the copy into usage_host
 	bool usage_pending = false;
+	// device words [0] = tile count, [1 ..] = the tiles ordered by the work-list length of this stream's previous frame
+	// (BlendFwdArgs::tile_order: the weights pre-pass of the next frame takes its tiles longest-first)
+	uint32_t* tile_order = nullptr;
+	size_t tile_order_cap = 0;
 	// backward (work-list MFMA path)
 	uint32_t bwd_hint = 0;
 	uint32_t* bwd_usage_host = nullptr;
@@ -65,6 +69,7 @@ struct StreamCtx {
 	~StreamCtx()
 	{
 		if (usage_host) (void)hipHostFree(usage_host);
+		if (tile_order) (void)hipFree(tile_order);
 		if (bwd_usage_host) (void)hipHostFree(bwd_usage_host);
 		if (count_host) (void)hipHostFree(count_host);
 		if (count_ev) (void)hipEventDestroy(count_ev);
@@ -852,6 +857,23 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 			if (e != hipSuccess) return fail_hip(e, "memset (norm plane)");
 		}
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
+		// the stream's tile-order feedback buffer (allocated when the tile grid first appears / grows; hipFree waits for the
+		// device, so a buffer still in use by an earlier frame is never pulled away).  SGS_NO_TILE_ORDER=1: A/B switch.
+		static const bool no_tile_order = getenv("SGS_NO_TILE_ORDER") && atoi(getenv("SGS_NO_TILE_ORDER")) != 0;
+		if (!no_tile_order && cx->tile_order_cap < (size_t)ntiles) {
+			if (cx->tile_order) (void)hipFree(cx->tile_order);
+			cx->tile_order = nullptr;
+			cx->tile_order_cap = 0;
+			if (hipMalloc((void**)&cx->tile_order, ((size_t)ntiles + 1) * 4) == hipSuccess &&
+			    hipMemsetAsync(cx->tile_order, 0, 4, st) == hipSuccess)
+				cx->tile_order_cap = (size_t)ntiles;
+			else {
+				(void)hipGetLastError();
+				if (cx->tile_order) (void)hipFree(cx->tile_order);
+				cx->tile_order = nullptr;
+			}
+		}
+		a.tile_order = no_tile_order ? nullptr : cx->tile_order;
 		const bool can_report = cx->ensure(cx->usage_host, cx->usage_ev);
 		a.usage_host = can_report ? cx->usage_host : nullptr;
 		bool usage_reported = false;

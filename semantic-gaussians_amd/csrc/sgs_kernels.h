@@ -95,6 +95,11 @@ struct BlendFwdArgs {
 	uint32_t* usage_host;        // optional pinned {work-list slots requested, overflow flag}: written by the sweep plan kernel
 	bool counter_reset_done;     // the work-list counter was already reset (launch_row_binning): no arena_reset_kernel
 	bool norm_plane;             // SGS_OPT_NORM_PLANE: `out` is an (H, pitch) plane that receives sum_c out[c]^2 (atomics), no feature map
+	// optional, per (device, stream): [0] = number of tiles the order below is for (0 = none yet), [1 ..] = the tiles sorted
+	// by the work-list length they had in the stream's PREVIOUS frame, longest first.  The weights pre-pass takes its
+	// tiles in this order when [0] matches (a scheduling hint: results do not depend on it); the sweep plan kernel of
+	// every frame rewrites it from the frame's own counts.
+	uint32_t* tile_order = nullptr;
 };
 // gate: optional device word; when non-null the 128-channel-aligned kernels exit unless
 // *gate != 0 (used as the arena-overflow fallback of the split path).

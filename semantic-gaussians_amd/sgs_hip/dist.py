@@ -30,6 +30,15 @@ def world():
     return 0, 1
 
 
+def _host_transport_fence(t):
+    """gloo moves bytes with the CPU and knows nothing about HIP streams: a device tensor handed to it must be COMPLETE in
+    memory first (round 4: the one-device gloo test of the Gaussian-sharded render exchanged bands the render kernels were
+    still writing -- the old O(1) slack of that test hid it).  Under RCCL the process group orders its kernels behind the
+    current stream itself; nothing to do."""
+    if t.is_cuda and dist.is_initialized() and dist.get_backend() == "gloo":
+        torch.cuda.synchronize(t.device)
+
+
 def shard_views(n_views, rank=None, world_size=None):
     """Round-robin view indices of this rank."""
     r, w = world()
@@ -73,6 +82,8 @@ def render_views_sharded(render_fn, views, gather_to=None):
         for i, t in sorted(mine.items()):
             ops.append(dist.P2POp(dist.isend, t.contiguous(), gather_to))
     if ops:
+        if first is not None:
+            _host_transport_fence(first)
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     if rank != gather_to:
@@ -228,6 +239,7 @@ def render_gaussian_sharded(render_partial_fn, bg, order=None, all_gather=True):
         if ra.numel():
             ops += [dist.P2POp(dist.irecv, ra, peer), dist.P2POp(dist.irecv, rt, peer)]
     if ops:
+        _host_transport_fence(a)   # (the contiguous send copies above are complete, too)
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     band, _ = composite_over([recv[r] for r in order], bg)
@@ -238,6 +250,7 @@ def render_gaussian_sharded(render_partial_fn, bg, order=None, all_gather=True):
     # way (uniform bands could use all_gather_into_tensor; 61 tile rows over 8 ranks are not uniform)
     sizes = [band_rows(H, r, w) for r in range(w)]
     band = band.contiguous()
+    _host_transport_fence(band)
     parts = [band if r == rank else torch.empty((band.shape[0], sizes[r][1] - sizes[r][0], band.shape[2]), dtype=band.dtype, device=band.device)
              for r in range(w)]
     ops = []
