@@ -404,12 +404,25 @@ def main():
 
     DEFER = args.deferred_count
 
-    def step(k=0, defer=None):   # one batch: V views of the scene (camera k of every slot), all in flight together
+    def step(k=0, defer=None, prev=None):   # one batch: V views of the scene (camera k of every slot), all in flight together
+        # `prev`: the previous step's results.  Slot i's old feature map is released right before slot i renders again: the
+        # block goes back to that stream's pool and the new frame reuses it in stream order, so a step keeps V feature maps
+        # alive, not 2 V (round 3: 45 GB reserved for four views in flight -- half of it was the previous step's outputs).
+        def drop(i):
+            if prev is not None:
+                prev[i] = None
         if not (DEFER if defer is None else defer):   # the reference's host pattern: every forward blocks on its num_rendered read-back
-            return [render(i, False, k) for i in range(V)]
+            res = []
+            for i in range(V):
+                drop(i)
+                res.append(render(i, False, k))
+            return res
         # deferred counts (SGS_OPT_DEFER_COUNT): all V forwards are enqueued without the host waiting for the GPU,
         # then every frame's counts are checked (a frame that outgrew its capacity guess is rendered again there)
-        pending = [render(i, True, k) for i in range(V)]
+        pending = []
+        for i in range(V):
+            drop(i)
+            pending.append(render(i, True, k))
         return [h.result() for h in pending]
 
     def barrier():
@@ -457,13 +470,15 @@ def main():
                 n += raster.stream_stat(_lib.STAT_DEFERRED_RETRIES, dev)
         return n
 
+    rank_ms = {}   # ms per step of the slowest / fastest rank in the last in_flight() (a straggler shows here)
+
     def in_flight(variant, steps, warmup, stage_timing=False, defer=None):
         raster.set_blend_variant(variant)
         out = None
         for k in range(warmup):
-            out = step(k, defer)   # bound like the timed loop: step n's outputs live while step n + 1 allocates, so the
-            #                caching allocator reaches its steady-state footprint here, not in the timed region
-            #                (a 10 GB hipMalloc in timed step 2 was a 240 ms stall, profiles/r02h_bench_default.json)
+            out = step(k, defer, out)   # exactly like the timed loop, so that the caching allocator reaches its steady-state
+            #                footprint here, not in the timed region (a 10 GB hipMalloc in timed step 2 was a 240 ms stall,
+            #                profiles/r02h_bench_default.json)
         if stage_timing:   # deferred per-stage hipEvents for the timed steps only (no extra synchronisation)
             raster.get_stage_ms()
             raster.set_stage_timing(2)
@@ -474,17 +489,19 @@ def main():
         t0 = time.perf_counter()
         marks, mism = [], 0
         for k in range(steps):
-            out = step(k, defer)
+            out = step(k, defer, out)
             mism += sum(int(o[0] != ref_n[i][k % NCAM]) for i, o in enumerate(out))   # host ints, no device work
             marks.append(time.perf_counter())
         barrier()
         t = time.perf_counter() - t0
         gc.enable()
         retries = deferred_retries() - retries0
+        rank_ms["min"] = rank_ms["max"] = t / steps * 1e3   # this rank's own clock; over the ranks below
         if world > 1:
-            tt = torch.tensor([t], device=red_dev, dtype=torch.float64)
+            tt = torch.tensor([t, -t], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t = float(tt.item())
+            rank_ms["max"], rank_ms["min"] = float(tt[0].item()) / steps * 1e3, -float(tt[1].item()) / steps * 1e3
+            t = float(tt[0].item())
         per = [b - a for a, b in zip([t0] + marks[:-1], marks)]
         per.sort()
         if rank == 0:   # host-side enqueue cadence (diagnostic only; the metric uses t / steps)
@@ -545,11 +562,23 @@ def main():
                        "synchronisation) during which the GPU idles; single_view brackets the internal entry point")
 
     # ---- the headline: K timed steps, V views in flight, default arithmetic
+    gc.collect()
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()              # (the legs above leave their own cached blocks behind: the memory figures below are
+    torch.cuda.reset_peak_memory_stats(dev)   # the headline's -- scene, resident state buffers, V feature maps)
     ms_per_step, ms_step_median, mismatches, out, retries = in_flight(args.variant, args.steps, max(2, args.warmup), True)
     raster.set_stage_timing(0)
     stage_ms_timed = raster.get_stage_ms()   # per-stream event spacing inside the timed region (queueing included)
+    headline_rank_ms = dict(rank_ms)
+    mem = {"max_allocated_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
+           "reserved_GB": round(torch.cuda.memory_reserved(dev) / 1e9, 2),
+           "scene_GB": round(sum(t.numel() * t.element_size() for t in (s.means3D, s.features, s.opacities, s.scales, s.rotations)) / 1e9, 2),
+           "note": f"this rank, up to the end of the headline's timed region ({V} views in flight: per view slot one feature map "
+                   f"of {C * H * W * 4 / 1e9:.2f} GB + resident geometry / binning / work-list buffers; a slot's previous map is "
+                   "released before it renders again); the legs measured afterwards add their own buffers"}
+    mem["per_view_slot_GB"] = round((mem["max_allocated_GB"] - mem["scene_GB"]) / V, 2)
     if rank == 0:
-        log(f"torch reserved {torch.cuda.memory_reserved(dev) / 1e9:.2f} GB")
+        log(f"torch max allocated {mem['max_allocated_GB']:.2f} GB, reserved {mem['reserved_GB']:.2f} GB")
 
     # ---- workload statistics of this rank's first view (slot 0, camera 0: the view single_view / the roofline time;
     # every run prints them: bytes depend on them)
@@ -745,6 +774,8 @@ def main():
                                             "on < 1e-5 of the elements -- as the oracle's own chain does against the exact composite "
                                             "(tests/test_configs_gpu.py); exact_f32 below is the bit-identical fp32-MFMA path")},
             "ms_per_step_median": ms_step_median,
+            "ms_per_step_ranks": headline_rank_ms,   # slowest / fastest rank's own clock over the same timed region
+            "memory": mem,
             "ms_per_view": ms_per_step / V,
             "single_view": sv_default,
             "api_path": api,

@@ -775,10 +775,11 @@ def test_output_pitch_is_consumed_by_one_forward(orc):
     scene, cam = small_scene(P=1500, C=128, W=205, H=48, fx=90.0, seed=3)
     sp = C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
     with torch.cuda.device(DEV):
-        lib.sgs_stream_set_option(sp, _lib.OPT_OUT_PITCH, 224)
-        want = _hip_forward(scene, cam, variant=15)   # a contiguous forward: consumes (and, W != pitch, honours) nothing
-    # ... the call above DID see pitch 224 with a contiguous (C,H,W) buffer: that is the caller's bug this test does not
-    # exercise; what it checks is that the override is gone afterwards
+        lib.sgs_stream_set_option(sp, _lib.OPT_OUT_PITCH, 205)
+        want = _hip_forward(scene, cam, variant=15)   # a contiguous forward: pitch == W, the override changes nothing but is consumed
+    # (round 4: this used to set 224 -- wider than the contiguous buffer -- and so made the forward write 0.5 MB past its
+    # end; harmless only while the allocator had mapped memory behind it: a GPU memory fault in a shorter test run.)  What
+    # is checked is that the override is gone afterwards
     with torch.cuda.device(DEV):
         prev = lib.sgs_stream_set_option(sp, _lib.OPT_OUT_PITCH, -1)
     assert prev == 0x7fffffff
