@@ -1018,14 +1018,15 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 //     waves 0-3 (parity 0):  PREP(j)  |B|  MFMA(j)   |B|  PREP(j+1) |B|  MFMA(j+1) ...
 //     waves 4-7 (parity 1):       |B|  PREP(j)   |B|  MFMA(j)   |B|  PREP(j+1) |B| ...
 //
-//   MFMA(j) = the 48 v_mfma_f32_32x32x8_bf16 of batch j, operands already in registers, nothing else;
-//   PREP(j) = everything else: the step's table words, operand LDS reads + the feature split of batch j, this wave's DMA
-//             pieces of bundle j + LA, the deferred / pair stores.
+//   MFMA(j) = the 48 v_mfma_f32_32x32x8_bf16 of batch j, operands already in registers, with this wave's five DMA pieces of
+//             bundle j + LA between the MFMA pairs of the second half (their issue hides under matrix time there);
+//   PREP(j) = everything else: the step's table words, operand LDS reads + the feature split of batch j, the deferred /
+//             pair stores.
 // The code of the two halves is THE SAME loop (PREP, barrier, MFMA, barrier); the second half simply executes one extra
 // s_barrier before it (and the first half one after it), i.e. it runs one barrier behind.  Every workgroup-wide barrier
 // inside the common code therefore stays matched, and the only obligations are about data one half produces for both:
 //   * ring stage of batch j: read by half 0 in [B2j, B2j+1), by half 1 in [B2j+1, B2j+2); refilled (bundle j + NST) by
-//     DMA pieces issued after B2j+2 by either half -- never before the slower reader is done;
+//     DMA pieces issued in the MFMA phases of step j + 1, i.e. after B2j+3 -- never before the slower reader is done;
 //   * arrival of bundle j + 1: half 0 reads it right after B2j+2, so EVERY wave checks its own pieces (the id words its
 //     last DMA deposits, as above) before it arrives at B2j+2: half 0 at the end of MFMA(j), half 1 at the end of PREP(j);
 //   * the batch-table window: refilled by half 0 only, between two barriers during which half 1 reads nothing.
@@ -1197,10 +1198,15 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 
 	// "my pieces of the bundle in stage st have landed" (the wave's id words no longer hold the sentinel); returns the id of
 	// the feature row this lane fetches for the bundle LA ahead of it, and re-arms the words for the stage's next bundle
-	auto poll = [&](uint32_t st) __attribute__((always_inline)) -> uint32_t {
+	// The check is split so that its LDS round trip can ride under other work: poll_issue sends the two reads, poll_finish
+	// (after an s_waitcnt lgkmcnt(0) that the caller needs anyway, or its own) looks at them.
+	auto poll_issue = [&](uint32_t st, uint32_t& wv, uint32_t& id0) __attribute__((always_inline)) {
 		const uint32_t pa = st + my_ids + (uint32_t)lane * 4u, ia = st + my_ids + sub * 4u;
-		uint32_t wv, id0;
-		asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(wv), "=&v"(id0) : "v"(pa), "v"(ia) : "memory");
+		asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(wv), "=&v"(id0) : "v"(pa), "v"(ia) : "memory");
+	};
+	auto poll_finish = [&](uint32_t st, uint32_t wv, uint32_t id0) __attribute__((always_inline)) -> uint32_t {
+		const uint32_t pa = st + my_ids + (uint32_t)lane * 4u, ia = st + my_ids + sub * 4u;
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv), "+v"(id0) : : "memory");
 		if (__builtin_amdgcn_ballot_w64(wv == S2_SENT) != 0ull) {   // not landed yet: poll (no vmcnt: stores may be outstanding in any number)
 			if (trace) late++;
 			int spins = 0;
@@ -1212,6 +1218,11 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		}
 		asm volatile("ds_write_b32 %0, %1" : : "v"(pa), "v"(S2_SENT) : "memory");
 		return id0;
+	};
+	auto poll = [&](uint32_t st) __attribute__((always_inline)) -> uint32_t {
+		uint32_t wv, id0;
+		poll_issue(st, wv, id0);
+		return poll_finish(st, wv, id0);
 	};
 	uint32_t nid = poll(ring);   // bundle 0: the ids of batch LA
 	__builtin_amdgcn_s_barrier();   // every wave's pieces of bundle 0 have landed
@@ -1269,6 +1280,17 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 #define S3_RDB(dst_, pb_)                                                                            \
 	asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6" \
 		     : "=&v"(dst_[0]), "=&v"(dst_[1]), "=&v"(dst_[2]) : "v"(wa_), "n"((pb_) * 512), "n"(2048 + (pb_) * 512), "n"(4096 + (pb_) * 512) : "memory")
+// second pixel-block pair of the batch: the same (A term, B term, k half) order as mfma_dense, as MFMA pairs with this wave's
+// five DMA pieces of bundle j + LA between them.  Measured (tools/sweep_phases.py, profiles/r04_sweep_phases.txt): issued
+// in the PREP phase right behind the operand ds_reads a piece cost ~275 cycles of issue (1 370 per step, the longest item
+// of the phase); between MFMA pairs, with no LDS read in flight, its slot hides under the 64 cycles of matrix work.
+#define S3_HALF2(bx_, by_, c_)                                                                       \
+	do {                                                                                             \
+		constexpr int TA_[6] = {2, 0, 1, 1, 0, 0}, TB_[6] = {0, 2, 1, 0, 1, 0};   /* smallest terms first */ \
+		mfma_pair<bx_, by_>(A_.t[TA_[c_]][0], u32x2{x2_[TB_[c_]].x, x2_[TB_[c_]].y}, u32x2{y2_[TB_[c_]].x, y2_[TB_[c_]].y}); \
+		if constexpr ((c_) < 5) dma_piece(std::integral_constant<int, (c_)>{}, nb);                  \
+		mfma_pair<bx_, by_>(A_.t[TA_[c_]][1], u32x2{x2_[TB_[c_]].z, x2_[TB_[c_]].w}, u32x2{y2_[TB_[c_]].z, y2_[TB_[c_]].w}); \
+	} while (0)
 // One step = batch j into accumulator blocks b0_..b3_.  PREP: table words; operand reads of batch j go out first (stage j
 // landed before the barrier this phase began with); the DMA pieces of bundle j + LA and the deferred stores (DEF_) are
 // issued while they land; the feature split; [second half: arrival check of bundle j + 1]; barrier; MFMA: 48 products;
@@ -1281,6 +1303,8 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		float f_[8];                                                                                 \
 		u32x4 x_[3], y_[3], x2_[3], y2_[3];                                                          \
 		Op3 A_;                                                                                      \
+		const uint32_t stn_ = st0 + S3_STAGE == ring + S3_NST * S3_STAGE ? ring : st0 + S3_STAGE;     \
+		uint32_t pw_ = 0u, pid_ = 0u;                                                                \
 		const uint32_t fa_ = st0 + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;                \
 		const uint32_t wa_ = st0 + 8192u + (uint32_t)g * 12288u + (uint32_t)half * 6144u + (uint32_t)l31 * 16u; \
 		if (!(DBG & 2)) {                                                                            \
@@ -1288,7 +1312,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			S3_RDB(x_, 0);                                                                           \
 			S3_RDB(y_, 1);                                                                           \
 		}                                                                                            \
-		issue_all(nb);                                                                               \
+		if (DBG & 2) issue_all(nb);                                                                  \
 		S3_STAMP(1);                                                                                 \
 		DEF_;                                                                                        \
 		S3_STAMP(2);                                                                                 \
@@ -1298,22 +1322,28 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			split8(f_, A_);                                                                          \
 			S3_RDB(x2_, 2);                                                                          \
 			S3_RDB(y2_, 3);                                                                          \
+			if (g) poll_issue(stn_, pw_, pid_);   /* (second half) the arrival check's reads ride along */ \
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x_[0]), "+v"(x_[1]), "+v"(x_[2]), "+v"(y_[0]), "+v"(y_[1]), "+v"(y_[2]), \
 				     "+v"(x2_[0]), "+v"(x2_[1]), "+v"(x2_[2]), "+v"(y2_[0]), "+v"(y2_[1]), "+v"(y2_[2]) : : "memory"); \
 			__builtin_amdgcn_sched_barrier(0);                                                       \
 		}                                                                                            \
-		const uint32_t stn_ = st0 + S3_STAGE == ring + S3_NST * S3_STAGE ? ring : st0 + S3_STAGE;     \
 		S3_STAMP(3);                                                                                 \
-		if (g) nid = poll(stn_);                                                                     \
+		if (g) {                                                                                     \
+			if (DBG & 2) poll_issue(stn_, pw_, pid_);                                                \
+			nid = poll_finish(stn_, pw_, pid_);                                                      \
+		}                                                                                            \
 		S3_STAMP(4);                                                                                 \
 		__builtin_amdgcn_s_barrier();                                                                \
 		S3_STAMP(5);                                                                                 \
 		if (!(DBG & 2)) {                                                                            \
 			mfma_dense<b0_, b1_>(A_, x_, y_);                                                        \
-			mfma_dense<b2_, b3_>(A_, x2_, y2_);                                                      \
-		}                                                                                            \
+			S3_HALF2(b2_, b3_, 0); S3_HALF2(b2_, b3_, 1); S3_HALF2(b2_, b3_, 2);                     \
+			S3_HALF2(b2_, b3_, 3); S3_HALF2(b2_, b3_, 4);                                            \
+			if (!g) poll_issue(stn_, pw_, pid_);   /* (first half) under the last four MFMAs */       \
+			S3_HALF2(b2_, b3_, 5);                                                                   \
+		} else if (!g) poll_issue(stn_, pw_, pid_);                                                  \
 		S3_STAMP(6);                                                                                 \
-		if (!g) nid = poll(stn_);                                                                    \
+		if (!g) nid = poll_finish(stn_, pw_, pid_);                                                  \
 		S3_STAMP(7);                                                                                 \
 		__builtin_amdgcn_s_barrier();                                                                \
 		S3_STAMP(8);                                                                                 \
@@ -1380,6 +1410,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		}
 	}
 #undef S3_STAMP
+#undef S3_HALF2
 #undef S3_STEP
 #undef S3_LEFT_TILE
 #undef S3_RIGHT_TILE
