@@ -1047,9 +1047,11 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const char* __restrict__ wgt, const float* __restrict__ features,
 	const float* __restrict__ bg, float* __restrict__ out, const uint32_t* __restrict__ counter,
 	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int PW,
-	unsigned long long* __restrict__ trace, const uint32_t* __restrict__ order, int dealt)
+	unsigned long long* __restrict__ trace, const uint32_t* __restrict__ order, int dealt, int tune)
 {
 	if (counter[1] != 0u) return;   // arena overflowed / frame aborted
+	(void)tune;   // (tuning word, bits [19:16] of the blend variant: unused -- call E's placement / priority experiments are settled,
+	// profiles/r04_sweep_dma_placement.txt: pieces issued in PREP cost 300-400 cycles each, per-phase priorities change nothing)
 	const int b = blockIdx.x;
 	int chunk, rest;   // 128-channel chunk, segment (= ty * nseg + sg) of this workgroup
 	if (dealt) {   // segments dealt to the XCDs in serpentine order of their rank (sweep_plan_kernel)
@@ -1151,6 +1153,34 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
 							 (__attribute__((address_space(3))) void*)(size_t)(bd.st + 8192u + (uint32_t)pc * 1024u), 16, 0, 0);
 		}
+	};
+	// the same pieces in two steps: source address (per lane) now, the load later
+	auto dma_src = [&](auto I, const Bundle& bd) __attribute__((always_inline)) -> const char* {
+		constexpr int i = decltype(I)::value;
+		if constexpr (i == 0) {
+			const float* row = bd.id0 == SGS_BG_ID ? bg : features + (size_t)bd.id0 * C;
+			return (const char*)(row + cbase + l31 * 4);
+		} else if constexpr (i == 4) {
+			const uint32_t li = (uint32_t)(lane & 15) < bd.n2 ? (uint32_t)(lane & 15) : bd.n2 - 1u;
+			return (const char*)(act_id + bd.slot2 + li);
+		} else {
+			const int pc = 3 * wave + (i - 1);
+			const int par = pc / 12, p = pc - 12 * par;
+			return wgt + (size_t)((bd.slot >> 3) + (uint32_t)(p / 6)) * 12288 + (size_t)((p % 6) / 2) * 4096 +
+			       (size_t)par * 2048 + (size_t)(p % 2) * 1024 + (size_t)lane * 16;
+		}
+	};
+	auto dma_go = [&](auto I, const char* src, uint32_t st) __attribute__((always_inline)) {
+		constexpr int i = decltype(I)::value;
+		if constexpr (i == 0)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+							 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(2 * wave) * 512u), 16, 0, 0);
+		else if constexpr (i == 4)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+							 (__attribute__((address_space(3))) void*)(size_t)(st + my_ids), 4, 0, 0);
+		else
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+							 (__attribute__((address_space(3))) void*)(size_t)(st + 8192u + (uint32_t)(3 * wave + (i - 1)) * 1024u), 16, 0, 0);
 	};
 	auto issue_all = [&](const Bundle& bd) __attribute__((always_inline)) {
 		dma_piece(std::integral_constant<int, 0>{}, bd);
@@ -1288,7 +1318,11 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	do {                                                                                             \
 		constexpr int TA_[6] = {2, 0, 1, 1, 0, 0}, TB_[6] = {0, 2, 1, 0, 1, 0};   /* smallest terms first */ \
 		mfma_pair<bx_, by_>(A_.t[TA_[c_]][0], u32x2{x2_[TB_[c_]].x, x2_[TB_[c_]].y}, u32x2{y2_[TB_[c_]].x, y2_[TB_[c_]].y}); \
-		if constexpr ((c_) < 5) dma_piece(std::integral_constant<int, (c_)>{}, nb);                  \
+		if constexpr ((c_) == 0) dma_go(std::integral_constant<int, 0>{}, da0_, dst_);               \
+		if constexpr ((c_) == 1) dma_go(std::integral_constant<int, 1>{}, da1_, dst_);               \
+		if constexpr ((c_) == 2) dma_go(std::integral_constant<int, 2>{}, da2_, dst_);               \
+		if constexpr ((c_) == 3) dma_go(std::integral_constant<int, 3>{}, da3_, dst_);               \
+		if constexpr ((c_) == 4) dma_go(std::integral_constant<int, 4>{}, da4_, dst_);               \
 		mfma_pair<bx_, by_>(A_.t[TA_[c_]][1], u32x2{x2_[TB_[c_]].z, x2_[TB_[c_]].w}, u32x2{y2_[TB_[c_]].z, y2_[TB_[c_]].w}); \
 	} while (0)
 // One step = batch j into accumulator blocks b0_..b3_.  PREP: table words; operand reads of batch j go out first (stage j
@@ -1300,6 +1334,15 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		S3_STAMP(9);                                                                                 \
 		e_ = step_head();                                                                            \
 		S3_STAMP(0);                                                                                 \
+		/* the source addresses of this wave's five DMA pieces: computed HERE (64-bit VALU chains), issued between the MFMA  \
+		   pairs, where only the m0 write and the load itself remain */                                \
+		const char* da0_ = dma_src(std::integral_constant<int, 0>{}, nb);                             \
+		const char* da1_ = dma_src(std::integral_constant<int, 1>{}, nb);                             \
+		const char* da2_ = dma_src(std::integral_constant<int, 2>{}, nb);                             \
+		const char* da3_ = dma_src(std::integral_constant<int, 3>{}, nb);                             \
+		const char* da4_ = dma_src(std::integral_constant<int, 4>{}, nb);                             \
+		const uint32_t dst_ = nb.st;                                                                 \
+		asm volatile("" : "+v"(da0_), "+v"(da1_), "+v"(da2_), "+v"(da3_), "+v"(da4_));                \
 		float f_[8];                                                                                 \
 		u32x4 x_[3], y_[3], x2_[3], y2_[3];                                                          \
 		Op3 A_;                                                                                      \
@@ -1433,12 +1476,12 @@ hipError_t launch_norm_plane_background(hipStream_t st, float* plane, size_t n, 
 hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
-			       const uint32_t* order, int dealt)
+			       const uint32_t* order, int dealt, int tune)
 {
 #define S3_LAUNCH(D_)                                                                                \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
-			   pxcd, items, a.pitch, trace, order, dealt)
+			   pxcd, items, a.pitch, trace, order, dealt, tune)
 	if (dbg == 1) S3_LAUNCH(1);        // (development ablations) no stores
 	else if (dbg == 2) S3_LAUNCH(2);   // no matrix work
 	else if (dbg == 3) S3_LAUNCH(3);   // ring only
