@@ -530,6 +530,46 @@ __device__ __forceinline__ void s2_store4(const float* ubase, uint32_t o0, uint3
 {
 	static_assert((R0 & 3) == 0, "four consecutive planes");
 	const uint64_t p0 = (uint64_t)ubase + (uint64_t)(8 * (R0 >> 2)) * plane, p1 = p0 + plane, p2 = p1 + plane, p3 = p2 + plane;
+	if constexpr (SMODE == 3) {
+		// Round 4 (ping-pong sweep): the same bytes as TWO global_store_dwordx4.  After the permlane16 swap lane l31 of register
+		// k holds pixel xp + l31 of plane R0 + k; a 4 x 4 transpose inside every quad of lanes (two rounds of quad_perm DPP +
+		// bit merge) makes lane qi of a quad hold four CONSECUTIVE pixels of plane R0 + qi, so one store instruction writes
+		// eight complete 128-B lines and a tile pair is 32 store instructions instead of 128.  Why it matters here and did
+		// not in the kernel above: the wave's loads, LDS-DMAs and stores share ONE 6-bit counter of outstanding operations;
+		// a pair's 64 immediate stores on top of three bundles in flight run into it and the wave stalls for a memory
+		// latency -- in the ping-pong workgroup the partner half then waits at the barrier too.
+		// o0 / o1 here: byte offsets of [4 half + (lane & 3)][row][x pair + 4 ((lane & 31) >> 2)]; wdelta = the lane's masks
+		// (bit 0: lane & 1, bit 1: lane & 2).  The masks are bit merges on purpose (as ?: the compiler branches, and a DPP move
+		// under a partial exec mask cannot read the disabled lanes).
+		uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+		asm volatile(
+			"v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c12]\n\t"
+			"v_accvgpr_read_b32 %2, a[%c9]\n\tv_accvgpr_read_b32 %3, a[%c13]\n\t"
+			"v_accvgpr_read_b32 %4, a[%c10]\n\tv_accvgpr_read_b32 %5, a[%c14]\n\t"
+			"v_accvgpr_read_b32 %6, a[%c11]\n\tv_accvgpr_read_b32 %7, a[%c15]\n\t"
+			"s_nop 1\n\t"
+			"v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+			"s_nop 1"
+			: "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+			: "i"(BL * 16 + R0), "i"(BL * 16 + R0 + 1), "i"(BL * 16 + R0 + 2), "i"(BL * 16 + R0 + 3),
+			  "i"(BR * 16 + R0), "i"(BR * 16 + R0 + 1), "i"(BR * 16 + R0 + 2), "i"(BR * 16 + R0 + 3));
+		const uint32_t m1 = (wdelta & 1u) ? 0xFFFFFFFFu : 0u, m2 = (wdelta & 2u) ? 0xFFFFFFFFu : 0u;
+		auto sel = [](uint32_t m, uint32_t a, uint32_t b) __attribute__((always_inline)) { return (a & m) | (b & ~m); };
+		auto qx1 = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); };
+		auto qx2 = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); };
+#pragma unroll
+		for (int w = 0; w < 2; w++) {   // row y (t0 t2 t4 t6) and row y + 2 (t1 t3 t5 t7)
+			const uint32_t v0 = w ? t1 : t0, v1 = w ? t3 : t2, v2 = w ? t5 : t4, v3 = w ? t7 : t6;
+			const uint32_t x0 = sel(m1, qx1(v1), v0), x1 = sel(m1, v1, qx1(v0));
+			const uint32_t x2 = sel(m1, qx1(v3), v2), x3 = sel(m1, v3, qx1(v2));
+			const uint32_t y0 = sel(m2, qx2(x2), x0), y2 = sel(m2, x2, qx2(x0));
+			const uint32_t y1 = sel(m2, qx2(x3), x1), y3 = sel(m2, x3, qx2(x1));
+			const u32x4 d = {y0, y1, y2, y3};
+			// (s_nop: a store of more than 64 bits is still reading its data registers when the next VALU may overwrite them)
+			asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(w ? o1 : o0), "v"(d), "s"(p0) : "memory");
+		}
+		return;
+	}
 	if constexpr (SMODE == 2) {
 		asm volatile(
 			"global_store_dwordx4 %2, a[%c0:%c0+3], %4 nt\n\t"
@@ -875,6 +915,8 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 	const bool skip_stores = (DBG & 1) != 0;
 	constexpr int SMODE = (DBG & 4) ? 2 : ((DBG & 8) ? 1 : 0);
 	const uint32_t wdelta = (((uint32_t)(lane >> 3) * (uint32_t)HW + 4u * (uint32_t)(lane & 7)) - ((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)l31)) * 4u;
+// byte offset (from ubase) this lane's stores of a pair start at: row y_, the pair's left tile column txl_
+#define S2_PAIR_OFF(y_, txl_) ((((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)((y_) * PW + (txl_) * SGS_TILE + l31)) * 4u))
 // 16 stores of the deferred half of the pair finished under mapping MP_: chunk c = block 2 + (c >> 1), registers 8 (c & 1) ..
 #define S2_DEFERRED_CHUNK(MP_)                                                                       \
 	do {                                                                                             \
@@ -959,7 +1001,7 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 		} else if (skip_stores) {                                                                    \
 			S2_ZERO_ALL();                                                                           \
 		} else if (inside_) {                                                                        \
-			const uint32_t o0_ = ((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)(y0 * PW + xp_)) * 4u; \
+			const uint32_t o0_ = S2_PAIR_OFF(y0, (tx_) - 1);                                          \
 			const uint32_t o1_ = o0_ + (uint32_t)(2 * PW) * 4u;                                      \
 			asm volatile("s_nop 15" : : : "memory");                                                 \
 			s2_store_rows<LB(M_, 0), RB(M_, 0), 0, 16, SMODE>(ubase, o0_, o1_, plane, wdelta);                      \
@@ -1305,8 +1347,12 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	};
 
 	const bool skip_stores = (DBG & 1) != 0;
-	constexpr int SMODE = 0;
-	const uint32_t wdelta = 0u;   // (only the store ablations of the kernel above use it)
+	constexpr int SMODE = (DBG & 8) ? 0 : 3;   // transposed 16-byte stores (s2_store4, SMODE 3); DBG & 8: the 4-byte stores of the kernel above (A/B)
+	const uint32_t wdelta = SMODE == 3 ? (uint32_t)(lane & 3) : 0u;   // (SMODE 3: the lane's transpose masks)
+#undef S2_PAIR_OFF
+#define S2_PAIR_OFF(y_, txl_)                                                                        \
+	(SMODE == 3 ? (((uint32_t)(4 * half + (lane & 3)) * (uint32_t)HW + (uint32_t)((y_) * PW + (txl_) * SGS_TILE + 4 * (l31 >> 2))) * 4u) \
+		    : (((uint32_t)(4 * half) * (uint32_t)HW + (uint32_t)((y_) * PW + (txl_) * SGS_TILE + l31)) * 4u))
 #define S3_RDB(dst_, pb_)                                                                            \
 	asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6" \
 		     : "=&v"(dst_[0]), "=&v"(dst_[1]), "=&v"(dst_[2]) : "v"(wa_), "n"((pb_) * 512), "n"(2048 + (pb_) * 512), "n"(4096 + (pb_) * 512) : "memory")
@@ -1350,15 +1396,15 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		uint32_t pw_ = 0u, pid_ = 0u;                                                                \
 		const uint32_t fa_ = st0 + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;                \
 		const uint32_t wa_ = st0 + 8192u + (uint32_t)g * 12288u + (uint32_t)half * 6144u + (uint32_t)l31 * 16u; \
+		if (DBG & 2) issue_all(nb);                                                                  \
+		S3_STAMP(1);                                                                                 \
+		DEF_;   /* (before the operand reads: the transposes need registers the operands would occupy) */ \
+		S3_STAMP(2);                                                                                 \
 		if (!(DBG & 2)) {                                                                            \
 			S2_READ8(f_, fa_);                                                                       \
 			S3_RDB(x_, 0);                                                                           \
 			S3_RDB(y_, 1);                                                                           \
 		}                                                                                            \
-		if (DBG & 2) issue_all(nb);                                                                  \
-		S3_STAMP(1);                                                                                 \
-		DEF_;                                                                                        \
-		S3_STAMP(2);                                                                                 \
 		if (!(DBG & 2)) {                                                                            \
 			asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f_[0]), "+v"(f_[1]), "+v"(f_[2]), "+v"(f_[3]), "+v"(f_[4]), "+v"(f_[5]), "+v"(f_[6]), "+v"(f_[7]) : : "memory"); \
 			__builtin_amdgcn_sched_barrier(0);                                                       \
@@ -1452,6 +1498,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			q[11] = (unsigned long long)wave;
 		}
 	}
+#undef S2_PAIR_OFF
 #undef S3_STAMP
 #undef S3_HALF2
 #undef S3_STEP
@@ -1486,6 +1533,7 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	else if (dbg == 2) S3_LAUNCH(2);   // no matrix work
 	else if (dbg == 3) S3_LAUNCH(3);   // ring only
 	else if (dbg == 4) S3_LAUNCH(4);   // phase clocks (tools/sweep_phases.py)
+	else if (dbg == 8) S3_LAUNCH(8);   // 4-byte stores (A/B against the transposed 16-byte stores)
 	else S3_LAUNCH(0);
 #undef S3_LAUNCH
 	return hipGetLastError();
