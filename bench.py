@@ -787,7 +787,7 @@ def main():
             # the forward blend = blend_weights_kernel + blend_accum_sweep_kernel (one launch each);
             # SURVEY 8(d)'s algorithmic bytes are a property of the pair, so the roofline is quoted
             # on the pair; the per-kernel live durations are alongside (rocprof: profiles/).
-            "roofline": {"bound": "hbm", "kernel": "blend_fwd (blend_weights_kernel<4> + blend_accum_sweep2_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "blend_fwd (blend_weights_kernel<4> + blend_accum_sweep3_kernel)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "algorithmic_bytes": bytes_blend,
                          "kernel_ms": blend_ms,
@@ -799,8 +799,8 @@ def main():
                              "note": "algorithmic flops / blend time against the fp32 vector (= fp32 MFMA) peak 157.3 TF; the six "
                                      "bf16 products (all 256 pixels of every active entry, ~55 % of sum n_t_eff) against HALF the "
                                      "dense bf16 peak: the legacy 32x32x8 instruction the sweep issues runs at 512 FLOP/clk/SIMD "
-                                     "(the double-rate x16 form is not used, DESIGN.md 5.10) -- PMC: the matrix pipe is 59 % busy "
-                                     "(profiles/r03_blend_pmc.txt: SQ_VALU_MFMA_BUSY_CYCLES)"},
+                                     "(the double-rate x16 form is not in the product library, DESIGN.md 5.10) -- PMC: profiles/r04_blend_pmc.txt "
+                                     "(SQ_VALU_MFMA_BUSY_CYCLES)"},
                          "measured": f"hipEvents on the launch stream over {sv_default['forwards']} forwards with one view "
                                      f"in flight; the timed region keeps {V} in flight (stage_ms_timed_region)"},
             # bytes_alg of the WHOLE forward (blend + binning front end) over the frame time

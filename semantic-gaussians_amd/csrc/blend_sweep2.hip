@@ -1347,7 +1347,11 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	};
 
 	const bool skip_stores = (DBG & 1) != 0;
-	constexpr int SMODE = (DBG & 8) ? 0 : 3;   // transposed 16-byte stores (s2_store4, SMODE 3); DBG & 8: the 4-byte stores of the kernel above (A/B)
+	// DBG & 8 (experiment): transposed 16-byte stores (s2_store4, SMODE 3) -- a tile pair = 32 store instructions instead of 128.
+	// Measured (call G, profiles/r04_sweep_wide_stores.txt): 6 % SLOWER (1.26-1.34 vs 1.18-1.22 ms), and the cycles between
+	// steps did not move: what a pair's store burst costs is its BYTES (16 KB per wave through a CU's store path at ~7 B/clk),
+	// not its instruction count or the wave's 6-bit counter of outstanding operations.  The 4-byte stores stay.
+	constexpr int SMODE = (DBG & 8) ? 3 : 0;
 	const uint32_t wdelta = SMODE == 3 ? (uint32_t)(lane & 3) : 0u;   // (SMODE 3: the lane's transpose masks)
 #undef S2_PAIR_OFF
 #define S2_PAIR_OFF(y_, txl_)                                                                        \
@@ -1533,7 +1537,7 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	else if (dbg == 2) S3_LAUNCH(2);   // no matrix work
 	else if (dbg == 3) S3_LAUNCH(3);   // ring only
 	else if (dbg == 4) S3_LAUNCH(4);   // phase clocks (tools/sweep_phases.py)
-	else if (dbg == 8) S3_LAUNCH(8);   // 4-byte stores (A/B against the transposed 16-byte stores)
+	else if (dbg == 8) S3_LAUNCH(8);   // transposed 16-byte stores (experiment: slower)
 	else S3_LAUNCH(0);
 #undef S3_LAUNCH
 	return hipGetLastError();
