@@ -1209,20 +1209,25 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			const int pc = 3 * wave + (i - 1);
 			const int par = pc / 12, p = pc - 12 * par;
 			return wgt + (size_t)((bd.slot >> 3) + (uint32_t)(p / 6)) * 12288 + (size_t)((p % 6) / 2) * 4096 +
-			       (size_t)par * 2048 + (size_t)(p % 2) * 1024 + (size_t)lane * 16;
+			       (size_t)par * 2048 + (size_t)(p % 2) * 1024;   // (wave-uniform; the lane adds lane * 16)
 		}
 	};
-	auto dma_go = [&](auto I, const char* src, uint32_t st) __attribute__((always_inline)) {
+	// the load itself.  Piece 0 carries a 64-bit address per lane (two different rows per instruction); the weight and id
+	// pieces are "uniform base + 32-bit lane offset": the SGPR-base form of the instruction moves half the address bytes.
+	// (m0 = the LDS destination; the compiler sets m0 itself in front of its own LDS-DMA builtin, it keeps nothing in it.)
+	const uint32_t lane16 = (uint32_t)lane * 16u;
+	auto dma_go = [&](auto I, const char* src, uint32_t st, uint32_t voff) __attribute__((always_inline)) {
 		constexpr int i = decltype(I)::value;
 		if constexpr (i == 0)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
 							 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(2 * wave) * 512u), 16, 0, 0);
-		else if constexpr (i == 4)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-							 (__attribute__((address_space(3))) void*)(size_t)(st + my_ids), 4, 0, 0);
-		else
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-							 (__attribute__((address_space(3))) void*)(size_t)(st + 8192u + (uint32_t)(3 * wave + (i - 1)) * 1024u), 16, 0, 0);
+		else {
+			const uint32_t ldst = i == 4 ? st + my_ids : st + 8192u + (uint32_t)(3 * wave + (i - 1)) * 1024u;
+			if constexpr (i == 4)
+				asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(ldst), "v"(voff), "s"(src) : "memory", "m0");
+			else
+				asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(ldst), "v"(voff), "s"(src) : "memory", "m0");
+		}
 	};
 	auto issue_all = [&](const Bundle& bd) __attribute__((always_inline)) {
 		dma_piece(std::integral_constant<int, 0>{}, bd);
@@ -1368,11 +1373,11 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	do {                                                                                             \
 		constexpr int TA_[6] = {2, 0, 1, 1, 0, 0}, TB_[6] = {0, 2, 1, 0, 1, 0};   /* smallest terms first */ \
 		mfma_pair<bx_, by_>(A_.t[TA_[c_]][0], u32x2{x2_[TB_[c_]].x, x2_[TB_[c_]].y}, u32x2{y2_[TB_[c_]].x, y2_[TB_[c_]].y}); \
-		if constexpr ((c_) == 0) dma_go(std::integral_constant<int, 0>{}, da0_, dst_);               \
-		if constexpr ((c_) == 1) dma_go(std::integral_constant<int, 1>{}, da1_, dst_);               \
-		if constexpr ((c_) == 2) dma_go(std::integral_constant<int, 2>{}, da2_, dst_);               \
-		if constexpr ((c_) == 3) dma_go(std::integral_constant<int, 3>{}, da3_, dst_);               \
-		if constexpr ((c_) == 4) dma_go(std::integral_constant<int, 4>{}, da4_, dst_);               \
+		if constexpr ((c_) == 0) dma_go(std::integral_constant<int, 0>{}, da0_, dst_, 0u);           \
+		if constexpr ((c_) == 1) dma_go(std::integral_constant<int, 1>{}, da1_, dst_, lane16);       \
+		if constexpr ((c_) == 2) dma_go(std::integral_constant<int, 2>{}, da2_, dst_, lane16);       \
+		if constexpr ((c_) == 3) dma_go(std::integral_constant<int, 3>{}, da3_, dst_, lane16);       \
+		if constexpr ((c_) == 4) dma_go(std::integral_constant<int, 4>{}, da4_, dst_, io4_);         \
 		mfma_pair<bx_, by_>(A_.t[TA_[c_]][1], u32x2{x2_[TB_[c_]].z, x2_[TB_[c_]].w}, u32x2{y2_[TB_[c_]].z, y2_[TB_[c_]].w}); \
 	} while (0)
 // One step = batch j into accumulator blocks b0_..b3_.  PREP: table words; operand reads of batch j go out first (stage j
@@ -1386,13 +1391,14 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		S3_STAMP(0);                                                                                 \
 		/* the source addresses of this wave's five DMA pieces: computed HERE (64-bit VALU chains), issued between the MFMA  \
 		   pairs, where only the m0 write and the load itself remain */                                \
-		const char* da0_ = dma_src(std::integral_constant<int, 0>{}, nb);                             \
-		const char* da1_ = dma_src(std::integral_constant<int, 1>{}, nb);                             \
-		const char* da2_ = dma_src(std::integral_constant<int, 2>{}, nb);                             \
+		const char* da0_ = dma_src(std::integral_constant<int, 0>{}, nb);   /* per lane: two feature rows */ \
+		const char* da1_ = dma_src(std::integral_constant<int, 1>{}, nb);   /* wave-uniform bases (SGPRs): */ \
+		const char* da2_ = dma_src(std::integral_constant<int, 2>{}, nb);   /* the lane offset is lane * 16 */ \
 		const char* da3_ = dma_src(std::integral_constant<int, 3>{}, nb);                             \
-		const char* da4_ = dma_src(std::integral_constant<int, 4>{}, nb);                             \
+		const char* da4_ = (const char*)(act_id + nb.slot2);                                          \
+		uint32_t io4_ = ((uint32_t)(lane & 15) < nb.n2 ? (uint32_t)(lane & 15) : nb.n2 - 1u) * 4u;   \
 		const uint32_t dst_ = nb.st;                                                                 \
-		asm volatile("" : "+v"(da0_), "+v"(da1_), "+v"(da2_), "+v"(da3_), "+v"(da4_));                \
+		asm volatile("" : "+v"(da0_), "+s"(da1_), "+s"(da2_), "+s"(da3_), "+s"(da4_), "+v"(io4_));    \
 		float f_[8];                                                                                 \
 		u32x4 x_[3], y_[3], x2_[3], y2_[3];                                                          \
 		Op3 A_;                                                                                      \

@@ -221,8 +221,11 @@ struct BinLayout {
 	size_t rowtab, cmat, gtot, tilelen;
 };
 
+// sort_room: reserve the radix sort's temporary storage (binning modes 1 / 2 sort the instances; mode 0 -- the default, span
+// partitions -- never does: 0.4 GB per frame at cfg3 that round 3 carried for nothing).  The four public arrays come first, so
+// their offsets (what sgs_binning_layout_of reports and the backward uses) do not depend on it.
 BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int ntiles = 0, uint32_t R = 0,
-		     int gx = 0, int gy = 0, int P = 0)
+		     int gx = 0, int gy = 0, int P = 0, bool sort_room = true)
 {
 	BinLayout b;
 	Carver c;
@@ -231,7 +234,7 @@ BinLayout bin_layout(size_t L, int sort_bits, uint32_t arena_capacity = 0, int n
 	b.pub.keys_sorted = c.take(L * 8);
 	b.pub.point_list = c.take(L * 4);
 	b.sort_temp_bytes = 0;
-	if (L) {   // room for either mode's radix sort
+	if (L && sort_room) {   // room for either sorting mode's radix sort
 		const size_t t64 = sgs::sort_temp_bytes(L, 0, sort_bits), t32 = sgs::sort32_temp_bytes(L, sort_bits - 32);
 		b.sort_temp_bytes = t64 > t32 ? t64 : t32;
 	}
@@ -734,7 +737,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 			cx->usage_pending = false;
 		}
 		(void)hipGetLastError();
-		if (hint < (uint32_t)ntiles * 192u) hint = (uint32_t)ntiles * 192u;   // chunks of 128 slots
+		// floor: every tile's implicit first chunk (128 slots) + a quarter on top for the tiles that need more (round 3: a half
+		// -- at cfg3 92 % of the tiles stay inside their first chunk; an overflow costs one fallback frame and grows the hint)
+		if (hint < (uint32_t)ntiles * 160u) hint = (uint32_t)ntiles * 160u;
 		hint = (hint + 0xffffu) & ~0xffffu;   // 64k-slot granularity keeps the buffer size stable
 		cx->arena_hint = hint;
 		cx->stat[SGS_STAT_ARENA_SLOTS] = hint;
@@ -742,7 +747,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		arena_max = (uint64_t)L + 128ull * (uint64_t)ntiles;
 		arena_cap = (uint64_t)hint < arena_max ? hint : (uint32_t)arena_max;
 	}
-	const BinLayout bl = bin_layout(L, sort_bits, arena_cap, ntiles, Rrows, gx, gy, P);
+	const BinLayout bl = bin_layout(L, sort_bits, arena_cap, ntiles, Rrows, gx, gy, P, !rows);
 	char* bchunk = (char*)binning_buffer(binning_user, bl.total);
 	if (!bchunk) return fail(SGS_EALLOC, "binning buffer allocation failed");
 	bchunk = align_ptr(bchunk);
