@@ -871,3 +871,39 @@ def test_empty_tiles_backward(orc):
                 continue
             ok, err = _grad_close(outs[i].reshape(gr[name].shape), gr[name], 1e-4)
             assert ok, (name, mode, err)
+
+
+def test_tile_order_feedback_does_not_change_results(orc):
+    """Round 4: the weights pre-pass takes its tiles longest-first by the work they had in the stream's PREVIOUS frame
+    (BlendFwdArgs::tile_order, written by sweep_plan_kernel).  A scheduling hint only: on a fresh stream the first frame runs
+    in tile order, the second with the first frame's order, a third frame of a DIFFERENT scene with the same tile grid runs
+    with a stale order -- every integer output and the feature map are identical to the renders without any order."""
+    from sgs_hip import raster
+    a, cam = small_scene(P=6000, C=128, W=208, H=160, fx=170.0, seed=41)
+    b, _ = small_scene(P=2500, C=128, W=208, H=160, fx=170.0, seed=42)
+    b = b._replace(scales=b.scales * 2.5)
+
+    def frame(scene):
+        n, color, radii, geom, binn, img, _ = _hip_forward(scene, cam, variant=0)
+        iv = raster.image_views(img, 208, 160)
+        return n, color.clone(), radii.clone(), iv["n_contrib"].clone(), iv["final_T"].clone()
+
+    fresh = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(fresh[0]):
+        a0 = frame(a)        # no order yet
+        a1 = frame(a)        # a's own order
+        b_stale = frame(b)   # a's order, b's scene
+        b_own = frame(b)     # b's order
+    with torch.cuda.stream(fresh[1]):
+        b0 = frame(b)        # no order
+    torch.cuda.synchronize()
+    for x, y in ((a0, a1), (b0, b_stale), (b0, b_own)):
+        assert x[0] == y[0]
+        for u, v in zip(x[1:], y[1:]):
+            assert torch.equal(u, v)
+    fw = oracle_forward(orc, a, cam)
+    assert a0[0] == fw["num_rendered"] and np.array_equal(a1[3].cpu().numpy().view(np.uint32), fw["n_contrib"])
+    for st in fresh[:2]:
+        with torch.cuda.stream(st):
+            raster.release_stream()
