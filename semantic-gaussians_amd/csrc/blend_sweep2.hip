@@ -374,6 +374,55 @@ __device__ __forceinline__ void mfma_dense_wide(const u32x4 (&a)[3], const u32x4
 #undef S2_P
 }
 
+// (round 4 experiment, make X16=1) the same double-rate statements with ONE filler between consecutive MFMAs -- SP = 1:
+// `s_nop 0`, SP = 2: a VALU move on a scratch register.  Round 3's evidence: the x16 sweep whose MFMAs were
+// separated by VALU work never disturbed a neighbour (0 of 324 000), 12 back-to-back ones do (1 in 300-1 100): is it the
+// DENSITY of the issue?  An MFMA holds the pipe for 32 cycles, so one filler in its shadow costs nothing.
+template <int SP, int BX, int BY>
+__device__ __forceinline__ void mfma_dense_wide_sp(const u32x4 (&a)[3], const u32x4 (&x)[3], const u32x4 (&y)[3])
+{
+	uint32_t scratch = 0u;
+#define S2_F "%13"
+#define S2_P(a_, bx_, by_)                                                                            \
+	"v_mfma_f32_32x32x16_bf16 a[%c0:%c1], " a_ ", " bx_ ", a[%c0:%c1]\n\t" S2_FILL                  \
+	"v_mfma_f32_32x32x16_bf16 a[%c2:%c3], " a_ ", " by_ ", a[%c2:%c3]\n\t" S2_FILL
+	if constexpr (SP == 1) {
+#define S2_FILL "s_nop 0\n\t"
+		asm volatile("s_nop 1\n\t" S2_P("%6", "%7", "%10") S2_P("%4", "%9", "%12") S2_P("%5", "%8", "%11")
+			     S2_P("%5", "%7", "%10") S2_P("%4", "%8", "%11") S2_P("%4", "%7", "%10") "s_nop 0"
+			     : : "i"(BX * 16), "i"(BX * 16 + 15), "i"(BY * 16), "i"(BY * 16 + 15),
+				 "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(scratch)
+			     : S2_ACC, "memory");
+#undef S2_FILL
+	} else {
+#define S2_FILL "v_mov_b32 " S2_F ", " S2_F "\n\t"
+		asm volatile("s_nop 1\n\t" S2_P("%6", "%7", "%10") S2_P("%4", "%9", "%12") S2_P("%5", "%8", "%11")
+			     S2_P("%5", "%7", "%10") S2_P("%4", "%8", "%11") S2_P("%4", "%7", "%10") "s_nop 0"
+			     : : "i"(BX * 16), "i"(BX * 16 + 15), "i"(BY * 16), "i"(BY * 16 + 15),
+				 "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(scratch)
+			     : S2_ACC, "memory");
+#undef S2_FILL
+	}
+#undef S2_P
+#undef S2_F
+}
+
+template <int SP, int BX, int BY>
+__device__ __forceinline__ void mfma_pair_wide_sp(u32x4 a, u32x4 bx, u32x4 by)
+{
+	uint32_t scratch = 0u;
+	if constexpr (SP == 1)
+		asm volatile("s_nop 1\n\t"
+			     "v_mfma_f32_32x32x16_bf16 a[%c0:%c1], %4, %5, a[%c0:%c1]\n\ts_nop 0\n\t"
+			     "v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %4, %6, a[%c2:%c3]\n\ts_nop 0"
+			     : : "i"(BX * 16), "i"(BX * 16 + 15), "i"(BY * 16), "i"(BY * 16 + 15), "v"(a), "v"(bx), "v"(by), "v"(scratch) : S2_ACC, "memory");
+	else
+		asm volatile("s_nop 1\n\t"
+			     "v_mfma_f32_32x32x16_bf16 a[%c0:%c1], %4, %5, a[%c0:%c1]\n\tv_mov_b32 %7, %7\n\t"
+			     "v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %4, %6, a[%c2:%c3]\n\tv_mov_b32 %7, %7"
+			     : : "i"(BX * 16), "i"(BX * 16 + 15), "i"(BY * 16), "i"(BY * 16 + 15), "v"(a), "v"(bx), "v"(by), "v"(scratch) : S2_ACC, "memory");
+}
+
 // The batch with the weights already split by the weights pre-pass (work-list format MODE 4): stage = features (fp32,
 // split here: 44 VALU) | [group h][term][128 px x 8 bf16].  A lane's B operand of a (term, pixel block) is ONE 16-byte
 // read: its two halves are the operands of the two MFMAs over k = 8 h + 4 q + i.  Pixel blocks in pairs, consecutive
@@ -1082,7 +1131,9 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 constexpr int S3_NST = 4, S3_LA = S3_NST - 1;
 constexpr int S3_STAGE = 8192 + 2 * 12288 + 8 * 256;   // features | weights parity 0 | weights parity 1 | id words of 8 waves
 
-template <int DBG>
+// MM (make X16=1 only): 0 = the six products on v_mfma_f32_32x32x8_bf16 (the product); 1 = on the double-rate x16 MFMA, dense
+// statements; 2 / 3 = x16 with one filler (s_nop 0 / a VALU move) between consecutive MFMAs -- the round-4 bisect of DESIGN.md 5.10
+template <int DBG, int MM = 0>
 __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -1380,6 +1431,17 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		if constexpr ((c_) == 4) dma_go(std::integral_constant<int, 4>{}, da4_, dst_, io4_);         \
 		mfma_pair<bx_, by_>(A_.t[TA_[c_]][1], u32x2{x2_[TB_[c_]].z, x2_[TB_[c_]].w}, u32x2{y2_[TB_[c_]].z, y2_[TB_[c_]].w}); \
 	} while (0)
+#define S3_HALF2W(bx_, by_, c_)                                                                      \
+	do {                                                                                             \
+		constexpr int TA_[6] = {2, 0, 1, 1, 0, 0}, TB_[6] = {0, 2, 1, 0, 1, 0};                      \
+		if constexpr (MM == 1) mfma_pair_wide<bx_, by_>(aw_[TA_[c_]], x2_[TB_[c_]], y2_[TB_[c_]]);   \
+		else mfma_pair_wide_sp<(MM > 1 ? MM - 1 : 1), bx_, by_>(aw_[TA_[c_]], x2_[TB_[c_]], y2_[TB_[c_]]); \
+		if constexpr ((c_) == 0) dma_go(std::integral_constant<int, 0>{}, da0_, dst_, 0u);           \
+		if constexpr ((c_) == 1) dma_go(std::integral_constant<int, 1>{}, da1_, dst_, lane16);       \
+		if constexpr ((c_) == 2) dma_go(std::integral_constant<int, 2>{}, da2_, dst_, lane16);       \
+		if constexpr ((c_) == 3) dma_go(std::integral_constant<int, 3>{}, da3_, dst_, lane16);       \
+		if constexpr ((c_) == 4) dma_go(std::integral_constant<int, 4>{}, da4_, dst_, io4_);         \
+	} while (0)
 // One step = batch j into accumulator blocks b0_..b3_.  PREP: table words; operand reads of batch j go out first (stage j
 // landed before the barrier this phase began with); the DMA pieces of bundle j + LA and the deferred stores (DEF_) are
 // issued while they land; the feature split; [second half: arrival check of bundle j + 1]; barrier; MFMA: 48 products;
@@ -1435,11 +1497,22 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		__builtin_amdgcn_s_barrier();                                                                \
 		S3_STAMP(5);                                                                                 \
 		if (!(DBG & 2)) {                                                                            \
-			mfma_dense<b0_, b1_>(A_, x_, y_);                                                        \
-			S3_HALF2(b2_, b3_, 0); S3_HALF2(b2_, b3_, 1); S3_HALF2(b2_, b3_, 2);                     \
-			S3_HALF2(b2_, b3_, 3); S3_HALF2(b2_, b3_, 4);                                            \
-			if (!g) poll_issue(stn_, pw_, pid_);   /* (first half) under the last four MFMAs */       \
-			S3_HALF2(b2_, b3_, 5);                                                                   \
+			if constexpr (MM == 0) {                                                                 \
+				mfma_dense<b0_, b1_>(A_, x_, y_);                                                    \
+				S3_HALF2(b2_, b3_, 0); S3_HALF2(b2_, b3_, 1); S3_HALF2(b2_, b3_, 2);                 \
+				S3_HALF2(b2_, b3_, 3); S3_HALF2(b2_, b3_, 4);                                        \
+				if (!g) poll_issue(stn_, pw_, pid_);   /* (first half) under the last four MFMAs */   \
+				S3_HALF2(b2_, b3_, 5);                                                               \
+			} else {   /* (make X16=1) the double-rate forms */                                     \
+				u32x4 aw_[3];                                                                        \
+				for (int t_ = 0; t_ < 3; t_++) aw_[t_] = u32x4{A_.t[t_][0].x, A_.t[t_][0].y, A_.t[t_][1].x, A_.t[t_][1].y}; \
+				if constexpr (MM == 1) mfma_dense_wide<b0_, b1_>(aw_, x_, y_);                        \
+				else mfma_dense_wide_sp<MM - 1, b0_, b1_>(aw_, x_, y_);                               \
+				S3_HALF2W(b2_, b3_, 0); S3_HALF2W(b2_, b3_, 1); S3_HALF2W(b2_, b3_, 2);              \
+				S3_HALF2W(b2_, b3_, 3); S3_HALF2W(b2_, b3_, 4);                                      \
+				if (!g) poll_issue(stn_, pw_, pid_);                                                 \
+				S3_HALF2W(b2_, b3_, 5);                                                              \
+			}                                                                                        \
 		} else if (!g) poll_issue(stn_, pw_, pid_);                                                  \
 		S3_STAMP(6);                                                                                 \
 		if (!g) nid = poll_finish(stn_, pw_, pid_);                                                  \
@@ -1511,6 +1584,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 #undef S2_PAIR_OFF
 #undef S3_STAMP
 #undef S3_HALF2
+#undef S3_HALF2W
 #undef S3_STEP
 #undef S3_LEFT_TILE
 #undef S3_RIGHT_TILE
@@ -1539,6 +1613,21 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt, tune)
+#ifdef SGS_WITH_X16   // (make X16=1) bits [19:16] of the variant: 1 = x16 dense, 2 = x16 + s_nop filler, 3 = x16 + VALU filler
+	if (tune >= 1 && tune <= 3) {
+#define S3_LAUNCH_MM(M_)                                                                             \
+	hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, M_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
+			   pxcd, items, a.pitch, trace, order, dealt, tune)
+		if (tune == 1) S3_LAUNCH_MM(1);
+		else if (tune == 2) S3_LAUNCH_MM(2);
+		else S3_LAUNCH_MM(3);
+#undef S3_LAUNCH_MM
+		return hipGetLastError();
+	}
+#else
+	if (tune != 0) return hipErrorInvalidValue;   // (the x16 forms of this sweep are not in the product library)
+#endif
 	if (dbg == 1) S3_LAUNCH(1);        // (development ablations) no stores
 	else if (dbg == 2) S3_LAUNCH(2);   // no matrix work
 	else if (dbg == 3) S3_LAUNCH(3);   // ring only

@@ -716,8 +716,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		return fail(SGS_EINVAL, "blend variants 32-35 (fused single-kernel experiments) are not in this build (make FUSED=1)");
 #endif
 #ifndef SGS_WITH_X16   // (make X16=1: the double-rate-MFMA experiments, DESIGN.md 5.10 -- reproducers, not product)
-	if (variant >= 16 && ((variant & 15) == 12 || (variant & 15) == 15 || ((variant & 15) == 8 && ((variant >> 8) & 15) == 8)))
-		return fail(SGS_EINVAL, "blend variants on v_mfma_f32_32x32x16_bf16 (sweep nibble 12 / 15, 0x8.8) are not in this build (make X16=1)");
+	if (variant >= 16 && ((variant & 15) == 12 || (variant & 15) == 15 || ((variant & 15) == 8 && ((variant >> 8) & 15) == 8) ||
+			      ((variant & 15) == 6 && ((variant >> 16) & 15) != 0)))
+		return fail(SGS_EINVAL, "blend variants on v_mfma_f32_32x32x16_bf16 (sweep nibble 12 / 15, 0x8.8, 0x1..3 << 16 | ..6) are not in this build (make X16=1)");
 #endif
 	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
