@@ -177,7 +177,7 @@ def test_x16_experiments_are_not_in_the_product_library():
     on some boxes (a library GEMM beside the same victim does not): they are built only by `make X16=1`; the default library
     answers their variants with an error instead of running them."""
     scene, cam = small_scene(P=500, C=128, W=64, H=48, fx=100.0, seed=2)
-    for v in (0x6C, 0x6F, 0x16F, 0x808, 0x1F):
+    for v in (0x6C, 0x6F, 0x16F, 0x808, 0x1F, 0x10036, 0x30066):   # (the last two: x16 forms of the ping-pong sweep)
         with pytest.raises(RuntimeError, match="X16"):
             _hip_forward(scene, cam, variant=v)
     _hip_forward(scene, cam, variant=0)   # (and the stream is usable afterwards)
