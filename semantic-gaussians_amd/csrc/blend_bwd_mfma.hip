@@ -18,9 +18,7 @@
 //                                for the background: its D row is  bg . g.
 //   2. bwd_dcolor_kernel         dL/dF = W G^T per (tile, 128 channels): fp32 MFMA, one coalesced
 //                                atomic row per (entry, 32 channels).
-//   3. bwd_dot_kernel            D = F G per tile, fp32 MFMA; D rows have their own storage behind the weight rows (round 4:
-//                                2 and 3 are independent given the work list and run on two streams side by side -- the
-//                                gradient tile one has just read is in the L2 / Infinity Cache for the other).
+//   3. bwd_dot_kernel            D = F G per tile, fp32 MFMA; D rows overwrite the weight rows.
 //   4. bwd_geom_kernel           lane = pixel, back-to-front over the work list: recomputes G / alpha,
 //                                walks T back from T_final (as the reference does), the scalar
 //                                recurrence above, and the wave-reduced atomics of blend_bwd.hip for
@@ -755,8 +753,7 @@ bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 }
 
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products, size_t clear_dcolor_floats, hipStream_t side, hipEvent_t fork_ev,
-				      hipEvent_t join_ev)
+				      bool fp32_products, size_t clear_dcolor_floats)
 {
 	const int ntiles = a.gx * a.gy;
 	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
@@ -769,24 +766,16 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const uint32_t* table = (const uint32_t*)(arena + lay.table);
 	const uint32_t* act_id = (const uint32_t*)(arena + lay.act_id);
 	const uint32_t* act_idx = (const uint32_t*)(arena + lay.act_idx);
-	float* rows = (float*)(arena + lay.wgt);                      // the work list's weight rows (1 KB per slot)
-	float* drows = rows + (size_t)lay.capacity * 256;            // D = F G rows: their own storage (round 4), so that the two
-	// products need no order between them
-	const bool two_streams = side && fork_ev && join_ev;
+	float* rows = (float*)(arena + lay.wgt);
 	const int nch = (a.C + 127) / 128;
 	const int items = ntiles * nch;
 	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
 	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows
-	hipStream_t sd = st;   // the stream of D = F G
-	if (two_streams) {
-		if (hipEventRecord(fork_ev, st) == hipSuccess && hipStreamWaitEvent(side, fork_ev, 0) == hipSuccess) sd = side;
-		else (void)hipGetLastError();
-	}
 #define SGS_LAUNCH_BWD(DCOL_, DOT_)                                                                              \
-	hipLaunchKernelGGL(DOT_, dim3(txcd * 8), dim3(512), 0, sd, a.ranges, table, nact, act_id, a.colors, a.bg,  \
-			   a.dL_dpix, drows, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);                        \
 	hipLaunchKernelGGL(DCOL_, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id,                 \
-			   rows, a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items)
+			   rows, a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);        \
+	hipLaunchKernelGGL(DOT_, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, a.colors, a.bg,  \
+			   a.dL_dpix, rows, counter, a.W, a.H, a.C, a.gx, txcd, ntiles)
 	if (fp32_products) {
 		if (vec) { SGS_LAUNCH_BWD(bwd_dcolor_kernel<true>, bwd_dot_kernel<true>); }
 		else { SGS_LAUNCH_BWD(bwd_dcolor_kernel<false>, bwd_dot_kernel<false>); }
@@ -795,13 +784,8 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 		else { SGS_LAUNCH_BWD(bwd_dcolor_split_kernel<false>, bwd_dot_split_kernel); }
 	}
 #undef SGS_LAUNCH_BWD
-	if (sd != st) {   // join: the recurrence (and everything behind it on st, the scratch's release included) waits for D
-		hipError_t ej = hipEventRecord(join_ev, sd);
-		if (ej == hipSuccess) ej = hipStreamWaitEvent(st, join_ev, 0);
-		if (ej != hipSuccess) return ej;
-	}
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
-			   drows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
+			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
 			   a.dL_dopacity, counter, a.W, a.H, a.gx, txcd, ntiles);
 	e = hipGetLastError();
 	if (e != hipSuccess) return e;

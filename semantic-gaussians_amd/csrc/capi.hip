@@ -48,9 +48,6 @@ struct StreamCtx {
 	uint32_t* tile_order = nullptr;
 	size_t tile_order_cap = 0;
 	// backward (work-list MFMA path)
-	hipStream_t bwd_side = nullptr;   // the second stream the backward's D = F G product runs on (blend_bwd_mfma.hip), with its
-	hipEvent_t bwd_fork = nullptr, bwd_join = nullptr;   // fork / join events; created on first use
-	bool bwd_side_failed = false;
 	uint32_t bwd_hint = 0;
 	uint32_t* bwd_usage_host = nullptr;
 	hipEvent_t bwd_ev = nullptr;
@@ -73,9 +70,6 @@ struct StreamCtx {
 	{
 		if (usage_host) (void)hipHostFree(usage_host);
 		if (tile_order) (void)hipFree(tile_order);
-		if (bwd_fork) (void)hipEventDestroy(bwd_fork);
-		if (bwd_join) (void)hipEventDestroy(bwd_join);
-		if (bwd_side) (void)hipStreamDestroy(bwd_side);
 		if (bwd_usage_host) (void)hipHostFree(bwd_usage_host);
 		if (count_host) (void)hipHostFree(count_host);
 		if (count_ev) (void)hipEventDestroy(count_ev);
@@ -1004,20 +998,7 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 			uint32_t cap = (uint64_t)hint < cap_max ? hint : (uint32_t)cap_max;
 			if (bw_mode == 2) cap = 128u * (uint32_t)((ntiles + 1) / 2);   // (tests: guaranteed overflow -> gated fallback)
 			sgs::SplitArena lay;
-			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay, 2048);   // fp32 weight rows | D rows
-			// the second stream of this context (SGS_BWD_SERIAL=1: both products on the caller's stream, A/B)
-			static const bool bwd_serial = getenv("SGS_BWD_SERIAL") && atoi(getenv("SGS_BWD_SERIAL")) != 0;
-			if (!bwd_serial && !cx->bwd_side && !cx->bwd_side_failed) {
-				if (hipStreamCreateWithFlags(&cx->bwd_side, hipStreamNonBlocking) != hipSuccess ||
-				    hipEventCreateWithFlags(&cx->bwd_fork, hipEventDisableTiming) != hipSuccess ||
-				    hipEventCreateWithFlags(&cx->bwd_join, hipEventDisableTiming) != hipSuccess) {
-					(void)hipGetLastError();
-					cx->bwd_side_failed = true;
-					if (cx->bwd_side) (void)hipStreamDestroy(cx->bwd_side);
-					cx->bwd_side = nullptr;
-				}
-			}
-			const bool use_side = !bwd_serial && cx->bwd_side && cx->bwd_fork && cx->bwd_join;
+			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay, 1024);   // fp32 weight rows
 			void* scratch = nullptr;
 			hipMemPool_t pool = scratch_pool();
 			hipError_t ea = pool ? hipMallocFromPoolAsync(&scratch, bytes + 128, pool, st)
@@ -1027,8 +1008,7 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 				const bool fold = dcolor_dirty && (dcolor_floats & 3) == 0 && ((uintptr_t)dL_dcolor & 15u) == 0;
 				if (dcolor_dirty && !fold) (void)hipMemsetAsync(dL_dcolor, 0, dcolor_floats * 4, st);
 				dcolor_dirty = false;
-				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3, fold ? dcolor_floats : 0,
-								    use_side ? cx->bwd_side : nullptr, cx->bwd_fork, cx->bwd_join);
+				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3, fold ? dcolor_floats : 0);
 				if (e == hipSuccess && cx->ensure(cx->bwd_usage_host, cx->bwd_ev)) {
 					if (hipMemcpyAsync(cx->bwd_usage_host, arena + lay.counter, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
 					    hipEventRecord(cx->bwd_ev, st) == hipSuccess)

@@ -184,14 +184,8 @@ hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const ui
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a);
 // fp32_products: the two channel products on v_mfma_f32_32x32x2_f32 (exact fp32 products) instead of split bf16
 // clear_dcolor: a.dL_dcolors (P x C floats) is zero-filled by the first kernel instead of by the caller
-// side / fork_ev / join_ev (optional, all three or none): a second stream of the caller's context.  The two products are
-// independent given the work list (D = F G is written to its own rows, dL/dF = W G^T reads the weight rows), so D runs on
-// `side` beside dL/dF on `st` and the scalar recurrence waits for both: the gradient tile one of them has just read is in the
-// L2 / Infinity Cache for the other, and one's tail fills with the other's workgroups.  The arena must have been laid out with
-// 2048 B per slot (weights rows | D rows).
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products, size_t clear_dcolor_floats = 0, hipStream_t side = nullptr,
-				      hipEvent_t fork_ev = nullptr, hipEvent_t join_ev = nullptr);
+				      bool fp32_products, size_t clear_dcolor_floats = 0);
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
 			   const int* radii, const float* shs, const uint8_t* clamped,
 			   const float* scales, const float* rotations, float mod,
