@@ -308,13 +308,17 @@ int sgs_stream_release(void *stream);
  *                 the fastest, NOT fp32-class;
  *  1/2/3        = single-kernel px1 with 64/128/32 channels per workgroup; 4/5/6 = single-kernel px4
  *                 forms (all bit-identical);
- *  >= 16        = sweep tuning word: bits [3:0] accumulate kernel (8 = variant 14's, 9 = its fp32-MFMA form,
- *                 blend_sweep2.hip: 10 six products with the weights split in the sweep, 11 fp32 MFMA, 13 as 10 block by
- *                 block, 14 six products with weights pre-split by the pre-pass (the default), 7 as 14 with fp32 weights
- *                 handed over and split once per workgroup into LDS (experiment, bit-identical), 12 / 15 = 10 / 14 on the
- *                 double-rate v_mfma_f32_32x32x16_bf16 -- EXPERIMENTS ONLY: kernels that issue that instruction densely
- *                 damage unrelated kernels running beside them on this hardware), [7:4] segment length / 8
- *                 (0 = adaptive), [11:8] development ablations (1 = no stores, 2 = no matrix work, 4 / 8 = store forms).
+ *  >= 16        = sweep tuning word: bits [3:0] accumulate kernel (6 = round 4's ping-pong sweep -- one 8-wave workgroup per
+ *                 (segment, 128 channels) for both row parities, six products with pre-split weights: THE DEFAULT; 8 =
+ *                 variant 14's, 9 = its fp32-MFMA form; blend_sweep2.hip: 10 six products with the weights split in the
+ *                 sweep, 11 fp32 MFMA, 13 as 10 block by block, 14 round 3's sweep (two workgroups per CU; the same
+ *                 arithmetic as 6, bit-identical), 7 as 14 with fp32 weights handed over and split once per workgroup into
+ *                 LDS (experiment, bit-identical); 12 / 15 = 10 / 14 on the double-rate v_mfma_f32_32x32x16_bf16, and bits
+ *                 [19:16] = 1..3 with kernel 6 = the ping-pong sweep on it -- NOT IN THE PRODUCT LIBRARY (`make X16=1`; the
+ *                 default build answers SGS_EINVAL): forwards running beside these kernels come out damaged on some boxes,
+ *                 a library GEMM beside the same victim does not do that), [7:4] segment length / 8
+ *                 (0 = adaptive), [11:8] development ablations (1 = no stores, 2 = no matrix work, 4 / 8 = phase clocks /
+ *                 store forms).
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.
