@@ -1137,8 +1137,9 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// fp32-input MFMA; blend_sweep2.hip: 10 = f32-equivalent (six bf16 products), 11 = exact fp32 MFMA, 14 = six products
 		// with pre-split weights (round 3's default), 12 / 15 = six products on the double-rate MFMA (make X16=1).
 		// (the norm-plane epilogue of N1 lives in round 3's kernel: same arithmetic, same hand-over format)
-		const int arith_nib = ((split_mode & 15) == 6 && a.norm_plane) ? 14 : (split_mode & 15);
-		const bool sweep3 = arith_nib == 6;
+		const int arith_nib = (((split_mode & 15) == 6 || (split_mode & 15) == 5) && a.norm_plane) ? 14 : (split_mode & 15);
+		const bool sweep3c = arith_nib == 5;   // ping-pong sweep, fp32 weights handed over and split by the sweep (one step ahead)
+		const bool sweep3 = arith_nib == 6 || sweep3c;
 		// a ping-pong workgroup covers both parities and there is one per CU: half as many, twice as large work items
 		const int wg_per_item = sweep3 ? 1 : 2, wg_target = sweep3 ? 768 : 1536;
 		int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) * 8 : 48;
@@ -1148,7 +1149,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		const int nseg = (a.gx + seg - 1) / seg;
 		seg = ((a.gx + nseg - 1) / nseg + 1) & ~1;   // balanced, even (segments start on even tiles)
 		const bool sweep2 = (arith_nib >= 10 && arith_nib <= 15) || arith_nib == 7 || sweep3;   // 7 = six products, fp32 hand-over, split once per workgroup (S2_X6C)
-		const bool presplit3 = arith_nib >= 14 || sweep3;   // weights handed over as three bf16 terms
+		const bool presplit3 = arith_nib >= 14 || (sweep3 && !sweep3c);   // weights handed over as three bf16 terms
 		const bool exact = arith_nib == 9;
 		// weights pre-pass.  blend_weights2.hip (lane = two pixels: a third fewer instructions) is used for the fp32-row format
 		// (0.25 -> 0.22 ms at cfg3; the backward's pre-pass is the same kernel).  For the three-term format it is no faster
@@ -1160,7 +1161,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		if ((presplit3 || exact || sweep2) && !w_old) {
 			const hipError_t ew = launch_blend_weights2(st, presplit3 ? 4 : 3, a.ranges, a.point_list, a.means2D, a.conic_opacity,
 								    a.final_T, a.n_contrib, act_id, nullptr, wgt, table, nbatches, counter,
-								    lay.capacity, a.W, a.H, a.gx, ntiles, nullptr, 0);
+								    lay.capacity, a.W, a.H, a.gx, ntiles, nullptr, 0, a.tile_order);
 			if (ew != hipSuccess) return ew;
 		} else if (presplit3) SGS_LAUNCH_W(4, st, 0, ntiles);
 		else if (exact || sweep2) SGS_LAUNCH_W(3, st, 0, ntiles);
@@ -1187,7 +1188,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
 		if (sweep3) {
 			const hipError_t e3 = launch_accum_sweep3(st, (split_mode >> 8) & 15, a, table, nbatches, act_id, (const char*)wgt, counter,
-								  nc, seg, nseg, pxcd, items, g_sweep_trace, order_arg, dealt, (split_mode >> 16) & 15);
+								  nc, seg, nseg, pxcd, items, g_sweep_trace, order_arg, dealt, (split_mode >> 16) & 15, sweep3c);
 			if (e3 != hipSuccess) return e3;
 		} else if (sweep2) {
 			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 7 ? 6 : arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : (arith_nib == 15 ? 5 : 1)))), a.norm_plane ? 32 : ((split_mode >> 8) & 15), a, table,

@@ -1129,11 +1129,15 @@ __global__ __launch_bounds__(256, 2) void blend_accum_sweep2_kernel(
 // nothing changed but WHEN it does things.  Arithmetic: S2_X6P (pre-split weights, six products) only; results are
 // bit-identical to variant 0x6E (same products, same order, same accumulators).
 constexpr int S3_NST = 4, S3_LA = S3_NST - 1;
-constexpr int S3_STAGE = 8192 + 2 * 12288 + 8 * 256;   // features | weights parity 0 | weights parity 1 | id words of 8 waves
+// stage = features | weights parity 0 | weights parity 1 | id words of 8 waves.  COOP (sweep nibble 5): the weights arrive as
+// fp32 rows (8 KB per parity and batch instead of 12 KB of pre-split terms) and each wave splits the quarter it fetched into
+// a per-parity split buffer ONE STEP AHEAD (s2_split_coop): the two barriers of a step make it visible to its three sister waves
+constexpr int S3_WB(bool coop) { return coop ? 8192 : 12288; }
+constexpr int S3_STAGE_OF(bool coop) { return 8192 + 2 * S3_WB(coop) + 8 * 256; }
 
 // MM (make X16=1 only): 0 = the six products on v_mfma_f32_32x32x8_bf16 (the product); 1 = on the double-rate x16 MFMA, dense
 // statements; 2 / 3 = x16 with one filler (s_nop 0 / a VALU move) between consecutive MFMAs -- the round-4 bisect of DESIGN.md 5.10
-template <int DBG, int MM = 0>
+template <int DBG, int MM = 0, bool COOP = false>
 __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -1173,8 +1177,11 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const int c0 = cbase + cg * 32;
 	const size_t HW = (size_t)H * PW;
 
+	constexpr int S3_STAGE = S3_STAGE_OF(COOP), WB = S3_WB(COOP);
+	constexpr int NP = COOP ? 4 : 5;   // DMA pieces per wave and bundle: features | 3 pre-split / 2 fp32 weight pieces | ids
 	__shared__ float4 s_ring[S3_NST * S3_STAGE / 16];
-	constexpr int JMAX = S2_JMAX;
+	__shared__ float4 s_split[COOP ? 4 * 12288 / 16 : 1];   // COOP: [parity][batch & 1] x 12 KB of split terms
+	constexpr int JMAX = COOP ? 768 : S2_JMAX;   // (COOP: 163 KB of ring + split buffers + a 1024-batch window would not fit 160 KB)
 	__shared__ uint2 s_bt[JMAX];   // .x = first arena slot of the batch, .y = entries | tile in segment << 8 | last of tile << 16
 	__shared__ uint32_t s_tot[S2_SEGMAX], s_cb[S2_SEGMAX], s_pref[S2_SEGMAX + 1];
 
@@ -1222,70 +1229,60 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint32_t ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_ring;
 	const uint32_t bt_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_bt;
 	const uint32_t sub = (uint32_t)(2 * wave + half);   // this lane fetches the feature row of entry sub (one 1-KB piece = two rows per wave)
-	const uint32_t my_ids = 8192u + 2u * 12288u + (uint32_t)wave * 256u;   // this wave's id words inside a stage
+	const uint32_t my_ids = 8192u + 2u * (uint32_t)WB + (uint32_t)wave * 256u;   // this wave's id words inside a stage
+	const uint32_t split_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_split + (uint32_t)g * 2u * 12288u;   // this parity's two split buffers
 	// bundle = features + both parities' weights of the batch at `slot` into stage st, then the ids of the batch
 	// (slot2, n2) into the wave's id words -- LAST, so that their arrival means the wave's whole bundle arrived.
 	struct Bundle { uint32_t slot, id0, slot2, n2, st; };
-	auto dma_piece = [&](auto I, const Bundle& bd) __attribute__((always_inline)) {
-		constexpr int i = decltype(I)::value;
-		if constexpr (i == 0) {   // feature rows of entries 2 wave, 2 wave + 1: this chunk's 512 B of each
-			const float* row = bd.id0 == SGS_BG_ID ? bg : features + (size_t)bd.id0 * C;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + cbase + l31 * 4),
-							 (__attribute__((address_space(3))) void*)(size_t)(bd.st + (uint32_t)(2 * wave) * 512u), 16, 0, 0);
-		} else if constexpr (i == 4) {
-			const uint32_t li = (uint32_t)(lane & 15) < bd.n2 ? (uint32_t)(lane & 15) : bd.n2 - 1u;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(act_id + bd.slot2 + li),
-							 (__attribute__((address_space(3))) void*)(size_t)(bd.st + my_ids), 4, 0, 0);
-		} else {
-			// three bf16 terms: per group of 8 entries [term][256 px'][8 x bf16] = 12 KB, a parity's half of a term = 2 KB =
-			// two 1-KB pieces; 24 pieces per batch: pc = 3 wave + (i - 1) -> parity pc / 12, then (group, term, half) as above
-			const int pc = 3 * wave + (i - 1);
-			const int par = pc / 12, p = pc - 12 * par;
-			const char* wsrc = wgt + (size_t)((bd.slot >> 3) + (uint32_t)(p / 6)) * 12288 + (size_t)((p % 6) / 2) * 4096 +
-					   (size_t)par * 2048 + (size_t)(p % 2) * 1024 + (size_t)lane * 16;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
-							 (__attribute__((address_space(3))) void*)(size_t)(bd.st + 8192u + (uint32_t)pc * 1024u), 16, 0, 0);
-		}
-	};
-	// the same pieces in two steps: source address (per lane) now, the load later
+	// Pieces of a wave: 0 = two feature rows (entries 2 wave, 2 wave + 1: this chunk's 512 B of each; a 64-bit address per
+	// lane), then the weight pieces, then (NP - 1) the ids.  Weight pieces, pre-split hand-over: the batch is per group of 8
+	// entries [term][256 px'][8 x bf16] = 12 KB, a parity's half of a term = 2 KB = two 1-KB pieces, 24 per batch: pc = 3 wave
+	// + (i - 1) -> parity pc / 12, then (group, term, half).  COOP: fp32 rows of 1 KB per entry; the wave fetches exactly what
+	// it will split -- the 128 B [32 cg .. 32 cg + 31] px' of its parity for entries 8 (i - 1) + (lane >> 3), 16 B per lane.
+	// Weight and id pieces are "uniform base + 32-bit lane offset": dma_src returns the base, dma_voff the lane's offset; the
+	// SGPR-base form of the instruction moves half the address bytes.  (m0 = the LDS destination; the compiler sets m0 itself
+	// in front of its own LDS-DMA builtin, it keeps nothing in it.)
+	const uint32_t lane16 = COOP ? (uint32_t)(lane >> 3) * 1024u + (uint32_t)(lane & 7) * 16u : (uint32_t)lane * 16u;
 	auto dma_src = [&](auto I, const Bundle& bd) __attribute__((always_inline)) -> const char* {
 		constexpr int i = decltype(I)::value;
 		if constexpr (i == 0) {
 			const float* row = bd.id0 == SGS_BG_ID ? bg : features + (size_t)bd.id0 * C;
 			return (const char*)(row + cbase + l31 * 4);
-		} else if constexpr (i == 4) {
-			const uint32_t li = (uint32_t)(lane & 15) < bd.n2 ? (uint32_t)(lane & 15) : bd.n2 - 1u;
-			return (const char*)(act_id + bd.slot2 + li);
+		} else if constexpr (i == NP - 1) {
+			return (const char*)(act_id + bd.slot2);
+		} else if constexpr (COOP) {
+			return wgt + (size_t)(bd.slot + 8u * (uint32_t)(i - 1)) * 1024 + (size_t)g * 512 + (size_t)cg * 128;
 		} else {
 			const int pc = 3 * wave + (i - 1);
 			const int par = pc / 12, p = pc - 12 * par;
 			return wgt + (size_t)((bd.slot >> 3) + (uint32_t)(p / 6)) * 12288 + (size_t)((p % 6) / 2) * 4096 +
-			       (size_t)par * 2048 + (size_t)(p % 2) * 1024;   // (wave-uniform; the lane adds lane * 16)
+			       (size_t)par * 2048 + (size_t)(p % 2) * 1024;
 		}
 	};
-	// the load itself.  Piece 0 carries a 64-bit address per lane (two different rows per instruction); the weight and id
-	// pieces are "uniform base + 32-bit lane offset": the SGPR-base form of the instruction moves half the address bytes.
-	// (m0 = the LDS destination; the compiler sets m0 itself in front of its own LDS-DMA builtin, it keeps nothing in it.)
-	const uint32_t lane16 = (uint32_t)lane * 16u;
 	auto dma_go = [&](auto I, const char* src, uint32_t st, uint32_t voff) __attribute__((always_inline)) {
 		constexpr int i = decltype(I)::value;
 		if constexpr (i == 0)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
 							 (__attribute__((address_space(3))) void*)(size_t)(st + (uint32_t)(2 * wave) * 512u), 16, 0, 0);
 		else {
-			const uint32_t ldst = i == 4 ? st + my_ids : st + 8192u + (uint32_t)(3 * wave + (i - 1)) * 1024u;
-			if constexpr (i == 4)
+			const uint32_t ldst = i == NP - 1 ? st + my_ids
+						  : (COOP ? st + 8192u + (uint32_t)g * 8192u + (uint32_t)cg * 2048u + (uint32_t)(i - 1) * 1024u
+							  : st + 8192u + (uint32_t)(3 * wave + (i - 1)) * 1024u);
+			if constexpr (i == NP - 1)
 				asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(ldst), "v"(voff), "s"(src) : "memory", "m0");
 			else
 				asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(ldst), "v"(voff), "s"(src) : "memory", "m0");
 		}
 	};
+	auto id_voff = [&](const Bundle& bd) __attribute__((always_inline)) -> uint32_t {
+		return ((uint32_t)(lane & 15) < bd.n2 ? (uint32_t)(lane & 15) : bd.n2 - 1u) * 4u;
+	};
 	auto issue_all = [&](const Bundle& bd) __attribute__((always_inline)) {
-		dma_piece(std::integral_constant<int, 0>{}, bd);
-		dma_piece(std::integral_constant<int, 1>{}, bd);
-		dma_piece(std::integral_constant<int, 2>{}, bd);
-		dma_piece(std::integral_constant<int, 3>{}, bd);
-		dma_piece(std::integral_constant<int, 4>{}, bd);
+		dma_go(std::integral_constant<int, 0>{}, dma_src(std::integral_constant<int, 0>{}, bd), bd.st, 0u);
+		dma_go(std::integral_constant<int, 1>{}, dma_src(std::integral_constant<int, 1>{}, bd), bd.st, lane16);
+		dma_go(std::integral_constant<int, 2>{}, dma_src(std::integral_constant<int, 2>{}, bd), bd.st, lane16);
+		if constexpr (NP == 5) dma_go(std::integral_constant<int, 3>{}, dma_src(std::integral_constant<int, 3>{}, bd), bd.st, lane16);
+		dma_go(std::integral_constant<int, NP - 1>{}, dma_src(std::integral_constant<int, NP - 1>{}, bd), bd.st, id_voff(bd));
 	};
 
 	// the eight accumulator blocks a[0:127] (see acc_zero)
@@ -1298,10 +1295,13 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
 #pragma unroll
 	for (int k = 0; k < S3_LA; k++) {   // prologue bundles 0 .. LA-1 (their feature ids by ordinary loads)
-		const uint2 e = s_bt[k], e2 = s_bt[k + S3_LA];
-		const uint32_t n = e.y & 255u;
-		const uint32_t id0 = act_id[e.x + (sub < n ? sub : n - 1u)];
-		issue_all(Bundle{e.x, id0, e2.x, e2.y & 255u, ring + (uint32_t)k * S3_STAGE});
+		const uint2 ev = s_bt[k], e2v = s_bt[k + S3_LA];
+		// (table words are workgroup-uniform: say so, the weight / id pieces want their bases in SGPRs)
+		const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)ev.x), ey = (uint32_t)__builtin_amdgcn_readfirstlane((int)ev.y);
+		const uint32_t e2x = (uint32_t)__builtin_amdgcn_readfirstlane((int)e2v.x), e2y = (uint32_t)__builtin_amdgcn_readfirstlane((int)e2v.y);
+		const uint32_t n = ey & 255u;
+		const uint32_t id0 = act_id[ex + (sub < n ? sub : n - 1u)];
+		issue_all(Bundle{ex, id0, e2x, e2y & 255u, ring + (uint32_t)k * S3_STAGE});
 	}
 	uint32_t st0 = ring, stI = ring + S3_LA * S3_STAGE;   // stages of batch j and of bundle j + LA (= the stage of batch j - 1)
 	uint32_t j = 0;
@@ -1353,7 +1353,12 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		return poll_finish(st, wv, id0);
 	};
 	uint32_t nid = poll(ring);   // bundle 0: the ids of batch LA
-	__builtin_amdgcn_s_barrier();   // every wave's pieces of bundle 0 have landed
+	uint32_t nid1 = 0u;          // (COOP) the ids one batch further on: the arrival check runs a step earlier there
+	if constexpr (COOP) {
+		nid1 = poll(ring + S3_STAGE);   // bundle 1
+		if (!(DBG & 2)) s2_split_coop(ring + (uint32_t)g * 8192u, split_a, cg, half, l31);   // batch 0's weights -> split buffer 0
+	}
+	__builtin_amdgcn_s_barrier();   // every wave's pieces of bundle 0 have landed (COOP: and batch 0's split terms are complete)
 	if (g) {   // the second half runs one barrier behind the first
 		__builtin_amdgcn_s_setprio(1);
 		__builtin_amdgcn_s_barrier();
@@ -1427,8 +1432,8 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		if constexpr ((c_) == 0) dma_go(std::integral_constant<int, 0>{}, da0_, dst_, 0u);           \
 		if constexpr ((c_) == 1) dma_go(std::integral_constant<int, 1>{}, da1_, dst_, lane16);       \
 		if constexpr ((c_) == 2) dma_go(std::integral_constant<int, 2>{}, da2_, dst_, lane16);       \
-		if constexpr ((c_) == 3) dma_go(std::integral_constant<int, 3>{}, da3_, dst_, lane16);       \
-		if constexpr ((c_) == 4) dma_go(std::integral_constant<int, 4>{}, da4_, dst_, io4_);         \
+		if constexpr ((c_) == 3 && NP == 5) dma_go(std::integral_constant<int, 3>{}, da3_, dst_, lane16); \
+		if constexpr ((c_) == NP - 1) dma_go(std::integral_constant<int, NP - 1>{}, da4_, dst_, io4_); \
 		mfma_pair<bx_, by_>(A_.t[TA_[c_]][1], u32x2{x2_[TB_[c_]].z, x2_[TB_[c_]].w}, u32x2{y2_[TB_[c_]].z, y2_[TB_[c_]].w}); \
 	} while (0)
 #define S3_HALF2W(bx_, by_, c_)                                                                      \
@@ -1439,8 +1444,8 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		if constexpr ((c_) == 0) dma_go(std::integral_constant<int, 0>{}, da0_, dst_, 0u);           \
 		if constexpr ((c_) == 1) dma_go(std::integral_constant<int, 1>{}, da1_, dst_, lane16);       \
 		if constexpr ((c_) == 2) dma_go(std::integral_constant<int, 2>{}, da2_, dst_, lane16);       \
-		if constexpr ((c_) == 3) dma_go(std::integral_constant<int, 3>{}, da3_, dst_, lane16);       \
-		if constexpr ((c_) == 4) dma_go(std::integral_constant<int, 4>{}, da4_, dst_, io4_);         \
+		if constexpr ((c_) == 3 && NP == 5) dma_go(std::integral_constant<int, 3>{}, da3_, dst_, lane16); \
+		if constexpr ((c_) == NP - 1) dma_go(std::integral_constant<int, NP - 1>{}, da4_, dst_, io4_); \
 	} while (0)
 // One step = batch j into accumulator blocks b0_..b3_.  PREP: table words; operand reads of batch j go out first (stage j
 // landed before the barrier this phase began with); the DMA pieces of bundle j + LA and the deferred stores (DEF_) are
@@ -1455,23 +1460,27 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		   pairs, where only the m0 write and the load itself remain */                                \
 		const char* da0_ = dma_src(std::integral_constant<int, 0>{}, nb);   /* per lane: two feature rows */ \
 		const char* da1_ = dma_src(std::integral_constant<int, 1>{}, nb);   /* wave-uniform bases (SGPRs): */ \
-		const char* da2_ = dma_src(std::integral_constant<int, 2>{}, nb);   /* the lane offset is lane * 16 */ \
-		const char* da3_ = dma_src(std::integral_constant<int, 3>{}, nb);                             \
+		const char* da2_ = dma_src(std::integral_constant<int, 2>{}, nb);   /* the lane offset is lane16 */ \
+		const char* da3_ = dma_src(std::integral_constant<int, (NP == 5 ? 3 : 2)>{}, nb);             \
 		const char* da4_ = (const char*)(act_id + nb.slot2);                                          \
-		uint32_t io4_ = ((uint32_t)(lane & 15) < nb.n2 ? (uint32_t)(lane & 15) : nb.n2 - 1u) * 4u;   \
+		uint32_t io4_ = id_voff(nb);                                                                 \
 		const uint32_t dst_ = nb.st;                                                                 \
 		asm volatile("" : "+v"(da0_), "+s"(da1_), "+s"(da2_), "+s"(da3_), "+s"(da4_), "+v"(io4_));    \
 		float f_[8];                                                                                 \
 		u32x4 x_[3], y_[3], x2_[3], y2_[3];                                                          \
 		Op3 A_;                                                                                      \
-		const uint32_t stn_ = st0 + S3_STAGE == ring + S3_NST * S3_STAGE ? ring : st0 + S3_STAGE;     \
+		const uint32_t st1_ = st0 + S3_STAGE == ring + S3_NST * S3_STAGE ? ring : st0 + S3_STAGE;     \
+		const uint32_t st2_ = st1_ + S3_STAGE == ring + S3_NST * S3_STAGE ? ring : st1_ + S3_STAGE;   \
+		const uint32_t stn_ = COOP ? st2_ : st1_;   /* the stage whose arrival this step checks (COOP: one step earlier) */ \
 		uint32_t pw_ = 0u, pid_ = 0u;                                                                \
 		const uint32_t fa_ = st0 + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;                \
-		const uint32_t wa_ = st0 + 8192u + (uint32_t)g * 12288u + (uint32_t)half * 6144u + (uint32_t)l31 * 16u; \
+		const uint32_t wa_ = (COOP ? split_a + (j & 1u) * 12288u : st0 + 8192u + (uint32_t)g * 12288u) + (uint32_t)half * 6144u + (uint32_t)l31 * 16u; \
 		if (DBG & 2) issue_all(nb);                                                                  \
 		S3_STAMP(1);                                                                                 \
 		DEF_;   /* (before the operand reads: the transposes need registers the operands would occupy) */ \
 		S3_STAMP(2);                                                                                 \
+		if constexpr (COOP && !(DBG & 2))   /* batch j + 1's weights (this wave's own pieces, checked a step ago) -> the other split buffer */ \
+			s2_split_coop(st1_ + (uint32_t)g * 8192u, split_a + ((j + 1u) & 1u) * 12288u, cg, half, l31); \
 		if (!(DBG & 2)) {                                                                            \
 			S2_READ8(f_, fa_);                                                                       \
 			S3_RDB(x_, 0);                                                                           \
@@ -1491,7 +1500,8 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		S3_STAMP(3);                                                                                 \
 		if (g) {                                                                                     \
 			if (DBG & 2) poll_issue(stn_, pw_, pid_);                                                \
-			nid = poll_finish(stn_, pw_, pid_);                                                      \
+			const uint32_t got_ = poll_finish(stn_, pw_, pid_);                                      \
+			if constexpr (COOP) { nid = nid1; nid1 = got_; } else nid = got_;                         \
 		}                                                                                            \
 		S3_STAMP(4);                                                                                 \
 		__builtin_amdgcn_s_barrier();                                                                \
@@ -1515,7 +1525,10 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			}                                                                                        \
 		} else if (!g) poll_issue(stn_, pw_, pid_);                                                  \
 		S3_STAMP(6);                                                                                 \
-		if (!g) nid = poll_finish(stn_, pw_, pid_);                                                  \
+		if (!g) {                                                                                    \
+			const uint32_t got_ = poll_finish(stn_, pw_, pid_);                                      \
+			if constexpr (COOP) { nid = nid1; nid1 = got_; } else nid = got_;                         \
+		}                                                                                            \
 		S3_STAMP(7);                                                                                 \
 		__builtin_amdgcn_s_barrier();                                                                \
 		S3_STAMP(8);                                                                                 \
@@ -1607,7 +1620,7 @@ hipError_t launch_norm_plane_background(hipStream_t st, float* plane, size_t n, 
 hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
-			       const uint32_t* order, int dealt, int tune)
+			       const uint32_t* order, int dealt, int tune, bool coop)
 {
 #define S3_LAUNCH(D_)                                                                                \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
@@ -1628,6 +1641,18 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 #else
 	if (tune != 0) return hipErrorInvalidValue;   // (the x16 forms of this sweep are not in the product library)
 #endif
+	if (coop) {   // sweep nibble 5: fp32 weights handed over, split by the sweep one step ahead
+#define S3_LAUNCH_C(D_)                                                                              \
+	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 0, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
+			   pxcd, items, a.pitch, trace, order, dealt, tune)
+		if (dbg == 1) S3_LAUNCH_C(1);
+		else if (dbg == 2) S3_LAUNCH_C(2);
+		else if (dbg == 4) S3_LAUNCH_C(4);
+		else S3_LAUNCH_C(0);
+#undef S3_LAUNCH_C
+		return hipGetLastError();
+	}
 	if (dbg == 1) S3_LAUNCH(1);        // (development ablations) no stores
 	else if (dbg == 2) S3_LAUNCH(2);   // no matrix work
 	else if (dbg == 3) S3_LAUNCH(3);   // ring only

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_kernel(
 	uint32_t* __restrict__ act_id, uint32_t* __restrict__ act_idx, float* __restrict__ wgt,
 	uint32_t* __restrict__ table, uint32_t* __restrict__ nact, uint32_t* __restrict__ counter,
 	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles,
-	float4* __restrict__ clear_ptr, unsigned long long clear_n4)
+	float4* __restrict__ clear_ptr, unsigned long long clear_n4, const uint32_t* __restrict__ tile_order)
 {
 	static_assert(MODE == 3 || MODE == 4, "weights format");
 	const int b = blockIdx.x;
@@ -118,7 +118,10 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_kernel(
 	auto clear_rest = [&]() {
 		for (; ci < ci1; ci += 128) clear_ptr[ci] = make_float4(0.f, 0.f, 0.f, 0.f);
 	};
-	const int tile = (b & 7) * per_xcd + (b >> 3);
+	// (round 4) tiles longest-first by the work they had in the stream's previous frame when that order exists
+	// (BlendFwdArgs::tile_order, blend_fwd_split.hip), XCD bands otherwise
+	const int tile = (tile_order && tile_order[0] == (uint32_t)ntiles) ? (b < ntiles ? (int)tile_order[1 + b] : ntiles)
+										  : (b & 7) * per_xcd + (b >> 3);
 	if (tile >= ntiles || counter[1] == 2u) {   // padding workgroup / aborted frame (the lists do not exist)
 		clear_rest();
 		return;
@@ -364,17 +367,18 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_kernel(
 hipError_t launch_blend_weights2(hipStream_t st, int mode, const uint2* ranges, const uint32_t* point_list,
 				 const float2* means2D, const float4* conic_opacity, float* final_T, uint32_t* n_contrib,
 				 uint32_t* act_id, uint32_t* act_idx, float* wgt, uint32_t* table, uint32_t* nact, uint32_t* counter,
-				 uint32_t capacity, int W, int H, int gx, int ntiles, float* clear_ptr, size_t clear_floats)
+				 uint32_t capacity, int W, int H, int gx, int ntiles, float* clear_ptr, size_t clear_floats,
+				 const uint32_t* tile_order)
 {
 	const dim3 grid(((ntiles + 7) / 8) * 8);
 	if (mode == 4)
 		hipLaunchKernelGGL(blend_weights2_kernel<4>, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
 				   n_contrib, act_id, act_idx, wgt, table, nact, counter, capacity, W, H, gx, (ntiles + 7) / 8, ntiles,
-				   (float4*)clear_ptr, (unsigned long long)(clear_floats / 4));
+				   (float4*)clear_ptr, (unsigned long long)(clear_floats / 4), tile_order);
 	else
 		hipLaunchKernelGGL(blend_weights2_kernel<3>, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
 				   n_contrib, act_id, act_idx, wgt, table, nact, counter, capacity, W, H, gx, (ntiles + 7) / 8, ntiles,
-				   (float4*)clear_ptr, (unsigned long long)(clear_floats / 4));
+				   (float4*)clear_ptr, (unsigned long long)(clear_floats / 4), tile_order);
 	return hipGetLastError();
 }
 

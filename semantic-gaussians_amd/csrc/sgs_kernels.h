@@ -125,7 +125,8 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 hipError_t launch_blend_weights2(hipStream_t st, int mode, const uint2* ranges, const uint32_t* point_list,
 				 const float2* means2D, const float4* conic_opacity, float* final_T, uint32_t* n_contrib,
 				 uint32_t* act_id, uint32_t* act_idx, float* wgt, uint32_t* table, uint32_t* nact, uint32_t* counter,
-				 uint32_t capacity, int W, int H, int gx, int ntiles, float* clear_ptr, size_t clear_floats);
+				 uint32_t capacity, int W, int H, int gx, int ntiles, float* clear_ptr, size_t clear_floats,
+				 const uint32_t* tile_order = nullptr);
 
 // ---- blend_sweep2.hip: the accumulate sweep in fp32-class arithmetic (arith: 0 = exact fp32 MFMA, 1 = six bf16 products,
 // 2 = the same on the x16 MFMA), LDS-polled DMA arrival, stores spread over the next tile; takes fp32 weight rows
@@ -141,7 +142,7 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
-			       const uint32_t* order, int dealt, int tune);
+			       const uint32_t* order, int dealt, int tune, bool coop = false);
 
 // debug: 4 x uint64 per sweep workgroup (begin, end on the 100 MHz steady counter, HW_ID | XCC_ID << 32, batches | tiles << 32)
 void set_sweep_trace(void* device_words);

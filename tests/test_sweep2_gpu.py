@@ -168,6 +168,9 @@ def test_ping_pong_sweep_equals_round3_sweep_bitwise():
             a = _hip_forward(scene, cam, variant=0xE | (segn << 4))[1]
             b = _hip_forward(scene, cam, variant=0x6 | (segn << 4))[1]
             assert torch.equal(a, b), (P, C, W, H, segn)
+            # nibble 5 (experiment): fp32 weight rows handed over, split one step ahead inside the sweep
+            c = _hip_forward(scene, cam, variant=0x5 | (segn << 4))[1]
+            assert torch.equal(c, b), ("fp32 hand-over", P, C, W, H, segn)
         d = _hip_forward(scene, cam, variant=0)[1]      # the default: the same kernel with its own segment length
         assert torch.equal(d, _hip_forward(scene, cam, variant=0x6E)[1]), (P, C, W, H)
 
