@@ -67,6 +67,7 @@ constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;   // work-list id of the closing T *
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int MODE>
 __global__ __launch_bounds__(256) void blend_weights_kernel(
@@ -420,9 +421,287 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 	}
 }
 
+// Round 4: the same pre-pass with the list walked 256 entries at a time ("super-batch").  Why: at cfg3 a tile's list has
+// ~3 300 entries of which ~100 end up active; the kernel above pays three barriers, an LDS staging round trip and ~30
+// scalar instructions of loop control per 16 LIST entries, nearly all of them for batches in which the tile-level test
+// rejects everything (PMC, round 3: 85.7 M SALU beside 111 M VALU, 55 % of the wave-cycles waiting).  Here every thread
+// stages ONE list entry (gathers prefetched a super-batch ahead, the tile-level rejection evaluated 256 wide), the kept
+// entries are compacted in list order (ballot + a four-word wave prefix), and only THEY go through the weight phase, 16 at a
+// time as before: two barriers per 256 list entries plus one per 16 kept entries.  A group's 16 weights of a pixel never leave
+// the thread's registers (the thread that evaluated pixel p is the one that copies column p out; the kernel above parks them
+// in 16 KB of LDS), so between a group's weight phase and its copy-out only the activity mask crosses waves -- one barrier per
+// group, a mask word per group.
+// Arithmetic, order of the entries, work-list contents: identical to the kernel above (bit-identical frames).
+template <int MODE>
+__global__ __launch_bounds__(256) void blend_weights_sb_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+	const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
+	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+	uint32_t* __restrict__ act_id, uint32_t* __restrict__ act_idx, float* __restrict__ wgt,
+	uint32_t* __restrict__ table, uint32_t* __restrict__ nact, uint32_t* __restrict__ counter,
+	uint32_t capacity, int W, int H, int gx, int per_xcd, int ntiles, const uint32_t* __restrict__ tile_order)
+{
+	static_assert(MODE == 3 || MODE == 4, "weights format: 3 = fp32 rows, 4 = three bf16 terms");
+	constexpr bool BF = MODE == 4;
+	constexpr int GROUP_BYTES = 12288;
+	constexpr int SB = 256;   // list entries staged at a time (one per thread)
+	const int b = blockIdx.x;
+	int tile;
+	if (tile_order && tile_order[0] == (uint32_t)ntiles) {   // longest-first by the previous frame's work (see above)
+		if (b >= ntiles) return;
+		tile = (int)tile_order[1 + b];
+	} else {
+		tile = (b & 7) * per_xcd + (b >> 3);
+		if (tile >= ntiles) return;
+	}
+	if (counter[1] == 2u) return;   // aborted frame
+	const int tx = tile % gx, ty = tile / gx;
+	const int t = threadIdx.x, lane = t & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int px = tx * SGS_TILE + (lane & 15);
+	const int py = ty * SGS_TILE + wave * 4 + (lane >> 4);
+	const bool inside = px < W && py < H;
+	const int pxp_own = ((wave * 4 + (lane >> 4)) & 1) * 128 + ((wave * 4 + (lane >> 4)) >> 1) * 16 + (lane & 15);
+	const float pxf = (float)px, pyf = (float)py;
+	const uint2 range = ranges[tile];
+	const int n_total = (int)(range.y - range.x);
+	const uint32_t chunk_base = (range.x >> 7) + (uint32_t)tile;
+
+	__shared__ StagedEntryW s_e[SB];          // the super-batch's kept entries, list order
+	__shared__ uint32_t s_amask[SB / WB];     // per group: entries taken by at least one pixel
+	__shared__ int s_cnt[4], s_alive[4];
+	__shared__ uint32_t s_ovf;
+	__shared__ uint32_t s_chunk[64];
+	__shared__ float s_pend[BF ? 8 * 256 : 1];
+
+	auto chunk_start_of = [&](uint32_t ci) -> uint32_t { return ci < 64 ? s_chunk[ci] : table[chunk_base + ci]; };
+	auto flush_group = [&](uint32_t gi) {   // entries 8 gi .. 8 gi + 7 of the tile are complete in s_pend: split and store
+		const uint32_t g0 = gi * 8u;
+		const uint32_t slot = chunk_start_of(g0 / ACH) + (g0 % ACH);
+		uint32_t t1[4], t2[4], t3[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const float x0 = s_pend[(2 * k) * 256 + t], x1 = s_pend[(2 * k + 1) * 256 + t];
+			typedef float f32x2_ __attribute__((ext_vector_type(2)));
+			typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+			const f32x2_ v0 = {x0, x1};
+			t1[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2_));
+			const float r0 = x0 - __uint_as_float(t1[k] << 16), r1 = x1 - __uint_as_float(t1[k] & 0xffff0000u);
+			const f32x2_ v1 = {r0, r1};
+			t2[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2_));
+			const f32x2_ v2 = {r0 - __uint_as_float(t2[k] << 16), r1 - __uint_as_float(t2[k] & 0xffff0000u)};
+			t3[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_));
+		}
+		uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * GROUP_BYTES);
+		dst[pxp_own] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+		dst[256 + pxp_own] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+		dst[512 + pxp_own] = make_uint4(t3[0], t3[1], t3[2], t3[3]);
+	};
+	// one work-list entry (tile-uniform position g) from this thread's weight w
+	auto emit = [&](uint32_t g, float w) {
+		if (BF) {
+			s_pend[(g & 7u) * 256 + t] = w;
+			if ((g & 7u) == 7u) flush_group(g >> 3);
+		} else {
+			wgt[(size_t)(chunk_start_of(g / ACH) + (g % ACH)) * 256 + pxp_own] = w;
+		}
+	};
+	// thread 0: make sure the chunks for entries [0, upto) exist; returns false after an arena overflow
+	auto reserve = [&](uint32_t& nchunks, uint32_t upto) {
+		uint32_t nc = nchunks;
+		while (nc * ACH < upto && s_ovf == 0u) {
+			const uint32_t start = nc == 0 ? (uint32_t)tile * ACH : atomicAdd(&counter[0], (uint32_t)ACH);
+			if (start + ACH > capacity) {
+				atomicExch(&counter[1], 1u);
+				s_ovf = 1u;
+				break;
+			}
+			if (nc != 0) table[chunk_base + nc] = start;
+			if (nc < 64) s_chunk[nc] = start;
+			nc++;
+		}
+	};
+
+	float T = 1.0f;
+	uint32_t last = 0;
+	bool done = !inside;
+	uint32_t total = 0, nchunks = 0;   // (tile-uniform) active entries emitted, chunks reserved
+	if (t == 0) s_ovf = 0u;
+
+	// gathers run a super-batch ahead, the ids two
+	uint32_t pf_id = 0u, pf_id_next = 0u;
+	float2 pf_xy = make_float2(0.f, 0.f);
+	float4 pf_co = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (t < n_total) {
+		pf_id = point_list[range.x + t];
+		pf_xy = means2D[pf_id];
+		pf_co = conic_opacity[pf_id];
+	}
+	if (SB + t < n_total) pf_id_next = point_list[range.x + SB + t];
+	const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+	for (int base = 0; base < n_total; base += SB) {
+		const uint32_t id = pf_id;
+		const float2 xy = pf_xy;
+		const float4 co = pf_co;
+		if (base + SB + t < n_total) {
+			pf_id = pf_id_next;
+			pf_xy = means2D[pf_id];
+			pf_co = conic_opacity[pf_id];
+		}
+		if (base + 2 * SB + t < n_total) pf_id_next = point_list[range.x + base + 2 * SB + t];
+		StagedEntryW e;
+		bool keep = false;
+		if (base + t < n_total) {
+			e.a2 = -0.5f * co.x;
+			e.b2 = -co.y;
+			e.c2 = -0.5f * co.z;
+			e.o = co.w;
+			e.x = xy.x;
+			e.y = xy.y;
+			e.id = id;
+			e.idx1 = (uint32_t)(base + t + 1);
+			e.pad = 0u;
+			e.thr = __logf(1.0f / (255.0f * co.w)) - 0.01f;   // (the prefilter and the tile-level rejection: see the kernel above)
+			keep = true;
+			if (e.a2 < 0.f && e.c2 < 0.f && 4.f * e.a2 * e.c2 - e.b2 * e.b2 > 0.f) {
+				const float dxl = xy.x - (float)(tx * SGS_TILE + SGS_TILE - 1) - 0.01f;
+				const float dxh = xy.x - (float)(tx * SGS_TILE) + 0.01f;
+				const float dyl = xy.y - (float)(ty * SGS_TILE + SGS_TILE - 1) - 0.01f;
+				const float dyh = xy.y - (float)(ty * SGS_TILE) + 0.01f;
+				if (!(dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f)) {
+					float qmax = -__builtin_inff();
+#pragma unroll
+					for (int k = 0; k < 2; k++) {
+						const float ex = k ? dxh : dxl;
+						const float sy = fmin_(fmax_(-e.b2 * ex / (2.f * e.c2), dyl), dyh);
+						qmax = fmax_(qmax, e.a2 * ex * ex + e.b2 * ex * sy + e.c2 * sy * sy);
+						const float ey = k ? dyh : dyl;
+						const float sx = fmin_(fmax_(-e.b2 * ey / (2.f * e.a2), dxl), dxh);
+						qmax = fmax_(qmax, e.a2 * sx * sx + e.b2 * sx * ey + e.c2 * ey * ey);
+					}
+					keep = !(qmax < e.thr - 0.01f);
+				}
+			}
+		}
+		const unsigned long long km = __ballot(keep);
+		const bool wave_alive = __ballot(!done) != 0ull;
+		if (lane == 0) {
+			s_cnt[wave] = __popcll(km);
+			s_alive[wave] = wave_alive ? 1 : 0;
+		}
+		lds_barrier();   // B1 (also: the previous super-batch's copy-out has finished reading s_e / its mask words)
+		if (!(s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3])) break;
+		const int c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+		const int nkeep = c0 + c1 + c2 + c3;
+		const int off = wave == 0 ? 0 : (wave == 1 ? c0 : (wave == 2 ? c0 + c1 : c0 + c1 + c2));
+		if (keep) s_e[off + __popcll(km & below)] = e;
+		if (t < ((nkeep + 3) & ~3) - nkeep) {   // pad to a multiple of 4 with null entries
+			StagedEntryW z;
+			z.a2 = z.b2 = z.c2 = z.o = z.x = z.y = 0.f;
+			z.id = 0u;
+			z.idx1 = 0u;
+			z.pad = 0u;
+			z.thr = __builtin_inff();
+			s_e[nkeep + t] = z;
+		}
+		if (t < SB / WB) s_amask[t] = 0u;
+		lds_barrier();   // B2
+		for (int g0 = 0, gi = 0; g0 < nkeep; g0 += WB, gi++) {
+			const int ng = (nkeep - g0) < WB ? (nkeep - g0) : WB;
+			// ---- weight phase (as above): this thread's pixel against the group's entries; the 16 weights stay in registers
+			f32x16 wv;
+#pragma unroll
+			for (int j = 0; j < WB; j++) wv[j] = 0.0f;
+			if (__ballot(!done) != 0ull) {
+				uint32_t act = 0u;
+				const int n4 = (ng + 3) & ~3;
+#pragma unroll
+				for (int j0 = 0; j0 < WB; j0 += 4) {
+					if (j0 < n4) {   // (uniform)
+						float power[4], opac[4];
+						uint32_t idx1[4];
+						bool pre[4];
+#pragma unroll
+						for (int u = 0; u < 4; u++) {
+							const StagedEntryW se = s_e[g0 + j0 + u];
+							const float dx = se.x - pxf, dy = se.y - pyf;
+							power[u] = __builtin_fmaf(se.b2 * dx, dy, __builtin_fmaf(se.c2 * dy, dy, (se.a2 * dx) * dx));
+							opac[u] = se.o;
+							idx1[u] = se.idx1;
+							pre[u] = !(power[u] > 0.0f) && !(power[u] < se.thr);
+						}
+#pragma unroll
+						for (int u = 0; u < 4; u++) {
+							const bool cand0 = !done && pre[u];
+							if (__ballot(cand0) != 0ull) {
+								const float alpha = fmin_(0.99f, opac[u] * expf_contract(power[u]));
+								const float test_T = T * (1.0f - alpha);
+								const bool cand = cand0 && !(alpha < 1.0f / 255.0f);
+								const bool stop = cand && (test_T < 0.0001f);
+								const bool take = cand && !stop;
+								done = done || stop;
+								if (take) {
+									wv[j0 + u] = alpha * T;
+									T = test_T;
+									last = idx1[u];
+								}
+								if (__ballot(take) != 0ull) act |= 1u << (j0 + u);
+							}
+						}
+					}
+				}
+				if (lane == 0 && act != 0u) atomicOr(&s_amask[gi], act);
+			}
+			lds_barrier();   // B3: the group's mask is complete
+			const uint32_t amask = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_amask[gi]);
+			const uint32_t cnt = (uint32_t)__popc(amask);
+			if (nchunks * ACH < total + cnt) {   // (tile-uniform) the group crosses into a new chunk: about once per tile
+				if (t == 0) reserve(nchunks, total + cnt);
+				__syncthreads();
+				nchunks = (total + cnt + ACH - 1) / ACH;
+			}
+			if (s_ovf == 0u) {
+				uint32_t m = amask;
+				for (uint32_t r = 0; r < cnt; r++) {
+					const int en = __builtin_ctz(m);   // (uniform: the register array is indexed through the scalar unit)
+					m &= m - 1;
+					const uint32_t g = total + r;
+					emit(g, wv[en]);
+					if (t == 0) {
+						const uint32_t slot = chunk_start_of(g / ACH) + (g % ACH);
+						act_id[slot] = s_e[g0 + en].id;
+						if (act_idx) act_idx[slot] = s_e[g0 + en].idx1;
+					}
+				}
+			}
+			total += cnt;
+		}
+	}
+	// the closing T * bg pseudo entry (every tile gets one, also an empty tile)
+	__syncthreads();
+	if (t == 0 && nchunks * ACH < total + 1u) reserve(nchunks, total + 1u);
+	__syncthreads();
+	nchunks = (total + 1u + ACH - 1) / ACH;
+	if (s_ovf == 0u) {
+		emit(total, inside ? T : 0.0f);
+		if (t == 0) act_id[chunk_start_of(total / ACH) + (total % ACH)] = SGS_BG_ID;
+	}
+	total += 1u;
+	if (s_ovf == 0u) {   // zero-pad the last batch to 16 entries (all inside the tile's last chunk)
+		const uint32_t pad_end = (total + 15u) & ~15u;
+		for (uint32_t g = total; g < pad_end; g++) emit(g, 0.0f);
+	}
+	if (t == 0) nact[tile] = total;
+	if (inside) {
+		const size_t pix = (size_t)py * W + px;
+		final_T[pix] = T;
+		n_contrib[pix] = last;
+	}
+}
+
 constexpr int AB = 16;   // work-list entries per batch (divides ACH)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // -------------------------------------------------------------------------------------
 // Row-sweep accumulate (blend_accum_sweep_kernel).
@@ -1158,7 +1437,16 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// carries the trace hooks).
 		const bool flip = (split_mode & 0x4000) != 0;
 		const bool w_old = (presplit3 ? !flip : flip) || g_sweep_trace != nullptr;
-		if ((presplit3 || exact || sweep2) && !w_old) {
+		// round 4: the list walked 256 entries at a time (blend_weights_sb_kernel) for the three-term format (2-3 % faster than the
+		// 16-entry-batch kernel there; for fp32 rows blend_weights2.hip's two-pixels-per-lane kernel stays ahead, 0.19 vs 0.245 ms);
+		// bit 15 of the word restores the 16-entry-batch kernel for A/B runs (so does a sweep trace: the old kernel carries the hooks)
+		const bool w_sb = presplit3 && (split_mode & 0x8000) == 0 && g_sweep_trace == nullptr;
+		if (w_sb) {
+			const int pxw = (ntiles + 7) / 8;
+			hipLaunchKernelGGL(blend_weights_sb_kernel<4>, dim3(pxw * 8), dim3(256), 0, st, a.ranges, a.point_list, a.means2D,
+					   a.conic_opacity, a.final_T, a.n_contrib, act_id, (uint32_t*)nullptr, wgt, table, nbatches, counter,
+					   lay.capacity, a.W, a.H, a.gx, pxw, ntiles, (const uint32_t*)a.tile_order);
+		} else if ((presplit3 || exact || sweep2) && !w_old) {
 			const hipError_t ew = launch_blend_weights2(st, presplit3 ? 4 : 3, a.ranges, a.point_list, a.means2D, a.conic_opacity,
 								    a.final_T, a.n_contrib, act_id, nullptr, wgt, table, nbatches, counter,
 								    lay.capacity, a.W, a.H, a.gx, ntiles, nullptr, 0, a.tile_order);

@@ -175,6 +175,32 @@ def test_ping_pong_sweep_equals_round3_sweep_bitwise():
         assert torch.equal(d, _hip_forward(scene, cam, variant=0x6E)[1]), (P, C, W, H)
 
 
+def test_superbatch_weights_prepass_equals_batch16_bitwise():
+    """Round 4's weights pre-pass walks a tile's list 256 entries at a time (blend_weights_sb_kernel; bit 15 of the variant
+    word restores the 16-entry-batch kernels): same arithmetic, same entry order, same work list -- the feature map, the final
+    transmittance and the contributor counts are bit-identical.  Cases: lists shorter than one super-batch, lists of thousands
+    of entries with most of them rejected at tile level, more than 128 active entries per tile (the work list crosses chunk
+    boundaries), more than 16 kept per super-batch (several groups), a non-zero background."""
+    from sgs_hip import raster
+    cases = [(300, 128, 64, 48, 100.0, 2, 1.0, 1.0), (6000, 256, 400, 160, 300.0, 21, 1.0, 1.0),
+             (40000, 128, 784, 32, 600.0, 77, 3.0, 0.05), (60000, 128, 96, 64, 90.0, 5, 0.6, 0.08),
+             (20000, 128, 48, 48, 60.0, 9, 2.0, 0.02)]
+    for (P, C, W, H, fx, seed, sc, op) in cases:
+        scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=fx, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        scene = scene._replace(bg=torch.randn(C, generator=g), scales=scene.scales * sc, opacities=scene.opacities * op)
+        for _ in range(3):   # (let the stream's work-list arena grow to this scene: an overflowing frame takes the exact single-kernel path)
+            _hip_forward(scene, cam, variant=0x66)
+        for v in (0x66, 0x6E, 0x16):
+            new = _hip_forward(scene, cam, variant=v)
+            old = _hip_forward(scene, cam, variant=v | 0x8000)
+            assert new[0] == old[0]
+            assert torch.equal(new[1], old[1]), (P, C, W, H, hex(v))
+            a = raster.image_views(new[5], W, H)
+            b = raster.image_views(old[5], W, H)
+            assert torch.equal(a["n_contrib"], b["n_contrib"]) and torch.equal(a["final_T"], b["final_T"]), (P, C, W, H, hex(v))
+
+
 def test_x16_experiments_are_not_in_the_product_library():
     """DESIGN.md 5.10 / profiles/r04_x16_gemm_aggressor.txt: the double-rate-MFMA sweeps damage forwards running beside them
     on some boxes (a library GEMM beside the same victim does not): they are built only by `make X16=1`; the default library
