@@ -759,7 +759,10 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
 						 const_cast<float*>(a.final_T), const_cast<uint32_t*>(a.n_contrib),
 						 arena, lay, a.W, a.H, a.gx, a.gy, clear_dcolor_floats ? a.dL_dcolors : nullptr,
-						 clear_dcolor_floats);
+						 clear_dcolor_floats, a.tile_order);
+	// (The pre-pass takes its tiles longest-first by the forward's own work-list lengths, like the forward's.  The three
+	// kernels below do NOT: measured, that order costs them their locality -- neighbouring tiles share feature rows and
+	// colour-gradient rows in an XCD's L2 -- dcolor 1.10 -> 1.30 ms, dot 0.86 -> 1.07, profiles/r04_backward_tile_order.txt)
 	if (e != hipSuccess) return e;
 	const uint32_t* counter = (const uint32_t*)(arena + lay.counter);
 	const uint32_t* nact = (const uint32_t*)(arena + lay.nbatches);

@@ -1349,7 +1349,7 @@ __global__ void arena_reset_kernel(uint32_t* __restrict__ counter, const uint32_
 hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
 				     const float2* means2D, const float4* conic_opacity, float* final_T,
 				     uint32_t* n_contrib, char* arena, const SplitArena& lay, int W, int H, int gx,
-				     int gy, float* clear_ptr, size_t clear_floats)
+				     int gy, float* clear_ptr, size_t clear_floats, const uint32_t* tile_order)
 {
 	const int ntiles = gx * gy;
 	uint32_t* counter = (uint32_t*)(arena + lay.counter);
@@ -1360,7 +1360,7 @@ hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const 
 	return launch_blend_weights2(st, 3, ranges, point_list, means2D, conic_opacity, final_T, n_contrib,
 				     (uint32_t*)(arena + lay.act_id), (uint32_t*)(arena + lay.act_idx), (float*)(arena + lay.wgt),
 				     (uint32_t*)(arena + lay.table), (uint32_t*)(arena + lay.nbatches), counter, lay.capacity, W, H, gx,
-				     ntiles, clear_ptr, clear_floats);
+				     ntiles, clear_ptr, clear_floats, tile_order);
 }
 
 size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* lay, int slot_bytes)

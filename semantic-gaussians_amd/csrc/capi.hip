@@ -966,6 +966,10 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 	a.dL_dconic = dL_dconic;
 	a.dL_dopacity = dL_dopacity;
 	a.dL_dcolors = dL_dcolor;
+	{   // the order this stream's last forward left (normally the forward of this very frame): a schedule, never a result
+		static const bool no_tile_order = getenv("SGS_NO_TILE_ORDER") && atoi(getenv("SGS_NO_TILE_ORDER")) != 0;
+		a.tile_order = (!no_tile_order && cx->tile_order && cx->tile_order_cap >= (size_t)gx * gy) ? cx->tile_order : nullptr;
+	}
 	// SGS_OPT_BWD_CLEARS_DCOLOR: dL_dcolor arrives uninitialised; it is cleared by the work-list pre-pass where that
 	// path runs, by a memset otherwise
 	const size_t dcolor_floats = (size_t)P * (size_t)num_channels;

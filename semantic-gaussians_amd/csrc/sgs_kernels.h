@@ -157,7 +157,8 @@ hipError_t launch_blend_forward_fused_pc(hipStream_t st, const BlendFwdArgs& a, 
 hipError_t launch_blend_weights_rows(hipStream_t st, const uint2* ranges, const uint32_t* point_list,
 				     const float2* means2D, const float4* conic_opacity, float* final_T,
 				     uint32_t* n_contrib, char* arena, const SplitArena& lay, int W, int H, int gx,
-				     int gy, float* clear_ptr = nullptr, size_t clear_floats = 0);   // clear: optional buffer this kernel zero-fills (a multiple of 4 floats, 16-B aligned)
+				     int gy, float* clear_ptr = nullptr, size_t clear_floats = 0,   // clear: optional buffer this kernel zero-fills (a multiple of 4 floats, 16-B aligned)
+				     const uint32_t* tile_order = nullptr);
 
 // ---- blend_bwd.hip
 struct BlendBwdArgs {
@@ -176,6 +177,7 @@ struct BlendBwdArgs {
 	float* dL_dconic;            // (P,4)
 	float* dL_dopacity;          // (P)
 	float* dL_dcolors;           // (P,C)
+	const uint32_t* tile_order = nullptr;   // optional: [0] = tile count, [1..] = tiles longest-first (the stream's forward wrote it)
 };
 // `gate` (optional): device flag pair; the kernel runs only if gate[1] != 0 (fallback of the MFMA path).
 hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const uint32_t* gate = nullptr);
