@@ -311,7 +311,8 @@ int sgs_stream_release(void *stream);
  *  >= 16        = sweep tuning word: bits [3:0] accumulate kernel (6 = round 4's ping-pong sweep -- one 8-wave workgroup per
  *                 (segment, 128 channels) for both row parities, six products with pre-split weights: THE DEFAULT; 5 = the same
  *                 with fp32 weights handed over and split one step ahead inside the sweep (experiment, bit-identical,
- *                 slower: DESIGN.md 5.11); 8 =
+ *                 slower: DESIGN.md 5.11), 4 = the same without its barriers (the halves run free on per-stage counters:
+ *                 experiment, bit-identical, slower); 8 =
  *                 variant 14's, 9 = its fp32-MFMA form; blend_sweep2.hip: 10 six products with the weights split in the
  *                 sweep, 11 fp32 MFMA, 13 as 10 block by block, 14 round 3's sweep (two workgroups per CU; the same
  *                 arithmetic as 6, bit-identical), 7 as 14 with fp32 weights handed over and split once per workgroup into

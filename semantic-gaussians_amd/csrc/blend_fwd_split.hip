@@ -1416,9 +1416,10 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// fp32-input MFMA; blend_sweep2.hip: 10 = f32-equivalent (six bf16 products), 11 = exact fp32 MFMA, 14 = six products
 		// with pre-split weights (round 3's default), 12 / 15 = six products on the double-rate MFMA (make X16=1).
 		// (the norm-plane epilogue of N1 lives in round 3's kernel: same arithmetic, same hand-over format)
-		const int arith_nib = (((split_mode & 15) == 6 || (split_mode & 15) == 5) && a.norm_plane) ? 14 : (split_mode & 15);
+		const int arith_nib = (((split_mode & 15) == 6 || (split_mode & 15) == 5 || (split_mode & 15) == 4) && a.norm_plane) ? 14 : (split_mode & 15);
 		const bool sweep3c = arith_nib == 5;   // ping-pong sweep, fp32 weights handed over and split by the sweep (one step ahead)
-		const bool sweep3 = arith_nib == 6 || sweep3c;
+		const bool sweep3f = arith_nib == 4;   // ping-pong sweep without the barriers: the halves run free, flags per ring stage (experiment)
+		const bool sweep3 = arith_nib == 6 || sweep3c || sweep3f;
 		// a ping-pong workgroup covers both parities and there is one per CU: half as many, twice as large work items
 		const int wg_per_item = sweep3 ? 1 : 2, wg_target = sweep3 ? 768 : 1536;
 		int seg = ((split_mode >> 4) & 15) ? ((split_mode >> 4) & 15) * 8 : 48;
@@ -1476,7 +1477,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
 		if (sweep3) {
 			const hipError_t e3 = launch_accum_sweep3(st, (split_mode >> 8) & 15, a, table, nbatches, act_id, (const char*)wgt, counter,
-								  nc, seg, nseg, pxcd, items, g_sweep_trace, order_arg, dealt, (split_mode >> 16) & 15, sweep3c);
+								  nc, seg, nseg, pxcd, items, g_sweep_trace, order_arg, dealt, (split_mode >> 16) & 15, sweep3c ? 1 : (sweep3f ? 2 : 0));
 			if (e3 != hipSuccess) return e3;
 		} else if (sweep2) {
 			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 7 ? 6 : arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : (arith_nib == 15 ? 5 : 1)))), a.norm_plane ? 32 : ((split_mode >> 8) & 15), a, table,

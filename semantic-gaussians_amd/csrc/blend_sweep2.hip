@@ -1137,7 +1137,12 @@ constexpr int S3_STAGE_OF(bool coop) { return 8192 + 2 * S3_WB(coop) + 8 * 256; 
 
 // MM (make X16=1 only): 0 = the six products on v_mfma_f32_32x32x8_bf16 (the product); 1 = on the double-rate x16 MFMA, dense
 // statements; 2 / 3 = x16 with one filler (s_nop 0 / a VALU move) between consecutive MFMAs -- the round-4 bisect of DESIGN.md 5.10
-template <int DBG, int MM = 0, bool COOP = false>
+// FREE (sweep nibble 4, experiment): the same kernel WITHOUT the two barriers per step -- the halves run free of each other, bounded
+// only by the data: a wave reads batch j when all eight waves' pieces of bundle j have landed (an arrival counter per ring stage,
+// bumped by every wave when its own pieces are in), and refills a stage when all eight waves have read the batch it held (a
+// consumption counter per stage).  Why: in lock step a half that is draining a tile pair's store burst keeps its partner at the
+// barrier (15-20 % of the step); free-running, the partner works on until the ring stops it.
+template <int DBG, int MM = 0, bool COOP = false, bool FREE = false>
 __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -1184,8 +1189,10 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	constexpr int JMAX = COOP ? 768 : S2_JMAX;   // (COOP: 163 KB of ring + split buffers + a 1024-batch window would not fit 160 KB)
 	__shared__ uint2 s_bt[JMAX];   // .x = first arena slot of the batch, .y = entries | tile in segment << 8 | last of tile << 16
 	__shared__ uint32_t s_tot[S2_SEGMAX], s_cb[S2_SEGMAX], s_pref[S2_SEGMAX + 1];
+	__shared__ uint32_t s_flag[8];   // (FREE) [0..3] waves whose pieces of the stage's bundle have landed, [4..7] waves that have read the stage's batch (both cumulative)
 
 	// ---- prologue: the segment's batches as one flat table (ordinary accesses: nothing is in flight yet)
+	if (FREE && threadIdx.x < 8) s_flag[threadIdx.x] = 0u;
 	if ((int)threadIdx.x < nt) {
 		const int tile = ty * gx + tx0 + threadIdx.x;
 		s_tot[threadIdx.x] = nact[tile];   // >= 1: every tile ends with the T * bg pseudo entry
@@ -1352,16 +1359,47 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		poll_issue(st, wv, id0);
 		return poll_finish(st, wv, id0);
 	};
+	const uint32_t flag_a = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_flag;
+	// (FREE) wait until the counter at LDS address a has reached `target` (wave-uniform; bounded: a protocol error must not hang the device)
+	auto flag_wait = [&](uint32_t a, uint32_t target) __attribute__((always_inline)) {
+		uint32_t v;
+		int spins = 0;
+		for (;;) {
+			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+			if ((uint32_t)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+			if (++spins > (1 << 22)) __builtin_trap();
+			__builtin_amdgcn_s_sleep(1);
+		}
+	};
+	// the same in two parts: the read goes out early (flag_peek), the check (flag_check) finds it landed -- only a counter that is
+	// still short costs a poll loop
+	auto flag_peek = [&](uint32_t a, uint32_t& v) __attribute__((always_inline)) {
+		asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a) : "memory");
+	};
+	auto flag_check = [&](uint32_t a, uint32_t v, uint32_t target) __attribute__((always_inline)) {
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
+		if ((uint32_t)__builtin_amdgcn_readfirstlane((int)v) < target) flag_wait(a, target);
+	};
+	// (FREE) this wave bumps the counter: the LDS unit executes a wave's instructions in order, so everything the wave read
+	// from / saw in LDS before is behind it
+	auto flag_add = [&](uint32_t a) __attribute__((always_inline)) {
+		if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(a), "v"(1u) : "memory");
+	};
 	uint32_t nid = poll(ring);   // bundle 0: the ids of batch LA
+	if constexpr (FREE) flag_add(flag_a);   // (this wave's pieces of bundle 0 are in)
 	uint32_t nid1 = 0u;          // (COOP) the ids one batch further on: the arrival check runs a step earlier there
 	if constexpr (COOP) {
 		nid1 = poll(ring + S3_STAGE);   // bundle 1
 		if (!(DBG & 2)) s2_split_coop(ring + (uint32_t)g * 8192u, split_a, cg, half, l31);   // batch 0's weights -> split buffer 0
 	}
-	__builtin_amdgcn_s_barrier();   // every wave's pieces of bundle 0 have landed (COOP: and batch 0's split terms are complete)
-	if (g) {   // the second half runs one barrier behind the first
+	if constexpr (!FREE) {
+		__builtin_amdgcn_s_barrier();   // every wave's pieces of bundle 0 have landed (COOP: and batch 0's split terms are complete)
+		if (g) {   // the second half runs one barrier behind the first
+			__builtin_amdgcn_s_setprio(1);
+			__builtin_amdgcn_s_barrier();
+		}
+	} else if (g) {
 		__builtin_amdgcn_s_setprio(1);
-		__builtin_amdgcn_s_barrier();
 	}
 
 	// store addressing of the pair whose blocks 2, 3 are still to be written (deferred), and how far that is
@@ -1454,6 +1492,8 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 #define S3_STEP(b0_, b1_, b2_, b3_, DEF_)                                                            \
 	do {                                                                                             \
 		S3_STAMP(9);                                                                                 \
+		uint32_t fa_v_ = 0u, fc_v_ = 0u;                                                             \
+		if constexpr (FREE) flag_peek(flag_a + (j & 3u) * 4u, fa_v_);   /* (rides with the table words) */ \
 		e_ = step_head();                                                                            \
 		S3_STAMP(0);                                                                                 \
 		/* the source addresses of this wave's five DMA pieces: computed HERE (64-bit VALU chains), issued between the MFMA  \
@@ -1475,10 +1515,11 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		uint32_t pw_ = 0u, pid_ = 0u;                                                                \
 		const uint32_t fa_ = st0 + (uint32_t)((8 * half) * 128 + cg * 32 + l31) * 4u;                \
 		const uint32_t wa_ = (COOP ? split_a + (j & 1u) * 12288u : st0 + 8192u + (uint32_t)g * 12288u) + (uint32_t)half * 6144u + (uint32_t)l31 * 16u; \
-		if (DBG & 2) issue_all(nb);                                                                  \
+		if (DBG & 2) { if constexpr (FREE) flag_wait(flag_a + 16u + ((j + 3u) & 3u) * 4u, 8u * ((j + 3u) >> 2)); issue_all(nb); } \
 		S3_STAMP(1);                                                                                 \
 		DEF_;   /* (before the operand reads: the transposes need registers the operands would occupy) */ \
 		S3_STAMP(2);                                                                                 \
+		if constexpr (FREE) flag_check(flag_a + (j & 3u) * 4u, fa_v_, 8u * ((j >> 2) + 1u));   /* every wave's pieces of bundle j are in */ \
 		if constexpr (COOP && !(DBG & 2))   /* batch j + 1's weights (this wave's own pieces, checked a step ago) -> the other split buffer */ \
 			s2_split_coop(st1_ + (uint32_t)g * 8192u, split_a + ((j + 1u) & 1u) * 12288u, cg, half, l31); \
 		if (!(DBG & 2)) {                                                                            \
@@ -1492,26 +1533,30 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			split8(f_, A_);                                                                          \
 			S3_RDB(x2_, 2);                                                                          \
 			S3_RDB(y2_, 3);                                                                          \
-			if (g) poll_issue(stn_, pw_, pid_);   /* (second half) the arrival check's reads ride along */ \
+			if (g && !FREE) poll_issue(stn_, pw_, pid_);   /* (second half) the arrival check's reads ride along */ \
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x_[0]), "+v"(x_[1]), "+v"(x_[2]), "+v"(y_[0]), "+v"(y_[1]), "+v"(y_[2]), \
 				     "+v"(x2_[0]), "+v"(x2_[1]), "+v"(x2_[2]), "+v"(y2_[0]), "+v"(y2_[1]), "+v"(y2_[2]) : : "memory"); \
 			__builtin_amdgcn_sched_barrier(0);                                                       \
 		}                                                                                            \
+		if constexpr (FREE) flag_add(flag_a + 16u + (j & 3u) * 4u);   /* this wave has read batch j out of its stage */ \
 		S3_STAMP(3);                                                                                 \
-		if (g) {                                                                                     \
+		if (g && !FREE) {                                                                            \
 			if (DBG & 2) poll_issue(stn_, pw_, pid_);                                                \
 			const uint32_t got_ = poll_finish(stn_, pw_, pid_);                                      \
 			if constexpr (COOP) { nid = nid1; nid1 = got_; } else nid = got_;                         \
 		}                                                                                            \
 		S3_STAMP(4);                                                                                 \
-		__builtin_amdgcn_s_barrier();                                                                \
+		if constexpr (!FREE) __builtin_amdgcn_s_barrier();                                           \
 		S3_STAMP(5);                                                                                 \
 		if (!(DBG & 2)) {                                                                            \
 			if constexpr (MM == 0) {                                                                 \
+				if constexpr (FREE) flag_peek(flag_a + 16u + ((j + 3u) & 3u) * 4u, fc_v_);            \
 				mfma_dense<b0_, b1_>(A_, x_, y_);                                                    \
+				/* (FREE) the stage bundle j + LA goes into held batch j - 1: every wave must have read it */ \
+				if constexpr (FREE) flag_check(flag_a + 16u + ((j + 3u) & 3u) * 4u, fc_v_, 8u * ((j + 3u) >> 2)); \
 				S3_HALF2(b2_, b3_, 0); S3_HALF2(b2_, b3_, 1); S3_HALF2(b2_, b3_, 2);                 \
 				S3_HALF2(b2_, b3_, 3); S3_HALF2(b2_, b3_, 4);                                        \
-				if (!g) poll_issue(stn_, pw_, pid_);   /* (first half) under the last four MFMAs */   \
+				if (!g || FREE) poll_issue(stn_, pw_, pid_);   /* (first half) under the last four MFMAs */ \
 				S3_HALF2(b2_, b3_, 5);                                                               \
 			} else {   /* (make X16=1) the double-rate forms */                                     \
 				u32x4 aw_[3];                                                                        \
@@ -1523,14 +1568,15 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 				if (!g) poll_issue(stn_, pw_, pid_);                                                 \
 				S3_HALF2W(b2_, b3_, 5);                                                              \
 			}                                                                                        \
-		} else if (!g) poll_issue(stn_, pw_, pid_);                                                  \
+		} else if (!g || FREE) poll_issue(stn_, pw_, pid_);                                          \
 		S3_STAMP(6);                                                                                 \
-		if (!g) {                                                                                    \
+		if (!g || FREE) {                                                                            \
 			const uint32_t got_ = poll_finish(stn_, pw_, pid_);                                      \
 			if constexpr (COOP) { nid = nid1; nid1 = got_; } else nid = got_;                         \
+			if constexpr (FREE) flag_add(flag_a + ((j + 1u) & 3u) * 4u);   /* this wave's pieces of bundle j + 1 are in */ \
 		}                                                                                            \
 		S3_STAMP(7);                                                                                 \
-		__builtin_amdgcn_s_barrier();                                                                \
+		if constexpr (!FREE) __builtin_amdgcn_s_barrier();                                           \
 		S3_STAMP(8);                                                                                 \
 		step_tail();                                                                                 \
 	} while (0)
@@ -1576,7 +1622,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		S2_PAIR_DONE(1, tx);
 		if (j >= J) { while (dprog < 4) S2_DEFERRED_CHUNK(1); break; }
 	}
-	if (!g) __builtin_amdgcn_s_barrier();   // (the first half's counterpart of the second half's extra barrier)
+	if (!g && !FREE) __builtin_amdgcn_s_barrier();   // (the first half's counterpart of the second half's extra barrier)
 	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the dummy tail bundles before LDS is released
 	if (trace && threadIdx.x == 0) {
 		trace[4 * (size_t)b] = t_begin;
@@ -1620,8 +1666,9 @@ hipError_t launch_norm_plane_background(hipStream_t st, float* plane, size_t n, 
 hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
-			       const uint32_t* order, int dealt, int tune, bool coop)
+			       const uint32_t* order, int dealt, int tune, int form)
 {
+	const bool coop = form == 1;   // (form: 0 = lock step, 1 = fp32 hand-over, 2 = free-running halves)
 #define S3_LAUNCH(D_)                                                                                \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
@@ -1651,6 +1698,18 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 		else if (dbg == 4) S3_LAUNCH_C(4);
 		else S3_LAUNCH_C(0);
 #undef S3_LAUNCH_C
+		return hipGetLastError();
+	}
+	if (form == 2) {   // sweep nibble 4: free-running halves (flags instead of barriers)
+#define S3_LAUNCH_F(D_)                                                                              \
+	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 0, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
+			   pxcd, items, a.pitch, trace, order, dealt, tune)
+		if (dbg == 1) S3_LAUNCH_F(1);
+		else if (dbg == 2) S3_LAUNCH_F(2);
+		else if (dbg == 4) S3_LAUNCH_F(4);
+		else S3_LAUNCH_F(0);
+#undef S3_LAUNCH_F
 		return hipGetLastError();
 	}
 	if (dbg == 1) S3_LAUNCH(1);        // (development ablations) no stores

@@ -171,6 +171,9 @@ def test_ping_pong_sweep_equals_round3_sweep_bitwise():
             # nibble 5 (experiment): fp32 weight rows handed over, split one step ahead inside the sweep
             c = _hip_forward(scene, cam, variant=0x5 | (segn << 4))[1]
             assert torch.equal(c, b), ("fp32 hand-over", P, C, W, H, segn)
+            # nibble 4 (experiment): no barriers, the halves run free on per-stage arrival / consumption counters
+            f = _hip_forward(scene, cam, variant=0x4 | (segn << 4))[1]
+            assert torch.equal(f, b), ("free-running halves", P, C, W, H, segn)
         d = _hip_forward(scene, cam, variant=0)[1]      # the default: the same kernel with its own segment length
         assert torch.equal(d, _hip_forward(scene, cam, variant=0x6E)[1]), (P, C, W, H)
 
