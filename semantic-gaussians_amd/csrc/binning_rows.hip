@@ -358,6 +358,62 @@ __global__ __launch_bounds__(1024) void list_scan_kernel(int n, const uint32_t* 
 	if (!RANGES && threadIdx.x == 1023) starts[n] = s_part[1023];
 }
 
+// Stage A's two single-workgroup steps in one launch (round 4): the exclusive scan of the nb bin lengths (they are stage B's
+// segment starts; list_scan_kernel<false>) and stage B's chunk / group tables (seg_tables_kernel).  nb <= 2048 (the row
+// builder's own limit).  (The per-bin prefix over the scan groups stays a kernel of its own: 81 bins x 488 groups want more
+// than one workgroup -- folded in here it took 78 us instead of 9.)
+__global__ __launch_bounds__(1024) void stage_a_lists_kernel(int nb, const uint32_t* __restrict__ binlen, uint32_t* __restrict__ segB,
+							      uint32_t* __restrict__ chunk0B, uint32_t* __restrict__ grp0B,
+							      const uint32_t* __restrict__ abort)
+{
+	if (abort && *abort != 0u) return;
+	__shared__ uint32_t s_len[2048 + 1];
+	for (int b = threadIdx.x; b < nb; b += 1024) s_len[b] = binlen[b];
+	__syncthreads();
+	// exclusive scan of the nb lengths: thread t owns bins 2 t, 2 t + 1
+	__shared__ uint32_t s_part[1024];
+	const int b0 = 2 * (int)threadIdx.x;
+	const uint32_t v0 = b0 < nb ? s_len[b0] : 0u, v1 = b0 + 1 < nb ? s_len[b0 + 1] : 0u;
+	s_part[threadIdx.x] = v0 + v1;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) {
+		const uint32_t a = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+		__syncthreads();
+		s_part[threadIdx.x] += a;
+		__syncthreads();
+	}
+	const uint32_t start = s_part[threadIdx.x] - (v0 + v1);
+	if (b0 < nb) segB[b0] = start;
+	if (b0 + 1 < nb) segB[b0 + 1] = start + v0;
+	if (threadIdx.x == 1023) segB[nb] = s_part[1023];
+	// stage B's tables: the same scan over (chunks << 32 | scan groups) of each segment
+	__shared__ unsigned long long s_cg[1024];
+	const uint32_t nc0 = (v0 + RCH - 1) / RCH, nc1 = (v1 + RCH - 1) / RCH;
+	const unsigned long long cg0 = ((unsigned long long)nc0 << 32) | (unsigned long long)((nc0 + RGRP - 1) / RGRP);
+	const unsigned long long cg1 = ((unsigned long long)nc1 << 32) | (unsigned long long)((nc1 + RGRP - 1) / RGRP);
+	s_cg[threadIdx.x] = cg0 + cg1;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) {
+		const unsigned long long a = (int)threadIdx.x >= off ? s_cg[threadIdx.x - off] : 0ull;
+		__syncthreads();
+		s_cg[threadIdx.x] += a;
+		__syncthreads();
+	}
+	const unsigned long long cgs = s_cg[threadIdx.x] - (cg0 + cg1);
+	if (b0 < nb) {
+		chunk0B[b0] = (uint32_t)(cgs >> 32);
+		grp0B[b0] = (uint32_t)cgs;
+	}
+	if (b0 + 1 < nb) {
+		chunk0B[b0 + 1] = (uint32_t)((cgs + cg0) >> 32);
+		grp0B[b0 + 1] = (uint32_t)(cgs + cg0);
+	}
+	if (threadIdx.x == 1023) {   // (bins beyond nb contribute nothing: the last partial is the total)
+		chunk0B[nb] = (uint32_t)(s_cg[1023] >> 32);
+		grp0B[nb] = (uint32_t)s_cg[1023];
+	}
+}
+
 // the ballot sweep: every covering item is written to its final position in the list of
 // (segment, bin).  OUT_ITEMS: stage A (the item with its payload span); else the Gaussian id.
 template <bool FROM_RANKS, int SCAT_NW>
@@ -473,6 +529,13 @@ __global__ __launch_bounds__(64 * SCAT_NW) void span_scatter_kernel(
 	}
 }
 
+void row_binning_stage_a_counts(int P, uint32_t* chunks, uint32_t* groups)
+{
+	const uint32_t chA = ((uint32_t)P + RCH - 1) / RCH;
+	*chunks = chA;
+	*groups = (chA + RGRP - 1) / RGRP;
+}
+
 // sizes of the builder's scratch in 32-bit words.  R = major instances (stage A output)
 void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, size_t* cmat_words,
 			 size_t* gtot_words, size_t* len_words)
@@ -489,7 +552,7 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
 			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort,
-			      uint32_t* arena_counter, uint32_t arena_first_free)
+			      uint32_t* arena_counter, uint32_t arena_first_free, const uint32_t* stage_a_tab)
 {
 	const int ntiles = gx * gy;
 	if (R == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st);
@@ -499,7 +562,8 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	uint32_t* segB = tabs;                    // nbA + 1 (+1 spare)
 	uint32_t* chunk0B = tabs + (nbA + 2);
 	uint32_t* grp0B = tabs + 2 * (nbA + 2);
-	uint32_t* segA = tabs + 3 * (nbA + 2);
+	// stage A's tables: written by the depth sort's last pass when the caller asked for it (stage_a_tab), else by a table kernel here
+	uint32_t* segA = stage_a_tab ? const_cast<uint32_t*>(stage_a_tab) : tabs + 3 * (nbA + 2);
 	uint32_t* chunk0A = segA + 2;
 	uint32_t* grp0A = segA + 4;
 	uint32_t* binlen = lens + ntiles;         // stage A list lengths
@@ -518,7 +582,7 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	const size_t ldsSA = nwA * ldsWA, ldsSB = nwB * ldsWB;
 
 	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
-	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
+	if (!stage_a_tab) hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
 	if (nbA <= HG_NB_MAX) {
 		hipLaunchKernelGGL(span_hist_group_kernel<true>, dim3(grA), dim3(512), (size_t)RGRP * (nbA + 1) * 4, st, nbA, 1,
 				   segA, chunk0A, (const uint2*)nullptr, rrec, cmat, grp0A, gtot, desc, abort);
@@ -530,8 +594,8 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	}
 	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
 			   binlen, abort);
-	hipLaunchKernelGGL(list_scan_kernel<false>, dim3(1), dim3(1024), 0, st, nbA, binlen, (uint2*)nullptr, segB, abort, 1, 1, 1,
-			   (uint32_t*)nullptr, 0u);
+	// (the bin lengths' scan = stage B's segment starts, and stage B's chunk / group tables: one launch)
+	hipLaunchKernelGGL(stage_a_lists_kernel, dim3(1), dim3(1024), 0, st, nbA, binlen, segB, chunk0B, grp0B, abort);
 #define SGS_SCATTER_A(NW_)                                                                                          \
 	hipLaunchKernelGGL((span_scatter_kernel<true, NW_>), dim3((chA + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)),  \
 			   dim3(64 * NW_), ldsSA, st, nbA, 1, segA, chunk0A, grp0A, (const uint2*)nullptr, rrec,    \
@@ -544,7 +608,6 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	// ---- stage B: the major instances of each major bin -> per-tile lists
 	const uint32_t chB = R / RCH + (uint32_t)nbA, grB = chB / RGRP + (uint32_t)nbA;   // upper bounds
 	const int seg_stride = major_x ? 1 : gx, bin_stride = major_x ? gx : 1;          // tile = y * gx + x
-	hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, nbA, R, segB, false, chunk0B, grp0B, abort);
 	if (nbB <= HG_NB_MAX) {
 		hipLaunchKernelGGL(span_hist_group_kernel<false>, dim3(grB), dim3(512), (size_t)RGRP * (nbB + 1) * 4, st, nbB, nbA,
 				   segB, chunk0B, items, rrec, cmat, grp0B, gtot, desc, abort);

@@ -621,7 +621,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
 	if (presort) {
 		sgs::DepthSortSpanOut span{radii, means2D, gx, gy, gx >= gy, (uint64_t*)(gchunk + gl.counts64),
-					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.trap_flag + 64)};
+					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.trap_flag + 64),
+					   (uint32_t*)(gchunk + gl.trap_flag + 80), 0u, 0u};   // (+80: six spare words of the trap block)
+		sgs::row_binning_stage_a_counts(P, &span.stage_a_chunks, &span.stage_a_groups);
 		e = sgs::launch_depth_sort(st, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm, rows ? &span : nullptr);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
 		if (rows) {
@@ -767,7 +769,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
 					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list,
 					    abort_word, use_split ? (uint32_t*)(bchunk + bl.arena + bl.arena_lay.counter) : nullptr,
-					    (uint32_t)ntiles * 128u);
+					    (uint32_t)ntiles * 128u, (const uint32_t*)(gchunk + gl.trap_flag + 80));
 		counter_reset_done = use_split && Rrows != 0;   // (launch_row_binning with R == 0 is just a memset)
 		if (e != hipSuccess) return fail_hip(e, "row binning");
 		SGS_CHECK_STAGE("row binning");

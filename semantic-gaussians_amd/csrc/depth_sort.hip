@@ -184,6 +184,14 @@ __global__ __launch_bounds__(256) void depth_sort_pass_kernel(
 			}
 		}
 	}
+	if (SPAN && so.stage_a_tab && k == 0 && t == 0) {   // stage A's one-segment tables (binning_rows.hip seg_tables_kernel, single)
+		so.stage_a_tab[0] = 0u;
+		so.stage_a_tab[1] = (uint32_t)P;
+		so.stage_a_tab[2] = 0u;
+		so.stage_a_tab[3] = so.stage_a_chunks;
+		so.stage_a_tab[4] = 0u;
+		so.stage_a_tab[5] = so.stage_a_groups;
+	}
 	if (SPAN) {   // only the TOTAL of counts64 is ever needed (num_rendered and the major-instance count): one atomic
 		// per workgroup instead of a scan of the array
 #pragma unroll

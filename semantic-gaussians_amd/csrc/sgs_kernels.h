@@ -34,6 +34,10 @@ struct DepthSortSpanOut {   // optional by-product of the last pass: what binnin
 	uint64_t* counts64;
 	uint4* rrec;
 	unsigned long long* total;   // += sum(counts64); zero before the sort
+	// stage A's one-segment tables for binning_rows.hip (segstart[2] | chunk0[2] | grp0[2]): six words the last pass's first
+	// workgroup writes, so that the span partitions start without a table kernel of their own (nullptr: not wanted)
+	uint32_t* stage_a_tab;
+	uint32_t stage_a_chunks, stage_a_groups;
 };
 void depth_sort_layout(int P, DepthSortLayout* lay);
 hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, char* scratch,
@@ -66,7 +70,10 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 // actual counts from device tables); abort: optional device word, != 0 -> every kernel exits
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
 			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort = nullptr,
-			      uint32_t* arena_counter = nullptr, uint32_t arena_first_free = 0);   // optional: also reset the split blend's counter
+			      uint32_t* arena_counter = nullptr, uint32_t arena_first_free = 0,
+			      const uint32_t* stage_a_tab = nullptr);   // stage_a_tab: DepthSortSpanOut::stage_a_tab, already written (else a table kernel runs)
+// chunks / scan groups of stage A (the P ranked Gaussians as one segment): what DepthSortSpanOut::stage_a_chunks / _groups must hold
+void row_binning_stage_a_counts(int P, uint32_t* chunks, uint32_t* groups);   // optional: also reset the split blend's counter
 void launch_reconstruct_keys_ranges(hipStream_t st, int ntiles, const uint2* ranges, const uint32_t* point_list,
 				    const float* depths, uint64_t* keys_sorted);
 size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit);
