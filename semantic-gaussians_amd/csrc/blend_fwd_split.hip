@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 				t3[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_));
 			}
 			uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * GROUP_BYTES);
-			dst[pxp_own] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
-			dst[256 + pxp_own] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
-			dst[512 + pxp_own] = make_uint4(t3[0], t3[1], t3[2], t3[3]);
+			store_nt(&dst[pxp_own], make_uint4(t1[0], t1[1], t1[2], t1[3]));
+			store_nt(&dst[256 + pxp_own], make_uint4(t2[0], t2[1], t2[2], t2[3]));
+			store_nt(&dst[512 + pxp_own], make_uint4(t3[0], t3[1], t3[2], t3[3]));
 			return;
 		}
 		bf16x8 hi, lo;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			lo[k] = (__bf16)(v - (float)hi[k]);
 		}
 		bf16x8* dst = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * 8192);
-		dst[pxp_own] = hi;
-		dst[256 + pxp_own] = lo;
+		store_nt(&dst[pxp_own], hi);
+		store_nt(&dst[256 + pxp_own], lo);
 	};
 
 	float T = 1.0f;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 						s_pend[(g & 7u) * 256 + threadIdx.x] = s_wt[e * 256 + threadIdx.x];
 						if ((g & 7u) == 7u) flush_group(g >> 3);
 					} else {
-						wgt[(size_t)slot * 256 + (SWEEP ? pxp_own : (int)threadIdx.x)] = s_wt[e * 256 + threadIdx.x];
+						store_nt(&wgt[(size_t)slot * 256 + (SWEEP ? pxp_own : (int)threadIdx.x)], s_wt[e * 256 + threadIdx.x]);
 					}
 					if (threadIdx.x == 0) {
 						act_id[slot] = s_e[e].id;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 				s_pend[(g & 7u) * 256 + threadIdx.x] = wT;
 				if ((g & 7u) == 7u) flush_group(g >> 3);
 			} else {
-				wgt[(size_t)(cstart + (g % ACH)) * 256 + pxp_own] = wT;
+				store_nt(&wgt[(size_t)(cstart + (g % ACH)) * 256 + pxp_own], wT);
 			}
 			if (threadIdx.x == 0) act_id[cstart + (g % ACH)] = SGS_BG_ID;
 		}
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void blend_weights_kernel(
 			} else {
 				const uint32_t ci = g / ACH;
 				const uint32_t cstart = ci < 64 ? s_chunk[ci] : table[chunk_base + ci];   // (ci >= 64 > 0: a table entry)
-				wgt[(size_t)(cstart + (g % ACH)) * 256 + pxp_own] = 0.0f;
+				store_nt(&wgt[(size_t)(cstart + (g % ACH)) * 256 + pxp_own], 0.0f);
 			}
 		}
 	}
@@ -493,9 +493,9 @@ __global__ __launch_bounds__(256) void blend_weights_sb_kernel(
 			t3[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_));
 		}
 		uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(wgt) + (size_t)(slot >> 3) * GROUP_BYTES);
-		dst[pxp_own] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
-		dst[256 + pxp_own] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
-		dst[512 + pxp_own] = make_uint4(t3[0], t3[1], t3[2], t3[3]);
+		store_nt(&dst[pxp_own], make_uint4(t1[0], t1[1], t1[2], t1[3]));
+		store_nt(&dst[256 + pxp_own], make_uint4(t2[0], t2[1], t2[2], t2[3]));
+		store_nt(&dst[512 + pxp_own], make_uint4(t3[0], t3[1], t3[2], t3[3]));
 	};
 	// one work-list entry (tile-uniform position g) from this thread's weight w
 	auto emit = [&](uint32_t g, float w) {
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void blend_weights_sb_kernel(
 			s_pend[(g & 7u) * 256 + t] = w;
 			if ((g & 7u) == 7u) flush_group(g >> 3);
 		} else {
-			wgt[(size_t)(chunk_start_of(g / ACH) + (g % ACH)) * 256 + pxp_own] = w;
+			store_nt(&wgt[(size_t)(chunk_start_of(g / ACH) + (g % ACH)) * 256 + pxp_own], w);
 		}
 	};
 	// thread 0: make sure the chunks for entries [0, upto) exist; returns false after an arena overflow

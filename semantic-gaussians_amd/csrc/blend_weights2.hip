@@ -82,7 +82,7 @@ __device__ __noinline__ void flush_group3(const float* pend, uint4* dst, int pxp
 		}
 		dst[pxp + i] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
 		dst[256 + pxp + i] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
-		dst[512 + pxp + i] = make_uint4(t3[0], t3[1], t3[2], t3[3]);
+		dst[512 + pxp + i] = make_uint4(t3[0], t3[1], t3[2], t3[3]);   // (plain stores: this kernel completes a 128-B line with TWO instructions -- with the nt hint it ran 0.47 instead of 0.26 ms)
 	}
 }
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_kernel(
 			if ((g & 7u) == 7u) flush_group(g >> 3);
 		} else {
 			const uint32_t slot = chunk_start(g / ACH) + (g % ACH);
-			*reinterpret_cast<f32x2*>(wgt + (size_t)slot * 256 + pxp) = w;
+			store_nt(reinterpret_cast<f32x2*>(wgt + (size_t)slot * 256 + pxp), w);
 		}
 	};
 

@@ -19,6 +19,15 @@
 
 namespace sgs {
 
+// Streaming stores (the `nt` hint) for data that is written once and read by a LATER kernel: the work list's weight rows.
+// Measured (profiles/r04_worklist_nt_stores.txt): the weights pre-pass 0.262 -> 0.229 ms at cfg3, the sweep that reads them unchanged.
+typedef uint32_t sgs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt(uint4* p, uint4 v)
+{
+	__builtin_nontemporal_store(sgs_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<sgs_u32x4*>(p));
+}
+template <typename T> __device__ __forceinline__ void store_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
 __device__ __forceinline__ float fmin_(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float fmax_(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
