@@ -784,10 +784,10 @@ def main():
             "two_term": two_term,
             "backward": backward,
             "semantic_consumer": consumer,
-            # the forward blend = blend_weights_sb_kernel + blend_accum_sweep3_kernel (one launch each);
+            # the forward blend = blend_weights2_sb_kernel + blend_accum_sweep3_kernel (one launch each);
             # SURVEY 8(d)'s algorithmic bytes are a property of the pair, so the roofline is quoted
             # on the pair; the per-kernel live durations are alongside (rocprof: profiles/).
-            "roofline": {"bound": "hbm", "kernel": "blend_fwd (blend_weights_sb_kernel<4> + blend_accum_sweep3_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "blend_fwd (blend_weights2_sb_kernel + blend_accum_sweep3_kernel)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "algorithmic_bytes": bytes_blend,
                          "kernel_ms": blend_ms,

@@ -322,9 +322,9 @@ int sgs_stream_release(void *stream);
  *                 a library GEMM beside the same victim does not do that), [7:4] segment length / 8
  *                 (0 = adaptive), [11:8] development ablations (1 = no stores, 2 = no matrix work, 4 / 8 = phase clocks /
  *                 store forms), [13:12] workgroup order (0 / 3 = segments sorted by work and dealt to the XCDs, 1 = row-major,
- *                 2 = dealt unsorted), [14] / [15] A/B switches of the weights pre-pass (14: the other kernel family for the
- *                 format, 15: round 2's 16-entry-batch kernel instead of round 4's 256-entry super-batches; all
- *                 bit-identical).
+ *                 2 = dealt unsorted), [14] / [15] A/B switches of the weights pre-pass (three-term format: 0 = two pixels per
+ *                 lane, super-batches: the default; 0x4000 = lane per pixel, super-batches; 0x8000 / 0xC000 = the
+ *                 16-entry-batch kernels of rounds 2 / 3; all bit-identical).
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.

@@ -1438,11 +1438,18 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// carries the trace hooks).
 		const bool flip = (split_mode & 0x4000) != 0;
 		const bool w_old = (presplit3 ? !flip : flip) || g_sweep_trace != nullptr;
-		// round 4: the list walked 256 entries at a time (blend_weights_sb_kernel) for the three-term format (2-3 % faster than the
-		// 16-entry-batch kernel there; for fp32 rows blend_weights2.hip's two-pixels-per-lane kernel stays ahead, 0.19 vs 0.245 ms);
-		// bit 15 of the word restores the 16-entry-batch kernel for A/B runs (so does a sweep trace: the old kernel carries the hooks)
+		// round 4: the list walked a super-batch at a time for the three-term format -- blend_weights2_sb_kernel (two pixels per lane,
+		// 128 entries; the default) or blend_weights_sb_kernel (lane = pixel, 256 entries; bit 14); bit 15 of the word restores the
+		// 16-entry-batch kernels for A/B runs (0x8000: lane = pixel, 0xC000: two pixels per lane; a sweep trace needs the former:
+		// it carries the hooks).  fp32 rows (exact sweep, backward) stay with blend_weights2_kernel<3>.
 		const bool w_sb = presplit3 && (split_mode & 0x8000) == 0 && g_sweep_trace == nullptr;
-		if (w_sb) {
+		if (w_sb && !flip) {   // the default: the two-pixels-per-lane kernel with the super-batch walk (blend_weights2.hip, mode 5: 0.207 ms at cfg3;
+			// bit 14 of the word selects the lane-per-pixel super-batch kernel below, 0.217-0.22)
+			const hipError_t ew = launch_blend_weights2(st, 5, a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib,
+								    act_id, nullptr, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, ntiles,
+								    nullptr, 0, a.tile_order);
+			if (ew != hipSuccess) return ew;
+		} else if (w_sb) {
 			const int pxw = (ntiles + 7) / 8;
 			hipLaunchKernelGGL(blend_weights_sb_kernel<4>, dim3(pxw * 8), dim3(256), 0, st, a.ranges, a.point_list, a.means2D,
 					   a.conic_opacity, a.final_T, a.n_contrib, act_id, (uint32_t*)nullptr, wgt, table, nbatches, counter,

@@ -179,9 +179,10 @@ def test_ping_pong_sweep_equals_round3_sweep_bitwise():
 
 
 def test_superbatch_weights_prepass_equals_batch16_bitwise():
-    """Round 4's weights pre-pass walks a tile's list 256 entries at a time (blend_weights_sb_kernel; bit 15 of the variant
-    word restores the 16-entry-batch kernels): same arithmetic, same entry order, same work list -- the feature map, the final
-    transmittance and the contributor counts are bit-identical.  Cases: lists shorter than one super-batch, lists of thousands
+    """Round 4's weights pre-pass walks a tile's list a super-batch at a time (blend_weights2_sb_kernel: two pixels per lane,
+    128 entries; blend_weights_sb_kernel: lane = pixel, 256 entries; bit 15 of the variant word restores the 16-entry-batch
+    kernels): same arithmetic, same entry order, same work list -- the feature map, the final transmittance and the
+    contributor counts are bit-identical across all four kernels.  Cases: lists shorter than one super-batch, lists of thousands
     of entries with most of them rejected at tile level, more than 128 active entries per tile (the work list crosses chunk
     boundaries), more than 16 kept per super-batch (several groups), a non-zero background."""
     from sgs_hip import raster
@@ -195,13 +196,16 @@ def test_superbatch_weights_prepass_equals_batch16_bitwise():
         for _ in range(3):   # (let the stream's work-list arena grow to this scene: an overflowing frame takes the exact single-kernel path)
             _hip_forward(scene, cam, variant=0x66)
         for v in (0x66, 0x6E, 0x16):
-            new = _hip_forward(scene, cam, variant=v)
-            old = _hip_forward(scene, cam, variant=v | 0x8000)
-            assert new[0] == old[0]
-            assert torch.equal(new[1], old[1]), (P, C, W, H, hex(v))
+            new = _hip_forward(scene, cam, variant=v)          # two pixels per lane, 128-entry super-batches (the default)
             a = raster.image_views(new[5], W, H)
-            b = raster.image_views(old[5], W, H)
-            assert torch.equal(a["n_contrib"], b["n_contrib"]) and torch.equal(a["final_T"], b["final_T"]), (P, C, W, H, hex(v))
+            # 0x8000: 16-entry batches, lane = pixel (round 2's kernel) | 0x4000: 256-entry super-batches, lane = pixel |
+            # 0xC000: 16-entry batches, two pixels per lane (round 3's kernel)
+            for alt in (0x8000, 0x4000, 0xC000):
+                old = _hip_forward(scene, cam, variant=v | alt)
+                assert new[0] == old[0]
+                assert torch.equal(new[1], old[1]), (P, C, W, H, hex(v), hex(alt))
+                b = raster.image_views(old[5], W, H)
+                assert torch.equal(a["n_contrib"], b["n_contrib"]) and torch.equal(a["final_T"], b["final_T"]), (P, C, W, H, hex(v), hex(alt))
 
 
 def test_x16_experiments_are_not_in_the_product_library():
