@@ -1,12 +1,12 @@
 #!/bin/bash
-# round 4, GPU call X2: the final tree again after the nt work-list stores and the front-end merges: -m gpu suite, smoke, the evidence bundle, a 36 000-forward soak
+# round 4, GPU call X3: the final tree (two-pixels-per-lane super-batch pre-pass, nt work-list stores, front-end merges): -m gpu suite, smoke, the evidence bundle, a 36 000-forward soak
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-O=gpurun_out/r04x2; mkdir -p $O
+O=gpurun_out/r04x3; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -q -m gpu --timeout=900 > $O/pytest.txt 2>&1
 echo "pytest rc=$?"; tail -6 $O/pytest.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 1500 bash tools/profile_round.sh r04x2 > $O/profile_round.log 2>&1
+timeout 1500 bash tools/profile_round.sh r04x3 > $O/profile_round.log 2>&1
 tail -3 $O/bench_default.err; cat $O/bench_default.json | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
