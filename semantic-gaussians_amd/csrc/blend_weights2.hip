@@ -23,6 +23,9 @@ namespace sgs {
 namespace {
 
 constexpr int WB = 16;    // list entries per batch
+#ifndef SGS_W2SB_GROUP
+#define SGS_W2SB_GROUP 16   // kept entries per group of the super-batch kernel (A/B builds: 8 -> 80 VGPRs, 6 waves per SIMD)
+#endif
 constexpr int ACH = 128;  // work-list slots per chunk
 constexpr uint32_t SGS_BG_ID = 0xFFFFFFFFu;
 
@@ -373,7 +376,8 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_kernel(
 // 128-entry super-batch (gathers prefetched a super-batch ahead, the tile-level rejection 128 wide), the kept entries compacted
 // in list order, the weight phase over groups of 16 KEPT entries -- two barriers per 128 list entries plus one per group.
 // Same arithmetic, same entry order, same work list (bit-identical frames).  Three-term format only (the forward's default).
-__global__ __launch_bounds__(128, 5) void blend_weights2_sb_kernel(
+template <int GB>   // GB = kept entries per group (their weights stay in 2 GB registers of the lane)
+__global__ __launch_bounds__(128, GB == 8 ? 6 : 5) void blend_weights2_sb_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_sb_kernel(
 	const uint32_t chunk_base = (range.x >> 7) + (uint32_t)tile;
 
 	__shared__ StagedEntry2 s_e[SB];
-	__shared__ uint32_t s_amask[SB / WB];
+	__shared__ uint32_t s_amask[SB / GB];
 	__shared__ int s_cnt[2], s_alive[2];
 	__shared__ uint32_t s_ovf;
 	__shared__ uint32_t s_chunk[64];
@@ -501,16 +505,16 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_sb_kernel(
 		if (!(s_alive[0] | s_alive[1])) break;
 		const int c0 = s_cnt[0], nkeep = c0 + s_cnt[1];
 		if (keep) s_e[(wave ? c0 : 0) + __popcll(km & below)] = e;
-		if (t < SB / WB) s_amask[t] = 0u;
+		if (t < SB / GB) s_amask[t] = 0u;
 		lds_barrier2();   // B2
-		for (int g0 = 0, gi = 0; g0 < nkeep; g0 += WB, gi++) {
-			const int ng = (nkeep - g0) < WB ? (nkeep - g0) : WB;
+		for (int g0 = 0, gi = 0; g0 < nkeep; g0 += GB, gi++) {
+			const int ng = (nkeep - g0) < GB ? (nkeep - g0) : GB;
 			// ---- weight phase (the kernel above's): this wave's 128 pixels against the group's entries, weights in registers
-			f32x2 w[WB];
+			f32x2 w[GB];
 			uint32_t act = 0u;
 			const bool alive = __ballot(!(done0 && done1)) != 0ull;
 #pragma unroll
-			for (int j = 0; j < WB; j++) {
+			for (int j = 0; j < GB; j++) {
 				w[j] = f32x2{0.f, 0.f};
 				if (j < ng && alive) {   // (uniform)
 					const StagedEntry2 se = s_e[g0 + j];
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(128, 5) void blend_weights2_sb_kernel(
 			}
 			if (s_ovf == 0u) {
 #pragma unroll
-				for (int j = 0; j < WB; j++) {
+				for (int j = 0; j < GB; j++) {
 					if ((amask >> j) & 1u) {   // (uniform)
 						const uint32_t g = total + (uint32_t)__popc(amask & ((1u << j) - 1u));
 						emit(g, w[j]);
@@ -597,7 +601,7 @@ hipError_t launch_blend_weights2(hipStream_t st, int mode, const uint2* ranges, 
 {
 	const dim3 grid(((ntiles + 7) / 8) * 8);
 	if (mode == 5)   // three bf16 terms, 128-entry super-batches (the forward's default pre-pass)
-		hipLaunchKernelGGL(blend_weights2_sb_kernel, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
+		hipLaunchKernelGGL(blend_weights2_sb_kernel<SGS_W2SB_GROUP>, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
 				   n_contrib, act_id, wgt, table, nact, counter, capacity, W, H, gx, (ntiles + 7) / 8, ntiles, tile_order);
 	else if (mode == 4)
 		hipLaunchKernelGGL(blend_weights2_kernel<4>, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
