@@ -28,6 +28,7 @@
 // If the work list overflows its arena a device flag makes 2-4 exit and blend_bwd.hip's kernel
 // (launched behind them, gated on the same flag) do the work.
 #include "sgs_kernels.h"
+#include <stdlib.h>
 
 namespace sgs {
 
@@ -597,6 +598,313 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		}
 	}
 }
+// ================= 2 + 3 fused (round 5, the default): both products of a tile from ONE read of its gradient =================
+// The two products contract the gradient slab g[32 c][256 px'] over different dimensions (D = F g over c, dL/dF = W g^T over
+// px'), which is why rounds 2-4 ran them as two kernels that each streamed the 2.57 GB gradient.  One workgroup of eight waves
+// per tile, all channels, the work list in chunks of up to 128 entries; per 32-channel slab:
+//   * a lane owns ONE pixel (px' = 32 wave + lane % 32) and the sixteen channels 16 h .. 16 h + 15 of its lane half: sixteen
+//     dword loads a slab ahead.  Split into bf16 (hi, lo) pairs those registers ARE the B operand of D's products for the
+//     wave's own N block of 32 px' (accumulators: 4 x 16 registers for 128 entries), no LDS involved.  A = the chunk's
+//     feature rows, staged per slab by all threads (double buffered).
+//   * the same registers are written, 16 bits at a time, into a [c][256 px'] tile in LDS -- the transpose, K = px' contiguous
+//     -- which is the B operand of W g^T one slab LATER (double buffered: the one barrier per slab publishes it).  For that
+//     product wave w is (entry block w & 3, K half w >> 2): its A operand, the weights of 32 entries x 128 px', lives in 64
+//     registers for the whole chunk, 48 products per slab go into ONE accumulator, the upper half's partial sum crosses to the
+//     lower half's wave through LDS (plain stores: ds_add_f32 runs at ~170 cycles per wave instruction on this chip,
+//     tools/ubench_ldsadd.hip -- a reduction of eight partial tiles through LDS float atomics made this kernel 13 ms) and
+//     leaves as one coalesced 128-B atomic row per (entry, 32 channels), issued before the next loads so that the in-order
+//     memory counter never waits for an atomic's round trip.
+//   * the two waves of a SIMD run their phases in opposite order (lower half: split / transpose, then D, then W g^T of the
+//     previous slab; upper half: W g^T first), so one wave's VALU / LDS phase lies beside the other's matrix phase.
+// FP32 (backward mode 3): the same data flow with the operands left in fp32 and v_mfma_f32_32x32x2_f32 (k = lane half, the
+// sixteen positions 16 h + s of a 32-wide K block one by one) -- identical register and LDS footprints.
+constexpr int GROW = 260;                   // dwords per channel row of the transposed slab: [128 dwords hi | 128 lo | 4 pad] (or 256 floats + 4)
+constexpr int GTILE = 32 * GROW + 32;       // rows 16 .. 31 start 32 dwords later: the two lane halves of a transposing store hit different banks
+__device__ __forceinline__ int g_row(int c) { return c * GROW + (c >> 4) * 32; }
+
+template <bool FP32, int DBG = 0>   // DBG (development ablations, wrong results): 1 no pair exchange, 2 no global atomics, 4 no products, 8 no transposing stores
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_fused_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
+	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
+	const float* Wrows, const float* __restrict__ features, const float* __restrict__ bg,
+	const float* __restrict__ dL_dpix, float* Drows, float* __restrict__ dL_dcolors,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int per_xcd, int ntiles)
+{
+	if (counter[1] != 0u) return;
+	const int b = blockIdx.x;
+	const int tile = (b & 7) * per_xcd + (b >> 3);
+	if (tile >= ntiles) return;
+	const int t = threadIdx.x;
+	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int l31 = lane & 31, h = lane >> 5;
+	const int mblk = wave & 3, kh = wave >> 2;   // W g^T: this wave's block of 32 entries and its half of the 256 px' (= row parity)
+	const int tx = tile % gx, ty = tile / gx;
+	const uint32_t HW = (uint32_t)H * (uint32_t)W;
+	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+	const int total = (int)nact[tile];
+	const int nsl = C >> 5;
+
+	__shared__ __attribute__((aligned(16))) uint32_t sF[2][CHUNK * LDQ];   // the chunk's feature rows of a slab (A of D), double buffered
+	__shared__ __attribute__((aligned(16))) uint32_t sG[2][GTILE];         // a slab transposed: [c][256 px'], double buffered
+	__shared__ __attribute__((aligned(16))) float sX[2][4][16 * 64];       // the upper K half's partial dL/dF tiles, [entry block][register][lane]
+	__shared__ uint32_t s_id[CHUNK];
+
+	// this lane's pixel px' = 32 wave + l31 and its sixteen channels 16 h .. 16 h + 15 of every slab
+	const int gp = 32 * wave + l31;
+	const int g_y = ty * SGS_TILE + 2 * ((gp & 127) >> 4) + (gp >> 7), g_x = tx * SGS_TILE + (gp & 15);
+	const bool g_ok = g_y < H && g_x < W;
+	const uint32_t g_offb = 4u * ((uint32_t)(16 * h) * HW + (uint32_t)(g_y < H ? g_y : H - 1) * (uint32_t)W +
+				      (uint32_t)(g_x < W ? g_x : W - 1));   // (eligibility: 128 planes * 4 B < 2^32)
+	const int wr16 = 2 * g_row(16 * h) + gp;             // transposing store, 16-bit units: element (c = 16 h, px' = gp), hi term
+	const int wr32 = g_row(16 * h) + gp;                 // (FP32) in floats
+	const int rd = g_row(l31) + 64 * kh + 8 * h;         // W g^T's B operand, dwords: row c = l31, px' 128 kh + 16 h .. of block 0 (+ 16 j)
+	const int rdf = g_row(l31) + 128 * kh + 16 * h;      // (FP32) floats (+ 32 j)
+
+	for (int ci = 0; ci * CHUNK < total; ci++) {
+		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
+		const int mb = (cnt + 31) >> 5;
+		const bool e_on = mblk < mb;   // this wave's entry block holds entries
+		const uint32_t cstart = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)ci);
+		__syncthreads();   // the previous chunk is done with s_id, sF, sG, sX
+		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
+
+		// ---- the chunk's weights for W g^T: entries 32 mblk + l31, px' 128 kh + 32 j + 16 h .. + 15 (j = 0 .. 3), resident all chunk
+		uint32_t wh[4][8], wl[4][8];   // (split) bf16 pairs of positions 2 i, 2 i + 1
+		float wv[4][16];               // (FP32)
+		{
+			const int e = 32 * mblk + l31;
+			const bool ok = e < cnt;
+			// (unconditional loads on clamped rows: a branch around a load makes the compiler drain the load counter)
+			const float* wr = Wrows + (size_t)(cstart + (uint32_t)(ok ? e : 0)) * 256 + 128 * kh + 16 * h;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				float4 v[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) v[i] = mask4(*reinterpret_cast<const float4*>(wr + 32 * j + 4 * i), ok);
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					if (FP32) {
+						wv[j][4 * i] = v[i].x;
+						wv[j][4 * i + 1] = v[i].y;
+						wv[j][4 * i + 2] = v[i].z;
+						wv[j][4 * i + 3] = v[i].w;
+					} else {
+						split_pair(v[i].x, v[i].y, wh[j][2 * i], wl[j][2 * i]);
+						split_pair(v[i].z, v[i].w, wh[j][2 * i + 1], wl[j][2 * i + 1]);
+					}
+				}
+			}
+		}
+		f32x16 acc[4];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+		f32x16 held;   // (lower half) its own partial dL/dF of the previous slab, until the upper half's has crossed the barrier
+#pragma unroll
+		for (int r = 0; r < 16; r++) held[r] = 0.f;
+		__syncthreads();   // s_id visible
+		const float* frow[2];
+		bool fvalid[2];
+#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			const int q = t + 512 * i, e = q >> 3, f = q & 7;
+			const uint32_t id = s_id[e];
+			fvalid[i] = id != NO_ID;
+			frow[i] = ((id == BG_ID || id == NO_ID) ? bg : features + (size_t)id * C) + 4 * f;
+		}
+		// this lane's sixteen output rows of W g^T (the accumulator registers' entries), as gradient row pointers; null = no row
+		float pg[16];
+		float4 pf[2];
+		uint32_t gh[8], gl[8];
+		float gv[16];
+		auto fetch = [&](int c0) __attribute__((always_inline)) {
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+				const_cast<float*>(dL_dpix + (size_t)c0 * HW), 0, 0xFFFFFFFF, 0x00020000);
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				pg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, g_offb, (uint32_t)j * HW * 4u, 0));
+#pragma unroll
+			for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
+		};
+		auto stage_f = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				const int q = t + 512 * i, e = q >> 3, f = q & 7;
+				if (FP32) {
+					*reinterpret_cast<float4*>(&sF[buf][e * LDQ + 4 * f]) = mask4(pf[i], fvalid[i]);
+				} else {
+					uint2 hi, lo;
+					split_px4(pf[i], fvalid[i], hi, lo);
+					*reinterpret_cast<uint2*>(&sF[buf][e * LDQ + 2 * f]) = hi;
+					*reinterpret_cast<uint2*>(&sF[buf][e * LDQ + 16 + 2 * f]) = lo;
+				}
+			}
+		};
+		// A: the prefetched sub-slab becomes D's B operand (registers) and goes, transposed, into the slab's LDS tile
+		auto take_slab = [&](int buf) __attribute__((always_inline)) {
+			if (FP32) {
+				float* gt = reinterpret_cast<float*>(&sG[buf][0]) + wr32;
+#pragma unroll
+				for (int j = 0; j < 16; j++) {
+					gv[j] = g_ok ? pg[j] : 0.f;
+					if (!(DBG & 8)) gt[j * GROW] = gv[j];
+				}
+			} else {
+				uint16_t* gt = reinterpret_cast<uint16_t*>(&sG[buf][0]) + wr16;
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					split_pair(pg[2 * j], pg[2 * j + 1], gh[j], gl[j]);
+					gh[j] = g_ok ? gh[j] : 0u;
+					gl[j] = g_ok ? gl[j] : 0u;
+					if (DBG & 8) continue;
+					gt[2 * (2 * j) * GROW] = (uint16_t)gh[j];
+					gt[2 * (2 * j + 1) * GROW] = (uint16_t)(gh[j] >> 16);
+					gt[2 * (2 * j) * GROW + 256] = (uint16_t)gl[j];
+					gt[2 * (2 * j + 1) * GROW + 256] = (uint16_t)(gl[j] >> 16);
+				}
+			}
+			asm volatile("" ::: "memory");   // (the tile is read through differently typed pointers)
+		};
+		// D[e][px'] += sum_c F[e][c] g[c][px'] for the wave's 32 px'
+		auto prod_d = [&](int buf) __attribute__((always_inline)) {
+			if (DBG & 4) {
+#pragma unroll
+				for (int j = 0; j < 8; j++) acc[0][j] += FP32 ? gv[j] : __uint_as_float(gh[j] ^ gl[j]);
+			} else if (FP32) {
+				const float* sFf = reinterpret_cast<const float*>(&sF[buf][0]);
+#pragma unroll
+				for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+					for (int m = 0; m < 4; m++)
+						if (m < mb) {
+							const float4 a = *reinterpret_cast<const float4*>(&sFf[(32 * m + l31) * LDQ + 16 * h + 4 * s4]);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, gv[4 * s4], acc[m], 0, 0, 0);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, gv[4 * s4 + 1], acc[m], 0, 0, 0);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, gv[4 * s4 + 2], acc[m], 0, 0, 0);
+							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, gv[4 * s4 + 3], acc[m], 0, 0, 0);
+						}
+			} else {
+#pragma unroll
+				for (int sp = 0; sp < 2; sp++) {
+					Op2 bh, bl;
+					bh.k0 = __builtin_bit_cast(s16x4, uint2{gh[4 * sp], gh[4 * sp + 1]});
+					bh.k1 = __builtin_bit_cast(s16x4, uint2{gh[4 * sp + 2], gh[4 * sp + 3]});
+					bl.k0 = __builtin_bit_cast(s16x4, uint2{gl[4 * sp], gl[4 * sp + 1]});
+					bl.k1 = __builtin_bit_cast(s16x4, uint2{gl[4 * sp + 2], gl[4 * sp + 3]});
+#pragma unroll
+					for (int m = 0; m < 4; m++)
+						if (m < mb) {
+							const uint32_t* fa = &sF[buf][(32 * m + l31) * LDQ + 8 * h + 4 * sp];
+							const Op2 ah = lds_op2(fa), al = lds_op2(fa + 16);
+							acc[m] = SGS_MFMA_BF16(al.k0, bh.k0, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k0, bl.k0, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k0, bh.k0, acc[m]);
+							acc[m] = SGS_MFMA_BF16(al.k1, bh.k1, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k1, bl.k1, acc[m]);
+							acc[m] = SGS_MFMA_BF16(ah.k1, bh.k1, acc[m]);
+						}
+				}
+			}
+		};
+		// E: this wave's partial dL/dF[32 mblk ..][slab's 32 c] over its 128 px' from the slab tile `buf`; the upper half parks
+		// it in sX[buf], the lower half holds it in registers
+		auto prod_e = [&](int buf) __attribute__((always_inline)) {
+			if (!e_on) return;
+			f32x16 a2;
+#pragma unroll
+			for (int r = 0; r < 16; r++) a2[r] = 0.f;
+			if (DBG & 4) {
+				a2[0] = __uint_as_float(sG[buf][rd]);
+			} else if (FP32) {
+				const float* gt = reinterpret_cast<const float*>(&sG[buf][0]) + rdf;
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+#pragma unroll
+					for (int s4 = 0; s4 < 4; s4++) {
+						const float4 b4 = *reinterpret_cast<const float4*>(gt + 32 * j + 4 * s4);
+						a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][4 * s4], b4.x, a2, 0, 0, 0);
+						a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][4 * s4 + 1], b4.y, a2, 0, 0, 0);
+						a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][4 * s4 + 2], b4.z, a2, 0, 0, 0);
+						a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][4 * s4 + 3], b4.w, a2, 0, 0, 0);
+					}
+			} else {
+				const uint32_t* gt = &sG[buf][rd];
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+#pragma unroll
+					for (int sp = 0; sp < 2; sp++) {
+						const Op2 bh = lds_op2(gt + 16 * j + 4 * sp), bl = lds_op2(gt + 128 + 16 * j + 4 * sp);
+						Op2 ah, al;
+						ah.k0 = __builtin_bit_cast(s16x4, uint2{wh[j][4 * sp], wh[j][4 * sp + 1]});
+						ah.k1 = __builtin_bit_cast(s16x4, uint2{wh[j][4 * sp + 2], wh[j][4 * sp + 3]});
+						al.k0 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp], wl[j][4 * sp + 1]});
+						al.k1 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp + 2], wl[j][4 * sp + 3]});
+						a2 = SGS_MFMA_BF16(al.k0, bh.k0, a2);
+						a2 = SGS_MFMA_BF16(ah.k0, bl.k0, a2);
+						a2 = SGS_MFMA_BF16(ah.k0, bh.k0, a2);
+						a2 = SGS_MFMA_BF16(al.k1, bh.k1, a2);
+						a2 = SGS_MFMA_BF16(ah.k1, bl.k1, a2);
+						a2 = SGS_MFMA_BF16(ah.k1, bh.k1, a2);
+					}
+			}
+			if (kh) {
+				if (!(DBG & 1)) {
+#pragma unroll
+					for (int r = 0; r < 16; r++) sX[buf][mblk][r * 64 + lane] = a2[r];
+				}
+			} else {
+				held = a2;
+			}
+		};
+		// B (lower half): `held` + the upper half's tile in sX[buf] (a barrier old) = dL/dF of the slab at channel cb: atomics
+		auto finish_e = [&](int buf, int cb) __attribute__((always_inline)) {
+			if (kh || !e_on) return;
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const float v = held[r] + ((DBG & 1) ? 0.f : sX[buf][mblk][r * 64 + lane]);
+				// (volatile: left loop invariant, the sixteen row addresses are tabulated per chunk -- 32 registers the kernel
+				// does not have; they spill and come back from scratch in every slab)
+				const uint32_t id = *reinterpret_cast<volatile uint32_t*>(&s_id[32 * mblk + mfma_row(r, h)]);
+				if (id < NO_ID && !(DBG & 2)) atomicAdd(&dL_dcolors[(size_t)id * C + cb + l31], v);
+			}
+		};
+
+		fetch(0);
+		stage_f(0);
+		__syncthreads();
+		// iteration s: slab s is taken and multiplied into D, W g^T of slab s - 1 runs from the tile the last barrier published,
+		// the lower half finishes slab s - 2.  The atomics go out BEFORE the next slab's loads: the memory counter retires in
+		// order, so the wait for those loads at the top of the next iteration also covers atomics that are an iteration old by
+		// then -- issued behind the loads they would be the youngest entries and every slab would wait for their round trip.
+		for (int s = 0; s < nsl + 2; s++) {
+			const int cur = s & 1;
+			const bool slab = s < nsl, more = s + 1 < nsl;
+			if (kh) {
+				if (s >= 1 && s <= nsl) prod_e(cur ^ 1);
+				if (slab) take_slab(cur);
+				if (more) fetch(32 * (s + 1));
+				if (slab) prod_d(cur);
+			} else {
+				if (slab) take_slab(cur);
+				if (s >= 2) finish_e(cur, 32 * (s - 2));
+				if (more) fetch(32 * (s + 1));
+				if (slab) prod_d(cur);
+				if (s >= 1 && s <= nsl) prod_e(cur ^ 1);
+			}
+			if (more) stage_f(cur ^ 1);
+			if (s <= nsl) __syncthreads();
+		}
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			if (m < mb)
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					const int e = 32 * m + mfma_row(r, h);
+					if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 32 * wave + l31] = acc[m][r];
+				}
+	}
+}
 #undef SGS_MFMA_BF16
 
 struct StagedEntryG {
@@ -746,6 +1054,8 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 
 } // namespace
 
+static const int g_bwd_dbg = getenv("SGS_BWD_DBG") ? atoi(getenv("SGS_BWD_DBG")) : 0;   // development only
+
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 {
 	return a.C >= 32 && (a.C & 31) == 0 && (((uintptr_t)a.colors | (uintptr_t)a.bg) & 15u) == 0 &&
@@ -753,7 +1063,7 @@ bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 }
 
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products, size_t clear_dcolor_floats)
+				      bool fp32_products, size_t clear_dcolor_floats, bool two_kernels)
 {
 	const int ntiles = a.gx * a.gy;
 	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
@@ -774,6 +1084,20 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const int items = ntiles * nch;
 	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
 	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows
+	if (!two_kernels) {   // round 5: one kernel, one read of the gradient for both products
+		if (fp32_products)
+			hipLaunchKernelGGL(bwd_fused_kernel<true>, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows,
+					   a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
+		else if (g_bwd_dbg == 0)
+			hipLaunchKernelGGL(bwd_fused_kernel<false>, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows,
+					   a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
+#define SGS_DBG_CASE(D_) \
+		else if (g_bwd_dbg == D_) \
+			hipLaunchKernelGGL((bwd_fused_kernel<false, D_>), dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows, \
+					   a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
+		SGS_DBG_CASE(1) SGS_DBG_CASE(2) SGS_DBG_CASE(3) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15)
+#undef SGS_DBG_CASE
+	} else {
 #define SGS_LAUNCH_BWD(DCOL_, DOT_)                                                                              \
 	hipLaunchKernelGGL(DCOL_, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id,                 \
 			   rows, a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);        \
@@ -787,6 +1111,7 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 		else { SGS_LAUNCH_BWD(bwd_dcolor_split_kernel<false>, bwd_dot_split_kernel); }
 	}
 #undef SGS_LAUNCH_BWD
+	}
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
 			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
 			   a.dL_dopacity, counter, a.W, a.H, a.gx, txcd, ntiles);

@@ -1014,7 +1014,8 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 				const bool fold = dcolor_dirty && (dcolor_floats & 3) == 0 && ((uintptr_t)dL_dcolor & 15u) == 0;
 				if (dcolor_dirty && !fold) (void)hipMemsetAsync(dL_dcolor, 0, dcolor_floats * 4, st);
 				dcolor_dirty = false;
-				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3, fold ? dcolor_floats : 0);
+				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3 || bw_mode == 5, fold ? dcolor_floats : 0,
+								    bw_mode == 4 || bw_mode == 5);
 				if (e == hipSuccess && cx->ensure(cx->bwd_usage_host, cx->bwd_ev)) {
 					if (hipMemcpyAsync(cx->bwd_usage_host, arena + lay.counter, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
 					    hipEventRecord(cx->bwd_ev, st) == hipSuccess)

@@ -194,8 +194,9 @@ hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const ui
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a);
 // fp32_products: the two channel products on v_mfma_f32_32x32x2_f32 (exact fp32 products) instead of split bf16
 // clear_dcolor: a.dL_dcolors (P x C floats) is zero-filled by the first kernel instead of by the caller
+// two_kernels: rounds 2-4's form (bwd_dcolor + bwd_dot, each streaming the gradient) instead of the fused kernel
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products, size_t clear_dcolor_floats = 0);
+				      bool fp32_products, size_t clear_dcolor_floats = 0, bool two_kernels = false);
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
 			   const int* radii, const float* shs, const uint8_t* clamped,
 			   const float* scales, const float* rotations, float mod,
