@@ -622,13 +622,19 @@ constexpr int GROW = 260;                   // dwords per channel row of the tra
 constexpr int GTILE = 32 * GROW + 32;       // rows 16 .. 31 start 32 dwords later: the two lane halves of a transposing store hit different banks
 __device__ __forceinline__ int g_row(int c) { return c * GROW + (c >> 4) * 32; }
 
-template <bool FP32, int DBG = 0>   // DBG (development ablations, wrong results): 1 no pair exchange, 2 no global atomics, 4 no products, 8 no transposing stores
+// ROWS (the default): dL/dF leaves as plain stores into a scratch row per work-list SLOT, `frows[slot][C]`, and the chunk's
+// entries link their slots into per-Gaussian lists (g_head[id] / g_next[slot], values = slot + 1, 0 = end); bwd_gather_rows_kernel
+// then writes every row of dL_dcolors exactly once.  !ROWS: one coalesced 128-B atomic row per (entry, 32 channels) into the
+// zero-filled dL_dcolors -- 233 M lane atomics at cfg3, which the L2's atomic units retire at ~330 G/s: 0.7 ms of a 1.6 ms kernel.
+template <bool FP32, bool ROWS, int DBG = 0>   // DBG (development ablations, wrong results): 1 no pair exchange, 2 no global atomics / row stores, 4 no products, 8 no transposing stores
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_fused_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const float* Wrows, const float* __restrict__ features, const float* __restrict__ bg,
 	const float* __restrict__ dL_dpix, float* Drows, float* __restrict__ dL_dcolors,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int per_xcd, int ntiles)
+	float* __restrict__ frows, uint32_t* __restrict__ g_head, uint32_t* __restrict__ g_next,
+	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int per_xcd, int ntiles,
+	unsigned long long* __restrict__ trace)
 {
 	if (counter[1] != 0u) return;
 	const int b = blockIdx.x;
@@ -637,6 +643,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const int t = threadIdx.x;
 	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 	const int l31 = lane & 31, h = lane >> 5;
+	// DBG & 16 (tools/bwd_phases.py): shader-clock stamps at the phase boundaries of an iteration, summed per wave.  s_memtime is an
+	// SMEM access (reading it drains lgkmcnt), so the stamps cost LDS overlap: read the shares, not the total
+	constexpr bool PH = (DBG & 16) != 0;
+	uint32_t ph[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	uint32_t ph_prev = PH ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
+#define SGS_PH(K_)                                                          \
+	if (PH) {                                                           \
+		const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); \
+		ph[K_] += now_ - ph_prev;                                   \
+		ph_prev = now_;                                             \
+	}
 	const int mblk = wave & 3, kh = wave >> 2;   // W g^T: this wave's block of 32 entries and its half of the 256 px' (= row parity)
 	const int tx = tile % gx, ty = tile / gx;
 	const uint32_t HW = (uint32_t)H * (uint32_t)W;
@@ -666,7 +683,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		const bool e_on = mblk < mb;   // this wave's entry block holds entries
 		const uint32_t cstart = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)ci);
 		__syncthreads();   // the previous chunk is done with s_id, sF, sG, sX
-		if (t < CHUNK) s_id[t] = t < cnt ? act_id[cstart + t] : NO_ID;
+		uint32_t link_next = 0u;
+		if (t < CHUNK) {
+			const uint32_t id = t < cnt ? act_id[cstart + t] : NO_ID;
+			s_id[t] = id;
+			// (ROWS) this slot joins its Gaussian's list; the returned previous head is stored at the END of the chunk, so
+			// nobody waits for the atomic's round trip
+			if (ROWS && id < NO_ID) link_next = atomicExch(&g_head[id], cstart + (uint32_t)t + 1u);
+		}
 
 		// ---- the chunk's weights for W g^T: entries 32 mblk + l31, px' 128 kh + 32 j + 16 h .. + 15 (j = 0 .. 3), resident all chunk
 		uint32_t wh[4][8], wl[4][8];   // (split) bf16 pairs of positions 2 i, 2 i + 1
@@ -718,12 +742,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		float4 pf[2];
 		uint32_t gh[8], gl[8];
 		float gv[16];
-		auto fetch = [&](int c0) __attribute__((always_inline)) {
+		auto fetch_g = [&](int c0) __attribute__((always_inline)) {
 			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
 				const_cast<float*>(dL_dpix + (size_t)c0 * HW), 0, 0xFFFFFFFF, 0x00020000);
 #pragma unroll
 			for (int j = 0; j < 16; j++)
 				pg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, g_offb, (uint32_t)j * HW * 4u, 0));
+		};
+		auto fetch_f = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
 			for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
 		};
@@ -859,42 +885,76 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		};
 		// B (lower half): `held` + the upper half's tile in sX[buf] (a barrier old) = dL/dF of the slab at channel cb: atomics
 		auto finish_e = [&](int buf, int cb) __attribute__((always_inline)) {
-			if (kh || !e_on) return;
+			if (!e_on) return;
+			// (the row index is laundered: left loop invariant, the sixteen ids and row addresses are tabulated per chunk --
+			// 48 registers the kernel does not have; they spill and come back from scratch in every slab)
+			int eb = 32 * mblk + 4 * h;
+			asm volatile("" : "+v"(eb));
+			if (ROWS) {
+				// rows of slots that hold no entry (beyond cnt, the background's) belong to this tile's chunk all the same and
+				// are never linked: every register is stored, no test
+				float* const col = frows + (size_t)(cstart + (uint32_t)eb) * C + cb + l31;
 #pragma unroll
-			for (int r = 0; r < 16; r++) {
-				const float v = held[r] + ((DBG & 1) ? 0.f : sX[buf][mblk][r * 64 + lane]);
-				// (volatile: left loop invariant, the sixteen row addresses are tabulated per chunk -- 32 registers the kernel
-				// does not have; they spill and come back from scratch in every slab)
-				const uint32_t id = *reinterpret_cast<volatile uint32_t*>(&s_id[32 * mblk + mfma_row(r, h)]);
-				if (id < NO_ID && !(DBG & 2)) atomicAdd(&dL_dcolors[(size_t)id * C + cb + l31], v);
+				for (int r = 0; r < 16; r++) {
+					const float v = held[r] + ((DBG & 1) ? 0.f : sX[buf][mblk][r * 64 + lane]);
+					if (!(DBG & 2) || v == 12345.678f) col[(size_t)((r & 3) + 8 * (r >> 2)) * C] = v;
+				}
+			} else {
+				float* const col = dL_dcolors + cb + l31;
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					const float v = held[r] + ((DBG & 1) ? 0.f : sX[buf][mblk][r * 64 + lane]);
+					const uint32_t id = s_id[eb + (r & 3) + 8 * (r >> 2)];
+					if (id < NO_ID && (!(DBG & 2) || v == 12345.678f)) atomicAdd(col + (size_t)id * C, v);
+				}
 			}
 		};
 
-		fetch(0);
+		fetch_f(0);
+		fetch_g(0);
 		stage_f(0);
 		__syncthreads();
 		// iteration s: slab s is taken and multiplied into D, W g^T of slab s - 1 runs from the tile the last barrier published,
 		// the lower half finishes slab s - 2.  The atomics go out BEFORE the next slab's loads: the memory counter retires in
 		// order, so the wait for those loads at the top of the next iteration also covers atomics that are an iteration old by
 		// then -- issued behind the loads they would be the youngest entries and every slab would wait for their round trip.
-		for (int s = 0; s < nsl + 2; s++) {
+		// (One instance of every phase in program order, each behind a uniform branch: with the two halves' sequences written
+		// as two arms the compiler allocates them separately and copies ~100 registers where they join.)
+		for (int s = 0; s < nsl; s++) {
 			const int cur = s & 1;
-			const bool slab = s < nsl, more = s + 1 < nsl;
-			if (kh) {
-				if (s >= 1 && s <= nsl) prod_e(cur ^ 1);
-				if (slab) take_slab(cur);
-				if (more) fetch(32 * (s + 1));
-				if (slab) prod_d(cur);
-			} else {
-				if (slab) take_slab(cur);
-				if (s >= 2) finish_e(cur, 32 * (s - 2));
-				if (more) fetch(32 * (s + 1));
-				if (slab) prod_d(cur);
-				if (s >= 1 && s <= nsl) prod_e(cur ^ 1);
-			}
+			const bool more = s + 1 < nsl;
+			// the next slab's feature pieces are requested FIRST: they are staged at the end of this iteration, and the memory
+			// counter retires in order -- requested behind the gradient loads, waiting for them drained those as well and the
+			// gradient's prefetch distance shrank to half an iteration
+			SGS_PH(9)
+			if (more) fetch_f(32 * (s + 1));
+			SGS_PH(0)
+			if (kh && s >= 1) prod_e(cur ^ 1);
+			SGS_PH(1)
+			take_slab(cur);
+			SGS_PH(2)
+			if (!kh && s >= 2) finish_e(cur, 32 * (s - 2));
+			SGS_PH(3)
+			if (more) fetch_g(32 * (s + 1));
+			SGS_PH(4)
+			prod_d(cur);
+			SGS_PH(5)
+			if (!kh && s >= 1) prod_e(cur ^ 1);
+			SGS_PH(6)
 			if (more) stage_f(cur ^ 1);
-			if (s <= nsl) __syncthreads();
+			SGS_PH(7)
+			__syncthreads();
+			SGS_PH(8)
 		}
+		if (kh) {
+			prod_e((nsl & 1) ^ 1);
+		} else {
+			if (nsl >= 2) finish_e(nsl & 1, 32 * (nsl - 2));
+			prod_e((nsl & 1) ^ 1);
+		}
+		__syncthreads();
+		if (!kh) finish_e((nsl & 1) ^ 1, 32 * (nsl - 1));
+		if (ROWS && t < cnt) g_next[cstart + t] = link_next;
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 			if (m < mb)
@@ -904,8 +964,82 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 					if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 32 * wave + l31] = acc[m][r];
 				}
 	}
+	if (PH && trace && lane == 0) {
+		SGS_PH(9)
+		unsigned long long* o = trace + ((size_t)b * 8 + wave) * 12;
+#pragma unroll
+		for (int k = 0; k < 10; k++) o[k] = ph[k];
+		o[10] = (unsigned long long)(((total + CHUNK - 1) / CHUNK) * nsl);   // iterations with a slab
+		o[11] = (unsigned long long)wave | ((unsigned long long)total << 8);
+	}
+#undef SGS_PH
 }
 #undef SGS_MFMA_BF16
+
+// ---- 2 + 3, last step (ROWS): dL_dcolors[id][:] = the sum of the rows of the slots on Gaussian id's list, zero for an empty list:
+// every row of the (P, C) gradient is written exactly once, by plain stores -- no zero fill of the 2 GB buffer in front of the
+// backward, no atomics, and the sum does not depend on the order in which the tiles linked themselves (a list's first four
+// slots are sorted; a Gaussian that is active in more than four tiles adds the rest in arrival order).  A wave takes eight
+// consecutive Gaussians: lanes 0 .. 7 walk the eight lists at once, then all lanes move the rows, the loads of all eight issued
+// before the first is used.  `overflow` (the work list did not fit: the per-chunk kernel, launched behind this one, does the
+// backward with atomics): all rows are zero-filled instead.
+__global__ __launch_bounds__(256) void bwd_gather_rows_kernel(const uint32_t* __restrict__ g_head, const uint32_t* __restrict__ g_next,
+							      const float4* __restrict__ frows, float4* __restrict__ out,
+							      const uint32_t* __restrict__ counter, int P, int C4)
+{
+	const bool ovf = counter[1] != 0u;
+	const int lane = threadIdx.x & 63;
+	const int nwaves = (int)gridDim.x * 4;
+	constexpr uint32_t NONE = 0xFFFFFFFFu;
+	for (int base = (((int)blockIdx.x * 256 + (int)threadIdx.x) >> 6) * 8; base < P; base += nwaves * 8) {
+		uint32_t s0 = NONE, s1 = NONE, s2 = NONE, s3 = NONE, rest = 0u;
+		if (lane < 8 && base + lane < P && !ovf) {
+			uint32_t s = g_head[base + lane];
+			if (s) { s0 = s - 1u; s = g_next[s0]; }
+			if (s) { s1 = s - 1u; s = g_next[s1]; }
+			if (s) { s2 = s - 1u; s = g_next[s2]; }
+			if (s) { s3 = s - 1u; s = g_next[s3]; }
+			rest = s;
+			// sort the four (NONE = largest) ascending
+			uint32_t lo, hi;
+#define SGS_CSWAP(A_, B_) lo = A_ < B_ ? A_ : B_; hi = A_ < B_ ? B_ : A_; A_ = lo; B_ = hi
+			SGS_CSWAP(s0, s1); SGS_CSWAP(s2, s3); SGS_CSWAP(s0, s2); SGS_CSWAP(s1, s3); SGS_CSWAP(s1, s2);
+#undef SGS_CSWAP
+		}
+		for (int c = lane; c < C4; c += 64) {
+			float4 va[8], vb[8];
+#pragma unroll
+			for (int g = 0; g < 8; g++) {   // unconditional loads (an empty list reads row 0 and discards it): all sixteen in flight
+				const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)s0, g), b2 = (uint32_t)__builtin_amdgcn_readlane((int)s1, g);
+				va[g] = frows[(size_t)(a == NONE ? 0u : a) * C4 + c];
+				vb[g] = frows[(size_t)(b2 == NONE ? (a == NONE ? 0u : a) : b2) * C4 + c];
+			}
+#pragma unroll
+			for (int g = 0; g < 8; g++) {
+				if (base + g >= P) break;
+				const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)s0, g), b2 = (uint32_t)__builtin_amdgcn_readlane((int)s1, g);
+				const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)s2, g), d2 = (uint32_t)__builtin_amdgcn_readlane((int)s3, g);
+				uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rest, g);
+				float4 acc = a == NONE ? make_float4(0.f, 0.f, 0.f, 0.f) : va[g];
+				if (b2 != NONE) { acc.x += vb[g].x; acc.y += vb[g].y; acc.z += vb[g].z; acc.w += vb[g].w; }
+				if (c2 != NONE) {
+					const float4 v = frows[(size_t)c2 * C4 + c];
+					acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+				}
+				if (d2 != NONE) {
+					const float4 v = frows[(size_t)d2 * C4 + c];
+					acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+				}
+				while (r) {
+					const float4 v = frows[(size_t)(r - 1u) * C4 + c];
+					acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+					r = g_next[r - 1u];
+				}
+				out[(size_t)(base + g) * C4 + c] = acc;
+			}
+		}
+	}
+}
 
 struct StagedEntryG {
 	float a2, b2, c2, o;
@@ -1063,13 +1197,20 @@ bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 }
 
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products, size_t clear_dcolor_floats, bool two_kernels)
+				      bool fp32_products, size_t clear_dcolor_floats, bool two_kernels, const BwdRowBuffers& rowbuf)
 {
 	const int ntiles = a.gx * a.gy;
+	// the pre-pass zero-fills one buffer on the side: dL_dcolors where the colour gradient is summed with atomics, the per-Gaussian
+	// list heads (4 B per Gaussian) where it is gathered from slot rows
+	float* clear_ptr = clear_dcolor_floats ? a.dL_dcolors : nullptr;
+	size_t clear_floats = clear_dcolor_floats;
+	if (!two_kernels && rowbuf.frows) {
+		clear_ptr = reinterpret_cast<float*>(rowbuf.head);
+		clear_floats = ((size_t)a.P + 3) & ~(size_t)3;
+	}
 	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
 						 const_cast<float*>(a.final_T), const_cast<uint32_t*>(a.n_contrib),
-						 arena, lay, a.W, a.H, a.gx, a.gy, clear_dcolor_floats ? a.dL_dcolors : nullptr,
-						 clear_dcolor_floats, a.tile_order);
+						 arena, lay, a.W, a.H, a.gx, a.gy, clear_ptr, clear_floats, a.tile_order);
 	// (The pre-pass takes its tiles longest-first by the forward's own work-list lengths, like the forward's.  The three
 	// kernels below do NOT: measured, that order costs them their locality -- neighbouring tiles share feature rows and
 	// colour-gradient rows in an XCD's L2 -- dcolor 1.10 -> 1.30 ms, dot 0.86 -> 1.07, profiles/r04_backward_tile_order.txt)
@@ -1085,18 +1226,26 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
 	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows
 	if (!two_kernels) {   // round 5: one kernel, one read of the gradient for both products
-		if (fp32_products)
-			hipLaunchKernelGGL(bwd_fused_kernel<true>, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows,
-					   a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
-		else if (g_bwd_dbg == 0)
-			hipLaunchKernelGGL(bwd_fused_kernel<false>, dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows,
-					   a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
-#define SGS_DBG_CASE(D_) \
-		else if (g_bwd_dbg == D_) \
-			hipLaunchKernelGGL((bwd_fused_kernel<false, D_>), dim3(txcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id, rows, \
-					   a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, txcd, ntiles);
-		SGS_DBG_CASE(1) SGS_DBG_CASE(2) SGS_DBG_CASE(3) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15)
+		const dim3 grid(txcd * 8), block(512);
+#define SGS_FUSED_ARGS a.ranges, table, nact, act_id, rows, a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, rowbuf.frows, rowbuf.head, rowbuf.next, \
+		       counter, a.W, a.H, a.C, a.gx, txcd, ntiles, get_sweep_trace()
+		const bool rows_mode = rowbuf.frows != nullptr;
+		if (g_bwd_dbg != 0 && !fp32_products) {
+			switch (g_bwd_dbg) {
+#define SGS_DBG_CASE(D_) case D_: if (rows_mode) hipLaunchKernelGGL((bwd_fused_kernel<false, true, D_>), grid, block, 0, st, SGS_FUSED_ARGS); \
+				  else hipLaunchKernelGGL((bwd_fused_kernel<false, false, D_>), grid, block, 0, st, SGS_FUSED_ARGS); break;
+			SGS_DBG_CASE(2) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15) SGS_DBG_CASE(16)
 #undef SGS_DBG_CASE
+			default: break;
+			}
+		} else if (fp32_products) {
+			if (rows_mode) hipLaunchKernelGGL((bwd_fused_kernel<true, true>), grid, block, 0, st, SGS_FUSED_ARGS);
+			else hipLaunchKernelGGL((bwd_fused_kernel<true, false>), grid, block, 0, st, SGS_FUSED_ARGS);
+		} else {
+			if (rows_mode) hipLaunchKernelGGL((bwd_fused_kernel<false, true>), grid, block, 0, st, SGS_FUSED_ARGS);
+			else hipLaunchKernelGGL((bwd_fused_kernel<false, false>), grid, block, 0, st, SGS_FUSED_ARGS);
+		}
+#undef SGS_FUSED_ARGS
 	} else {
 #define SGS_LAUNCH_BWD(DCOL_, DOT_)                                                                              \
 	hipLaunchKernelGGL(DCOL_, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id,                 \
@@ -1115,6 +1264,9 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
 			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
 			   a.dL_dopacity, counter, a.W, a.H, a.gx, txcd, ntiles);
+	if (!two_kernels && rowbuf.frows)   // every row of dL_dcolors, once (zeros if the work list overflowed: the fallback below adds into them)
+		hipLaunchKernelGGL(bwd_gather_rows_kernel, dim3(2048), dim3(256), 0, st, rowbuf.head, rowbuf.next, (const float4*)rowbuf.frows,
+				   (float4*)a.dL_dcolors, counter, a.P, a.C / 4);
 	e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	return launch_blend_backward(st, a, counter);   // runs only if the work list overflowed

@@ -1383,6 +1383,7 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 
 static unsigned long long* g_sweep_trace = nullptr;   // debug only (sgs_debug_set_sweep_trace)
 void set_sweep_trace(void* device_words) { g_sweep_trace = (unsigned long long*)device_words; }
+unsigned long long* get_sweep_trace() { return g_sweep_trace; }
 
 hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, char* arena,
 				      const SplitArena& lay, void (*mark)(void*), void* mark_user,
