@@ -194,7 +194,9 @@ def forward(means3D, opacities, view, proj, campos, W, H, tanfovx, tanfovy, bg, 
     return r
 
 
-def blend_backward(fwd, bg, dL_dout, W, H):
+def blend_backward(fwd, bg, dL_dout, W, H, tile_lo=None, tile_hi=None):
+    """tile_lo / tile_hi: only those tiles' pixels are walked (= the backward for a dL_dout that is zero elsewhere; final_T and
+    n_contrib need only be valid there)."""
     feats = fwd["features"]
     P, Cn = feats.shape
     dL_dout = _c32(dL_dout)
@@ -205,16 +207,17 @@ def blend_backward(fwd, bg, dL_dout, W, H):
         C.c_int(P), C.c_int(W), C.c_int(H), C.c_int(Cn), _p(fwd["ranges"]), _p(fwd["point_list"]),
         _p(bg), _p(fwd["means2D"]), _p(fwd["conic_opacity"]), _p(feats), _p(fwd["final_T"]),
         _p(fwd["n_contrib"]), _p(dL_dout), _p(g["dL_dmean2D"]), _p(g["dL_dconic"]),
-        _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
+        _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), C.c_int(0 if tile_lo is None else tile_lo),
+        C.c_int(((W + 15) // 16) * ((H + 15) // 16) if tile_hi is None else tile_hi))
     return g
 
 
 def backward(fwd, dL_dout, means3D, view, proj, campos, W, H, tanfovx, tanfovy, bg, scales=None,
-             rotations=None, scale_modifier=1.0, cov3D_precomp=None, shs=None, sh_degree=0):
+             rotations=None, scale_modifier=1.0, cov3D_precomp=None, shs=None, sh_degree=0, tile_lo=None, tile_hi=None):
     """Whole Rasterizer::backward (CR/rasterizer_impl.cu:345-441), runtime C."""
     means3D = _c32(means3D)
     P = means3D.shape[0]
-    g = blend_backward(fwd, bg, dL_dout, W, H)
+    g = blend_backward(fwd, bg, dL_dout, W, H, tile_lo, tile_hi)
     scales, rotations, shs = _c32(scales), _c32(rotations), _c32(shs)
     M = 0 if shs is None else shs.shape[1]
     cov3Ds = _c32(cov3D_precomp) if cov3D_precomp is not None else fwd["cov3D"]

@@ -29,6 +29,7 @@
 // (launched behind them, gated on the same flag) do the work.
 #include "sgs_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace sgs {
 
@@ -622,31 +623,29 @@ constexpr int GROW = 260;                   // dwords per channel row of the tra
 constexpr int GTILE = 32 * GROW + 32;       // rows 16 .. 31 start 32 dwords later: the two lane halves of a transposing store hit different banks
 __device__ __forceinline__ int g_row(int c) { return c * GROW + (c >> 4) * 32; }
 
-// ROWS (the default): dL/dF leaves as plain stores into a scratch row per work-list SLOT, `frows[slot][C]`, and the chunk's
-// entries link their slots into per-Gaussian lists (g_head[id] / g_next[slot], values = slot + 1, 0 = end); bwd_gather_rows_kernel
-// then writes every row of dL_dcolors exactly once.  !ROWS: one coalesced 128-B atomic row per (entry, 32 channels) into the
-// zero-filled dL_dcolors -- 233 M lane atomics at cfg3, which the L2's atomic units retire at ~330 G/s: 0.7 ms of a 1.6 ms kernel.
-template <bool FP32, bool ROWS, int DBG = 0>   // DBG (development ablations, wrong results): 1 no pair exchange, 2 no global atomics / row stores, 4 no products, 8 no transposing stores
+template <bool FP32, int DBG = 0>   // DBG (development, wrong results): 2 no global atomics, 4 no products, 8 no transposing stores, 16 phase stamps
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_fused_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const float* Wrows, const float* __restrict__ features, const float* __restrict__ bg,
 	const float* __restrict__ dL_dpix, float* Drows, float* __restrict__ dL_dcolors,
-	float* __restrict__ frows, uint32_t* __restrict__ g_head, uint32_t* __restrict__ g_next,
-	const uint32_t* __restrict__ counter, int W, int H, int C, int gx, int per_xcd, int ntiles,
+	const uint32_t* __restrict__ counter, uint32_t capacity, int W, int H, int C, int gx, int per_xcd, int ntiles,
 	unsigned long long* __restrict__ trace)
 {
-	if (counter[1] != 0u) return;
 	const int b = blockIdx.x;
+	// (XCD bands, not the forward's longest-first order: measured, that order is 1.5 % slower here too -- neighbouring tiles share
+	// feature rows in an XCD's L2 -- profiles/r05_backward_fused.txt)
 	const int tile = (b & 7) * per_xcd + (b >> 3);
-	if (tile >= ntiles) return;
+	// (the overflow word is NOT tested here: a dependent load in front of everything costs every workgroup a memory round trip;
+	// it travels with the first chunk's loads below.  A first chunk beyond the arena's capacity means overflow without asking.)
+	if (tile >= ntiles || ((uint32_t)tile + 1u) * 128u > capacity) return;
 	const int t = threadIdx.x;
 	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 	const int l31 = lane & 31, h = lane >> 5;
 	// DBG & 16 (tools/bwd_phases.py): shader-clock stamps at the phase boundaries of an iteration, summed per wave.  s_memtime is an
 	// SMEM access (reading it drains lgkmcnt), so the stamps cost LDS overlap: read the shares, not the total
 	constexpr bool PH = (DBG & 16) != 0;
-	uint32_t ph[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	uint32_t ph[20] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 	uint32_t ph_prev = PH ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
 #define SGS_PH(K_)                                                          \
 	if (PH) {                                                           \
@@ -657,13 +656,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const int mblk = wave & 3, kh = wave >> 2;   // W g^T: this wave's block of 32 entries and its half of the 256 px' (= row parity)
 	const int tx = tile % gx, ty = tile / gx;
 	const uint32_t HW = (uint32_t)H * (uint32_t)W;
-	const uint32_t chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
-	const int total = (int)nact[tile];
 	const int nsl = C >> 5;
 
 	__shared__ __attribute__((aligned(16))) uint32_t sF[2][CHUNK * LDQ];   // the chunk's feature rows of a slab (A of D), double buffered
 	__shared__ __attribute__((aligned(16))) uint32_t sG[2][GTILE];         // a slab transposed: [c][256 px'], double buffered
-	__shared__ __attribute__((aligned(16))) float sX[2][4][16 * 64];       // the upper K half's partial dL/dF tiles, [entry block][register][lane]
+	__shared__ __attribute__((aligned(16))) float sX[2][4][2][8 * 64];     // partial dL/dF tiles crossing to the other K half: [entry block][destination half][register][lane]
 	__shared__ uint32_t s_id[CHUNK];
 
 	// this lane's pixel px' = 32 wave + l31 and its sixteen channels 16 h .. 16 h + 15 of every slab
@@ -677,82 +674,97 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const int rd = g_row(l31) + 64 * kh + 8 * h;         // W g^T's B operand, dwords: row c = l31, px' 128 kh + 16 h .. of block 0 (+ 16 j)
 	const int rdf = g_row(l31) + 128 * kh + 16 * h;      // (FP32) floats (+ 32 j)
 
+	float pg[16];
+	auto fetch_g = [&](int c0) __attribute__((always_inline)) {
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+			const_cast<float*>(dL_dpix + (size_t)c0 * HW), 0, 0xFFFFFFFF, 0x00020000);
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			pg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, g_offb, (uint32_t)j * HW * 4u, 0));
+	};
+
+	// Every tile has at least one entry (the closing background entry), and its first chunk sits at slot 128 tile: everything the
+	// first chunk needs -- the gradient's first slab, the entry ids, the weight rows -- is requested in ONE round trip, beside the
+	// entry count itself (masks are applied when it has arrived).  Written the obvious way (count, then ids, then pointers, then
+	// rows) a workgroup spent four dependent round trips, 13 us, before its first product: 16 % of the kernel.
+	int total = 0x7fffffff;
+	uint32_t chunk_base = 0u;
 	for (int ci = 0; ci * CHUNK < total; ci++) {
+		const uint32_t cstart = ci == 0 ? (uint32_t)tile * 128u : table[chunk_base + (uint32_t)ci];
+		SGS_PH(9)
+		fetch_g(0);
+		const uint32_t my_id = act_id[cstart + (uint32_t)(t & (CHUNK - 1))];   // (slots beyond the count: this chunk's own, unused memory)
+		uint32_t f_id[2];
+#pragma unroll
+		for (int i = 0; i < 2; i++) f_id[i] = act_id[cstart + (uint32_t)((t + 512 * i) >> 3)];
+		// ---- the chunk's weights for W g^T: entries 32 mblk + l31, px' 128 kh + 32 j + 16 h .. + 15 (j = 0 .. 3), resident all chunk
+		float4 wraw[4][4];
+		{
+			const float* wr = Wrows + (size_t)(cstart + (uint32_t)(32 * mblk + l31)) * 256 + 128 * kh + 16 * h;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) wraw[j][i] = *reinterpret_cast<const float4*>(wr + 32 * j + 4 * i);
+		}
+		if (ci == 0) {
+			const uint32_t overflow = counter[1];
+			total = (int)nact[tile];
+			chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+			if (overflow != 0u) return;   // (uniform; nothing has been written yet) the per-chunk kernel behind this one does the work
+		}
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
 		const int mb = (cnt + 31) >> 5;
 		const bool e_on = mblk < mb;   // this wave's entry block holds entries
-		const uint32_t cstart = sgs_chunk_start(table, chunk_base, (uint32_t)tile, (uint32_t)ci);
+		if (PH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		SGS_PH(10)   // first round trip (count, ids, weights, gradient slab 0)
 		__syncthreads();   // the previous chunk is done with s_id, sF, sG, sX
-		uint32_t link_next = 0u;
-		if (t < CHUNK) {
-			const uint32_t id = t < cnt ? act_id[cstart + t] : NO_ID;
-			s_id[t] = id;
-			// (ROWS) this slot joins its Gaussian's list; the returned previous head is stored at the END of the chunk, so
-			// nobody waits for the atomic's round trip
-			if (ROWS && id < NO_ID) link_next = atomicExch(&g_head[id], cstart + (uint32_t)t + 1u);
+		if (t < CHUNK) s_id[t] = t < cnt ? my_id : NO_ID;
+		const float* frow[2];
+		bool fvalid[2];
+#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			const int q = t + 512 * i, e = q >> 3, f = q & 7;
+			fvalid[i] = e < cnt;
+			const uint32_t id = fvalid[i] ? f_id[i] : NO_ID;
+			frow[i] = ((id == BG_ID || id == NO_ID) ? bg : features + (size_t)id * C) + 4 * f;
 		}
-
-		// ---- the chunk's weights for W g^T: entries 32 mblk + l31, px' 128 kh + 32 j + 16 h .. + 15 (j = 0 .. 3), resident all chunk
+		float4 pf[2];
+		auto fetch_f = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+			for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
+		};
+		fetch_f(0);
+		SGS_PH(11)   // barrier, ids, row pointers
 		uint32_t wh[4][8], wl[4][8];   // (split) bf16 pairs of positions 2 i, 2 i + 1
 		float wv[4][16];               // (FP32)
 		{
-			const int e = 32 * mblk + l31;
-			const bool ok = e < cnt;
-			// (unconditional loads on clamped rows: a branch around a load makes the compiler drain the load counter)
-			const float* wr = Wrows + (size_t)(cstart + (uint32_t)(ok ? e : 0)) * 256 + 128 * kh + 16 * h;
+			const bool ok = 32 * mblk + l31 < cnt;
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				float4 v[4];
-#pragma unroll
-				for (int i = 0; i < 4; i++) v[i] = mask4(*reinterpret_cast<const float4*>(wr + 32 * j + 4 * i), ok);
+			for (int j = 0; j < 4; j++)
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
+					const float4 v = mask4(wraw[j][i], ok);
 					if (FP32) {
-						wv[j][4 * i] = v[i].x;
-						wv[j][4 * i + 1] = v[i].y;
-						wv[j][4 * i + 2] = v[i].z;
-						wv[j][4 * i + 3] = v[i].w;
+						wv[j][4 * i] = v.x;
+						wv[j][4 * i + 1] = v.y;
+						wv[j][4 * i + 2] = v.z;
+						wv[j][4 * i + 3] = v.w;
 					} else {
-						split_pair(v[i].x, v[i].y, wh[j][2 * i], wl[j][2 * i]);
-						split_pair(v[i].z, v[i].w, wh[j][2 * i + 1], wl[j][2 * i + 1]);
+						split_pair(v.x, v.y, wh[j][2 * i], wl[j][2 * i]);
+						split_pair(v.z, v.w, wh[j][2 * i + 1], wl[j][2 * i + 1]);
 					}
 				}
-			}
 		}
 		f32x16 acc[4];
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-		f32x16 held;   // (lower half) its own partial dL/dF of the previous slab, until the upper half's has crossed the barrier
+		float held[8];   // this wave's own half of its partial dL/dF tile (lower K half: registers 0 .. 7, upper: 8 .. 15), a slab long
 #pragma unroll
-		for (int r = 0; r < 16; r++) held[r] = 0.f;
-		__syncthreads();   // s_id visible
-		const float* frow[2];
-		bool fvalid[2];
-#pragma unroll
-		for (int i = 0; i < 2; i++) {
-			const int q = t + 512 * i, e = q >> 3, f = q & 7;
-			const uint32_t id = s_id[e];
-			fvalid[i] = id != NO_ID;
-			frow[i] = ((id == BG_ID || id == NO_ID) ? bg : features + (size_t)id * C) + 4 * f;
-		}
-		// this lane's sixteen output rows of W g^T (the accumulator registers' entries), as gradient row pointers; null = no row
-		float pg[16];
-		float4 pf[2];
+		for (int r = 0; r < 8; r++) held[r] = 0.f;
 		uint32_t gh[8], gl[8];
 		float gv[16];
-		auto fetch_g = [&](int c0) __attribute__((always_inline)) {
-			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-				const_cast<float*>(dL_dpix + (size_t)c0 * HW), 0, 0xFFFFFFFF, 0x00020000);
-#pragma unroll
-			for (int j = 0; j < 16; j++)
-				pg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, g_offb, (uint32_t)j * HW * 4u, 0));
-		};
-		auto fetch_f = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-			for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
-		};
 		auto stage_f = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
 			for (int i = 0; i < 2; i++) {
@@ -811,6 +823,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 							acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, gv[4 * s4 + 3], acc[m], 0, 0, 0);
 						}
 			} else {
+				// the feature operand of the NEXT (k pair, block) is read from LDS before the current six products are issued: read
+				// where it is used, an LDS round trip stood in front of every group of six and a lone wave's matrix phase ran at 60 %
+				const uint32_t* fa0 = &sF[buf][l31 * LDQ + 8 * h];
+				Op2 nah = lds_op2(fa0), nal = lds_op2(fa0 + 16);
 #pragma unroll
 				for (int sp = 0; sp < 2; sp++) {
 					Op2 bh, bl;
@@ -821,8 +837,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
 					for (int m = 0; m < 4; m++)
 						if (m < mb) {
-							const uint32_t* fa = &sF[buf][(32 * m + l31) * LDQ + 8 * h + 4 * sp];
-							const Op2 ah = lds_op2(fa), al = lds_op2(fa + 16);
+							const Op2 ah = nah, al = nal;
+							const bool wrap = m + 1 >= mb;   // (uniform) the next operand is block 0 of the second k pair
+							if (!(wrap && sp == 1)) {
+								const uint32_t* fn = fa0 + (wrap ? 4 : 32 * (m + 1) * LDQ + 4 * sp);
+								nah = lds_op2(fn);
+								nal = lds_op2(fn + 16);
+							}
 							acc[m] = SGS_MFMA_BF16(al.k0, bh.k0, acc[m]);
 							acc[m] = SGS_MFMA_BF16(ah.k0, bl.k0, acc[m]);
 							acc[m] = SGS_MFMA_BF16(ah.k0, bh.k0, acc[m]);
@@ -833,8 +854,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 				}
 			}
 		};
-		// E: this wave's partial dL/dF[32 mblk ..][slab's 32 c] over its 128 px' from the slab tile `buf`; the upper half parks
-		// it in sX[buf], the lower half holds it in registers
+		// E: this wave's partial dL/dF[32 mblk ..][slab's 32 c] over its 128 px' from the slab tile `buf`.  The two K halves of an
+		// entry block split the FINISHING of the tile: the lower half's wave keeps accumulator registers 0 .. 7 and parks 8 .. 15 in
+		// sX for its partner, the upper half's wave the other way round (with all sixteen finished by the lower half, its waves spent
+		// a quarter of every iteration on the atomics while the upper half waited at the barrier)
 		auto prod_e = [&](int buf) __attribute__((always_inline)) {
 			if (!e_on) return;
 			f32x16 a2;
@@ -856,80 +879,90 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 					}
 			} else {
 				const uint32_t* gt = &sG[buf][rd];
+				Op2 nbh = lds_op2(gt), nbl = lds_op2(gt + 128);   // (read one (block, k pair) ahead of the products, as in D)
 #pragma unroll
-				for (int j = 0; j < 4; j++)
-#pragma unroll
-					for (int sp = 0; sp < 2; sp++) {
-						const Op2 bh = lds_op2(gt + 16 * j + 4 * sp), bl = lds_op2(gt + 128 + 16 * j + 4 * sp);
-						Op2 ah, al;
-						ah.k0 = __builtin_bit_cast(s16x4, uint2{wh[j][4 * sp], wh[j][4 * sp + 1]});
-						ah.k1 = __builtin_bit_cast(s16x4, uint2{wh[j][4 * sp + 2], wh[j][4 * sp + 3]});
-						al.k0 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp], wl[j][4 * sp + 1]});
-						al.k1 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp + 2], wl[j][4 * sp + 3]});
-						a2 = SGS_MFMA_BF16(al.k0, bh.k0, a2);
-						a2 = SGS_MFMA_BF16(ah.k0, bl.k0, a2);
-						a2 = SGS_MFMA_BF16(ah.k0, bh.k0, a2);
-						a2 = SGS_MFMA_BF16(al.k1, bh.k1, a2);
-						a2 = SGS_MFMA_BF16(ah.k1, bl.k1, a2);
-						a2 = SGS_MFMA_BF16(ah.k1, bh.k1, a2);
+				for (int q = 0; q < 8; q++) {
+					const int j = q >> 1, sp = q & 1;
+					const Op2 bh = nbh, bl = nbl;
+					if (q + 1 < 8) {
+						nbh = lds_op2(gt + 16 * ((q + 1) >> 1) + 4 * ((q + 1) & 1));
+						nbl = lds_op2(gt + 128 + 16 * ((q + 1) >> 1) + 4 * ((q + 1) & 1));
 					}
+					Op2 ah, al;
+					ah.k0 = __builtin_bit_cast(s16x4, uint2{wh[j][4 * sp], wh[j][4 * sp + 1]});
+					ah.k1 = __builtin_bit_cast(s16x4, uint2{wh[j][4 * sp + 2], wh[j][4 * sp + 3]});
+					al.k0 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp], wl[j][4 * sp + 1]});
+					al.k1 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp + 2], wl[j][4 * sp + 3]});
+					a2 = SGS_MFMA_BF16(al.k0, bh.k0, a2);
+					a2 = SGS_MFMA_BF16(ah.k0, bl.k0, a2);
+					a2 = SGS_MFMA_BF16(ah.k0, bh.k0, a2);
+					a2 = SGS_MFMA_BF16(al.k1, bh.k1, a2);
+					a2 = SGS_MFMA_BF16(ah.k1, bl.k1, a2);
+					a2 = SGS_MFMA_BF16(ah.k1, bh.k1, a2);
+				}
 			}
+			float* xo = &sX[buf][mblk][kh ^ 1][lane];
 			if (kh) {
-				if (!(DBG & 1)) {
 #pragma unroll
-					for (int r = 0; r < 16; r++) sX[buf][mblk][r * 64 + lane] = a2[r];
+				for (int r = 0; r < 8; r++) {
+					xo[r * 64] = a2[r];
+					held[r] = a2[8 + r];
 				}
 			} else {
-				held = a2;
+#pragma unroll
+				for (int r = 0; r < 8; r++) {
+					xo[r * 64] = a2[8 + r];
+					held[r] = a2[r];
+				}
 			}
 		};
-		// B (lower half): `held` + the upper half's tile in sX[buf] (a barrier old) = dL/dF of the slab at channel cb: atomics
+		// B: `held` + the partner's registers in sX[buf] (a barrier old) = this wave's eight rows of dL/dF of the slab at channel cb:
+		// one coalesced 128-B atomic row per (entry, 32 channels)
 		auto finish_e = [&](int buf, int cb) __attribute__((always_inline)) {
 			if (!e_on) return;
-			// (the row index is laundered: left loop invariant, the sixteen ids and row addresses are tabulated per chunk --
-			// 48 registers the kernel does not have; they spill and come back from scratch in every slab)
-			int eb = 32 * mblk + 4 * h;
+			// (the row index is laundered: left loop invariant, the ids and row addresses are tabulated per chunk -- registers the
+			// kernel does not have; they spill and come back from scratch in every slab)
+			int eb = 32 * mblk + 16 * kh + 4 * h;   // accumulator register 8 kh + r of half h = entry row 16 kh + (r & 3) + 8 (r >> 2) + 4 h
 			asm volatile("" : "+v"(eb));
-			if (ROWS) {
-				// rows of slots that hold no entry (beyond cnt, the background's) belong to this tile's chunk all the same and
-				// are never linked: every register is stored, no test
-				float* const col = frows + (size_t)(cstart + (uint32_t)eb) * C + cb + l31;
+			const float* xi = &sX[buf][mblk][kh][lane];
+			float v[8];
+			uint32_t id[8];
 #pragma unroll
-				for (int r = 0; r < 16; r++) {
-					const float v = held[r] + ((DBG & 1) ? 0.f : sX[buf][mblk][r * 64 + lane]);
-					if (!(DBG & 2) || v == 12345.678f) col[(size_t)((r & 3) + 8 * (r >> 2)) * C] = v;
-				}
-			} else {
-				float* const col = dL_dcolors + cb + l31;
+			for (int r = 0; r < 8; r++) {   // sixteen LDS reads in flight, one wait
+				v[r] = xi[r * 64];
+				id[r] = s_id[eb + (r & 3) + 8 * (r >> 2)];
+			}
+			float* const col = dL_dcolors + cb + l31;
 #pragma unroll
-				for (int r = 0; r < 16; r++) {
-					const float v = held[r] + ((DBG & 1) ? 0.f : sX[buf][mblk][r * 64 + lane]);
-					const uint32_t id = s_id[eb + (r & 3) + 8 * (r >> 2)];
-					if (id < NO_ID && (!(DBG & 2) || v == 12345.678f)) atomicAdd(col + (size_t)id * C, v);
-				}
+			for (int r = 0; r < 8; r++) {
+				const float sum = held[r] + v[r];
+				if (id[r] < NO_ID && (!(DBG & 2) || sum == 12345.678f)) atomicAdd(col + (size_t)id[r] * C, sum);
 			}
 		};
 
-		fetch_f(0);
-		fetch_g(0);
+		SGS_PH(12)   // weights split
 		stage_f(0);
+		SGS_PH(13)   // second round trip (feature pieces) + staging
 		__syncthreads();
+		SGS_PH(14)
 		// iteration s: slab s is taken and multiplied into D, W g^T of slab s - 1 runs from the tile the last barrier published,
-		// the lower half finishes slab s - 2.  The atomics go out BEFORE the next slab's loads: the memory counter retires in
-		// order, so the wait for those loads at the top of the next iteration also covers atomics that are an iteration old by
-		// then -- issued behind the loads they would be the youngest entries and every slab would wait for their round trip.
-		// (One instance of every phase in program order, each behind a uniform branch: with the two halves' sequences written
-		// as two arms the compiler allocates them separately and copies ~100 registers where they join.)
+		// slab s - 2 is finished.  The atomics go out BEFORE the next slab's gradient loads: the memory counter retires in order,
+		// so the wait for those loads at the top of the next iteration also covers atomics that are an iteration old by then --
+		// issued behind the loads they would be the youngest entries and every slab would wait for their round trip.  The
+		// feature pieces are requested FIRST for the same reason: they are staged at the end of the iteration.
+		// The two waves of a SIMD (w and w + 4) run W g^T at opposite ends of the iteration, so one's VALU / LDS phases lie beside
+		// the other's matrix phases.  (One instance of every phase in program order, each behind a uniform branch: with the two
+		// halves' sequences written as two arms the compiler allocates them separately and copies ~100 registers where they join.)
 		for (int s = 0; s < nsl; s++) {
 			const int cur = s & 1;
 			const bool more = s + 1 < nsl;
-			// the next slab's feature pieces are requested FIRST: they are staged at the end of this iteration, and the memory
-			// counter retires in order -- requested behind the gradient loads, waiting for them drained those as well and the
-			// gradient's prefetch distance shrank to half an iteration
 			SGS_PH(9)
 			if (more) fetch_f(32 * (s + 1));
 			SGS_PH(0)
+			if (kh && s >= 2) finish_e(cur, 32 * (s - 2));
+			if (DBG & 32) __builtin_amdgcn_s_setprio(2);
 			if (kh && s >= 1) prod_e(cur ^ 1);
+			if (DBG & 32) __builtin_amdgcn_s_setprio(0);
 			SGS_PH(1)
 			take_slab(cur);
 			SGS_PH(2)
@@ -937,24 +970,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 			SGS_PH(3)
 			if (more) fetch_g(32 * (s + 1));
 			SGS_PH(4)
+			if (DBG & 32) __builtin_amdgcn_s_setprio(2);
 			prod_d(cur);
 			SGS_PH(5)
 			if (!kh && s >= 1) prod_e(cur ^ 1);
+			if (DBG & 32) __builtin_amdgcn_s_setprio(0);
 			SGS_PH(6)
 			if (more) stage_f(cur ^ 1);
 			SGS_PH(7)
 			__syncthreads();
 			SGS_PH(8)
 		}
-		if (kh) {
-			prod_e((nsl & 1) ^ 1);
-		} else {
-			if (nsl >= 2) finish_e(nsl & 1, 32 * (nsl - 2));
-			prod_e((nsl & 1) ^ 1);
-		}
+		SGS_PH(9)
+		if (nsl >= 2) finish_e(nsl & 1, 32 * (nsl - 2));
+		SGS_PH(15)
+		prod_e((nsl & 1) ^ 1);
+		SGS_PH(16)
 		__syncthreads();
-		if (!kh) finish_e((nsl & 1) ^ 1, 32 * (nsl - 1));
-		if (ROWS && t < cnt) g_next[cstart + t] = link_next;
+		SGS_PH(17)
+		finish_e((nsl & 1) ^ 1, 32 * (nsl - 1));
+		SGS_PH(18)
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 			if (m < mb)
@@ -964,82 +999,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 					if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 32 * wave + l31] = acc[m][r];
 				}
 	}
-	if (PH && trace && lane == 0) {
-		SGS_PH(9)
-		unsigned long long* o = trace + ((size_t)b * 8 + wave) * 12;
+	if (PH && trace) {
+		if (PH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		SGS_PH(19)   // D rows written
+		if (lane == 0) {
+			unsigned long long* o = trace + ((size_t)b * 8 + wave) * 24;
 #pragma unroll
-		for (int k = 0; k < 10; k++) o[k] = ph[k];
-		o[10] = (unsigned long long)(((total + CHUNK - 1) / CHUNK) * nsl);   // iterations with a slab
-		o[11] = (unsigned long long)wave | ((unsigned long long)total << 8);
+			for (int k = 0; k < 20; k++) o[k] = ph[k];
+			o[20] = (unsigned long long)(((total + CHUNK - 1) / CHUNK) * nsl);   // iterations with a slab
+			o[21] = (unsigned long long)wave | ((unsigned long long)total << 8);
+			o[22] = wall_clock64();
+		}
 	}
 #undef SGS_PH
 }
 #undef SGS_MFMA_BF16
-
-// ---- 2 + 3, last step (ROWS): dL_dcolors[id][:] = the sum of the rows of the slots on Gaussian id's list, zero for an empty list:
-// every row of the (P, C) gradient is written exactly once, by plain stores -- no zero fill of the 2 GB buffer in front of the
-// backward, no atomics, and the sum does not depend on the order in which the tiles linked themselves (a list's first four
-// slots are sorted; a Gaussian that is active in more than four tiles adds the rest in arrival order).  A wave takes eight
-// consecutive Gaussians: lanes 0 .. 7 walk the eight lists at once, then all lanes move the rows, the loads of all eight issued
-// before the first is used.  `overflow` (the work list did not fit: the per-chunk kernel, launched behind this one, does the
-// backward with atomics): all rows are zero-filled instead.
-__global__ __launch_bounds__(256) void bwd_gather_rows_kernel(const uint32_t* __restrict__ g_head, const uint32_t* __restrict__ g_next,
-							      const float4* __restrict__ frows, float4* __restrict__ out,
-							      const uint32_t* __restrict__ counter, int P, int C4)
-{
-	const bool ovf = counter[1] != 0u;
-	const int lane = threadIdx.x & 63;
-	const int nwaves = (int)gridDim.x * 4;
-	constexpr uint32_t NONE = 0xFFFFFFFFu;
-	for (int base = (((int)blockIdx.x * 256 + (int)threadIdx.x) >> 6) * 8; base < P; base += nwaves * 8) {
-		uint32_t s0 = NONE, s1 = NONE, s2 = NONE, s3 = NONE, rest = 0u;
-		if (lane < 8 && base + lane < P && !ovf) {
-			uint32_t s = g_head[base + lane];
-			if (s) { s0 = s - 1u; s = g_next[s0]; }
-			if (s) { s1 = s - 1u; s = g_next[s1]; }
-			if (s) { s2 = s - 1u; s = g_next[s2]; }
-			if (s) { s3 = s - 1u; s = g_next[s3]; }
-			rest = s;
-			// sort the four (NONE = largest) ascending
-			uint32_t lo, hi;
-#define SGS_CSWAP(A_, B_) lo = A_ < B_ ? A_ : B_; hi = A_ < B_ ? B_ : A_; A_ = lo; B_ = hi
-			SGS_CSWAP(s0, s1); SGS_CSWAP(s2, s3); SGS_CSWAP(s0, s2); SGS_CSWAP(s1, s3); SGS_CSWAP(s1, s2);
-#undef SGS_CSWAP
-		}
-		for (int c = lane; c < C4; c += 64) {
-			float4 va[8], vb[8];
-#pragma unroll
-			for (int g = 0; g < 8; g++) {   // unconditional loads (an empty list reads row 0 and discards it): all sixteen in flight
-				const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)s0, g), b2 = (uint32_t)__builtin_amdgcn_readlane((int)s1, g);
-				va[g] = frows[(size_t)(a == NONE ? 0u : a) * C4 + c];
-				vb[g] = frows[(size_t)(b2 == NONE ? (a == NONE ? 0u : a) : b2) * C4 + c];
-			}
-#pragma unroll
-			for (int g = 0; g < 8; g++) {
-				if (base + g >= P) break;
-				const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)s0, g), b2 = (uint32_t)__builtin_amdgcn_readlane((int)s1, g);
-				const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)s2, g), d2 = (uint32_t)__builtin_amdgcn_readlane((int)s3, g);
-				uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rest, g);
-				float4 acc = a == NONE ? make_float4(0.f, 0.f, 0.f, 0.f) : va[g];
-				if (b2 != NONE) { acc.x += vb[g].x; acc.y += vb[g].y; acc.z += vb[g].z; acc.w += vb[g].w; }
-				if (c2 != NONE) {
-					const float4 v = frows[(size_t)c2 * C4 + c];
-					acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-				}
-				if (d2 != NONE) {
-					const float4 v = frows[(size_t)d2 * C4 + c];
-					acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-				}
-				while (r) {
-					const float4 v = frows[(size_t)(r - 1u) * C4 + c];
-					acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-					r = g_next[r - 1u];
-				}
-				out[(size_t)(base + g) * C4 + c] = acc;
-			}
-		}
-	}
-}
 
 struct StagedEntryG {
 	float a2, b2, c2, o;
@@ -1197,21 +1171,14 @@ bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 }
 
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products, size_t clear_dcolor_floats, bool two_kernels, const BwdRowBuffers& rowbuf)
+				      bool fp32_products, size_t clear_dcolor_floats, bool two_kernels)
 {
 	const int ntiles = a.gx * a.gy;
-	// the pre-pass zero-fills one buffer on the side: dL_dcolors where the colour gradient is summed with atomics, the per-Gaussian
-	// list heads (4 B per Gaussian) where it is gathered from slot rows
-	float* clear_ptr = clear_dcolor_floats ? a.dL_dcolors : nullptr;
-	size_t clear_floats = clear_dcolor_floats;
-	if (!two_kernels && rowbuf.frows) {
-		clear_ptr = reinterpret_cast<float*>(rowbuf.head);
-		clear_floats = ((size_t)a.P + 3) & ~(size_t)3;
-	}
 	hipError_t e = launch_blend_weights_rows(st, a.ranges, a.point_list, a.means2D, a.conic_opacity,
 						 const_cast<float*>(a.final_T), const_cast<uint32_t*>(a.n_contrib),
-						 arena, lay, a.W, a.H, a.gx, a.gy, clear_ptr, clear_floats, a.tile_order);
-	// (The pre-pass takes its tiles longest-first by the forward's own work-list lengths, like the forward's.  The three
+						 arena, lay, a.W, a.H, a.gx, a.gy, clear_dcolor_floats ? a.dL_dcolors : nullptr,
+						 clear_dcolor_floats, a.tile_order);
+	// (The pre-pass takes its tiles longest-first by the forward's own work-list lengths, like the forward's.  The
 	// kernels below do NOT: measured, that order costs them their locality -- neighbouring tiles share feature rows and
 	// colour-gradient rows in an XCD's L2 -- dcolor 1.10 -> 1.30 ms, dot 0.86 -> 1.07, profiles/r04_backward_tile_order.txt)
 	if (e != hipSuccess) return e;
@@ -1227,23 +1194,19 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows
 	if (!two_kernels) {   // round 5: one kernel, one read of the gradient for both products
 		const dim3 grid(txcd * 8), block(512);
-#define SGS_FUSED_ARGS a.ranges, table, nact, act_id, rows, a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, rowbuf.frows, rowbuf.head, rowbuf.next, \
-		       counter, a.W, a.H, a.C, a.gx, txcd, ntiles, get_sweep_trace()
-		const bool rows_mode = rowbuf.frows != nullptr;
+#define SGS_FUSED_ARGS a.ranges, table, nact, act_id, rows, a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, lay.capacity, a.W, a.H, a.C, a.gx, txcd, ntiles, \
+		       get_sweep_trace()
 		if (g_bwd_dbg != 0 && !fp32_products) {
 			switch (g_bwd_dbg) {
-#define SGS_DBG_CASE(D_) case D_: if (rows_mode) hipLaunchKernelGGL((bwd_fused_kernel<false, true, D_>), grid, block, 0, st, SGS_FUSED_ARGS); \
-				  else hipLaunchKernelGGL((bwd_fused_kernel<false, false, D_>), grid, block, 0, st, SGS_FUSED_ARGS); break;
-			SGS_DBG_CASE(2) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15) SGS_DBG_CASE(16)
+#define SGS_DBG_CASE(D_) case D_: hipLaunchKernelGGL((bwd_fused_kernel<false, D_>), grid, block, 0, st, SGS_FUSED_ARGS); break;
+			SGS_DBG_CASE(2) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15) SGS_DBG_CASE(16) SGS_DBG_CASE(32)
 #undef SGS_DBG_CASE
 			default: break;
 			}
 		} else if (fp32_products) {
-			if (rows_mode) hipLaunchKernelGGL((bwd_fused_kernel<true, true>), grid, block, 0, st, SGS_FUSED_ARGS);
-			else hipLaunchKernelGGL((bwd_fused_kernel<true, false>), grid, block, 0, st, SGS_FUSED_ARGS);
+			hipLaunchKernelGGL((bwd_fused_kernel<true>), grid, block, 0, st, SGS_FUSED_ARGS);
 		} else {
-			if (rows_mode) hipLaunchKernelGGL((bwd_fused_kernel<false, true>), grid, block, 0, st, SGS_FUSED_ARGS);
-			else hipLaunchKernelGGL((bwd_fused_kernel<false, false>), grid, block, 0, st, SGS_FUSED_ARGS);
+			hipLaunchKernelGGL((bwd_fused_kernel<false>), grid, block, 0, st, SGS_FUSED_ARGS);
 		}
 #undef SGS_FUSED_ARGS
 	} else {
@@ -1264,9 +1227,6 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
 			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,
 			   a.dL_dopacity, counter, a.W, a.H, a.gx, txcd, ntiles);
-	if (!two_kernels && rowbuf.frows)   // every row of dL_dcolors, once (zeros if the work list overflowed: the fallback below adds into them)
-		hipLaunchKernelGGL(bwd_gather_rows_kernel, dim3(2048), dim3(256), 0, st, rowbuf.head, rowbuf.next, (const float4*)rowbuf.frows,
-				   (float4*)a.dL_dcolors, counter, a.P, a.C / 4);
 	e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	return launch_blend_backward(st, a, counter);   // runs only if the work list overflowed

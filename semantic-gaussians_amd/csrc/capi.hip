@@ -968,7 +968,6 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 	a.dL_dconic = dL_dconic;
 	a.dL_dopacity = dL_dopacity;
 	a.dL_dcolors = dL_dcolor;
-	a.P = P;
 	{   // the order this stream's last forward left (normally the forward of this very frame): a schedule, never a result
 		static const bool no_tile_order = getenv("SGS_NO_TILE_ORDER") && atoi(getenv("SGS_NO_TILE_ORDER")) != 0;
 		a.tile_order = (!no_tile_order && cx->tile_order && cx->tile_order_cap >= (size_t)gx * gy) ? cx->tile_order : nullptr;
@@ -1005,32 +1004,19 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 			uint32_t cap = (uint64_t)hint < cap_max ? hint : (uint32_t)cap_max;
 			if (bw_mode == 2) cap = 128u * (uint32_t)((ntiles + 1) / 2);   // (tests: guaranteed overflow -> gated fallback)
 			sgs::SplitArena lay;
-			const size_t arena_bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay, 1024);   // fp32 weight rows
-			// modes 8 / 9 (experiment): the colour gradient leaves the fused kernel as one scratch row per work-list slot and is gathered per
-			// Gaussian (blend_bwd_mfma.hip): + list heads, links and cap x C floats of rows behind the arena
-			const bool rows_mode = (bw_mode == 8 || bw_mode == 9) && (num_channels & 3) == 0 && ((uintptr_t)dL_dcolor & 15u) == 0;
-			const size_t head_off = arena_bytes, head_bytes = ((((size_t)P + 3) & ~(size_t)3) * 4 + 127) & ~(size_t)127;
-			const size_t next_off = head_off + head_bytes, next_bytes = ((size_t)cap * 4 + 127) & ~(size_t)127;
-			const size_t rows_off = next_off + next_bytes, rows_bytes = (size_t)cap * (size_t)num_channels * 4;
-			const size_t bytes = rows_mode ? rows_off + rows_bytes : arena_bytes;
+			const size_t bytes = sgs::split_arena_bytes(cap, (size_t)R, ntiles, &lay, 1024);   // fp32 weight rows
 			void* scratch = nullptr;
 			hipMemPool_t pool = scratch_pool();
 			hipError_t ea = pool ? hipMallocFromPoolAsync(&scratch, bytes + 128, pool, st)
 					     : hipMallocAsync(&scratch, bytes + 128, st);
 			if (ea == hipSuccess && scratch) {
 				char* arena = align_ptr((char*)scratch);
-				sgs::BwdRowBuffers rb;
-				if (rows_mode) {
-					rb.head = (uint32_t*)(arena + head_off);
-					rb.next = (uint32_t*)(arena + next_off);
-					rb.frows = (float*)(arena + rows_off);
-					dcolor_dirty = false;   // every row of dL_dcolor is written by the gather kernel
-				}
 				const bool fold = dcolor_dirty && (dcolor_floats & 3) == 0 && ((uintptr_t)dL_dcolor & 15u) == 0;
 				if (dcolor_dirty && !fold) (void)hipMemsetAsync(dL_dcolor, 0, dcolor_floats * 4, st);
 				dcolor_dirty = false;
-				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3 || bw_mode == 5 || bw_mode == 9, fold ? dcolor_floats : 0,
-								    bw_mode == 4 || bw_mode == 5, rb);
+				// modes 0 / 2 / 3: the fused kernel (one read of the gradient); 4 / 5: rounds 2-4's two kernels (split / fp32 products)
+				e = sgs::launch_blend_backward_mfma(st, a, arena, lay, bw_mode == 3 || bw_mode == 5, fold ? dcolor_floats : 0,
+								    bw_mode == 4 || bw_mode == 5);
 				if (e == hipSuccess && cx->ensure(cx->bwd_usage_host, cx->bwd_ev)) {
 					if (hipMemcpyAsync(cx->bwd_usage_host, arena + lay.counter, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
 					    hipEventRecord(cx->bwd_ev, st) == hipSuccess)

@@ -186,7 +186,6 @@ struct BlendBwdArgs {
 	float* dL_dopacity;          // (P)
 	float* dL_dcolors;           // (P,C)
 	const uint32_t* tile_order = nullptr;   // optional: [0] = tile count, [1..] = tiles longest-first (the stream's forward wrote it)
-	int P = 0;                   // Gaussians (rows of dL_dcolors)
 };
 // `gate` (optional): device flag pair; the kernel runs only if gate[1] != 0 (fallback of the MFMA path).
 hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const uint32_t* gate = nullptr);
@@ -197,17 +196,8 @@ bool blend_backward_mfma_eligible(const BlendBwdArgs& a);
 // fp32_products: the two channel products on v_mfma_f32_32x32x2_f32 (exact fp32 products) instead of split bf16
 // clear_dcolor: a.dL_dcolors (P x C floats) is zero-filled by the first kernel instead of by the caller
 // two_kernels: rounds 2-4's form (bwd_dcolor + bwd_dot, each streaming the gradient) instead of the fused kernel
-// rowbuf (fused kernel only; all three or none): dL/dF leaves as plain stores into frows[slot][C] and a gather kernel writes every
-// row of dL_dcolors exactly once from the per-Gaussian slot lists (head: (P + 3) & ~3 words, 16-byte aligned, zero-filled by the
-// pre-pass; next: one word per work-list slot) -- dL_dcolors then needs no zero fill and receives no atomics
-struct BwdRowBuffers {
-	float* frows = nullptr;
-	uint32_t* head = nullptr;
-	uint32_t* next = nullptr;
-};
 hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, char* arena, const SplitArena& lay,
-				      bool fp32_products, size_t clear_dcolor_floats = 0, bool two_kernels = false,
-				      const BwdRowBuffers& rowbuf = BwdRowBuffers());
+				      bool fp32_products, size_t clear_dcolor_floats = 0, bool two_kernels = false);
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, const float* means3D,
 			   const int* radii, const float* shs, const uint8_t* clamped,
 			   const float* scales, const float* rotations, float mod,

@@ -185,6 +185,69 @@ def test_cfg3_backward_worklist_path_matches_chunk_kernel(cfg3):
         assert float((a - 2.0 * b).abs().max()) <= 1e-4 * float(a.abs().max())
 
 
+def test_cfg3_backward_matches_the_oracle_on_sampled_tiles(cfg3, orc):
+    """cfg3's backward with the ORACLE in the loop (CR/cuda_rasterizer/backward.cu:394-552 restated in oracle/sgs_oracle.c): dL/dout is
+    zero outside two sampled runs of tiles, so the full-size HIP backward (work-list products over all 4 941 tiles) equals the oracle's
+    backward restricted to those tiles.  Every leaf gradient at the usual bar -- 1e-4 of the largest entry -- for the default arithmetic
+    (one fused kernel, two-term bf16 products) and mode 3 (fp32 products)."""
+    from sgs_hip import raster
+    scene, cam, (P, C, W, H) = cfg3
+    s, c = scene.to(DEV), cam.to(DEV)
+    gx = (W + 15) // 16
+    runs = [(10 * gx + 20, 10 * gx + 44), (41 * gx + 50, 41 * gx + 74)]   # 2 x 24 tiles, two tile rows
+    g = torch.Generator().manual_seed(11)
+    dL = torch.zeros(C, H, W)
+    for lo, hi in runs:
+        ty, x0, x1 = lo // gx, (lo % gx) * 16, (hi - 1) % gx * 16 + 16
+        dL[:, ty * 16:ty * 16 + 16, x0:x1] = torch.randn(C, 16, x1 - x0, generator=g)
+    # the oracle: preprocess + binning of the whole frame, the T chain and the backward on the sampled tiles only
+    pre = orc.preprocess(scene.means3D.numpy(), scene.opacities.numpy(), cam.world_view_transform.numpy(),
+                         cam.full_proj_transform.numpy(), cam.camera_center.numpy(), W, H, cam.tanfovx, cam.tanfovy,
+                         scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
+                         colors_precomp=np.zeros((1, 1), np.float32))
+    binn_o = orc.binning(pre, W, H)
+    feats = scene.features.numpy()
+    bg = scene.bg[:C].numpy()
+    fwd = dict(pre)
+    fwd.update(binn_o)
+    fwd["features"] = feats
+    fwd["final_T"] = np.zeros((H, W), np.float32)
+    fwd["n_contrib"] = np.zeros((H, W), np.uint32)
+    want = None
+    for lo, hi in runs:
+        ob = orc.blend_forward(pre, binn_o, np.ascontiguousarray(feats[:, :1]), bg[:1], W, H, tile_lo=lo, tile_hi=hi)
+        ty, x0, x1 = lo // gx, (lo % gx) * 16, (hi - 1) % gx * 16 + 16
+        fwd["final_T"][ty * 16:ty * 16 + 16, x0:x1] = ob["final_T"][ty * 16:ty * 16 + 16, x0:x1]
+        fwd["n_contrib"][ty * 16:ty * 16 + 16, x0:x1] = ob["n_contrib"][ty * 16:ty * 16 + 16, x0:x1]
+    for lo, hi in runs:   # (the interval form adds into nothing: one call per run, summed here)
+        gr = orc.backward(fwd, dL.numpy(), scene.means3D.numpy(), cam.world_view_transform.numpy(),
+                          cam.full_proj_transform.numpy(), cam.camera_center.numpy(), W, H, cam.tanfovx, cam.tanfovy, bg,
+                          scales=scene.scales.numpy(), rotations=scene.rotations.numpy(), cov3D_precomp=None, shs=None,
+                          sh_degree=0, tile_lo=lo, tile_hi=hi)
+        want = gr if want is None else {k: want[k] + gr[k] for k in gr}
+    empty = torch.Tensor([])
+    dLd = dL.to(DEV)
+    names = ["dL_dmean2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+    for mode in (0, 3):
+        raster.set_backward_mode(mode)
+        try:
+            n, out, radii, geom, binn, img, _ = _render(s, c, C, W, H)
+            got = raster.rasterize_backward(s.bg[:C], s.means3D, radii, s.features, s.scales, s.rotations, 1.0, empty,
+                                            c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, dLd, empty, 0,
+                                            c.camera_center, geom, n, binn, img, False)
+            got = [t.cpu().numpy() for t in got]
+        finally:
+            raster.set_backward_mode(0)
+        for i, name in enumerate(names):
+            w = want[name]
+            if w.size == 0 or got[i].size == 0:
+                continue
+            scale = float(np.abs(w).max())
+            err = float(np.abs(got[i].reshape(w.shape) - w).max())
+            print(f"cfg3 backward vs oracle, mode {mode}, {name}: max|hip - oracle| = {err / scale:.2e} of the largest entry")
+            assert scale > 0 and err <= 1e-4 * scale, (name, mode, err / scale)
+
+
 def test_cfg3_pipelined_views_match_serial(cfg3):
     """Four views of the headline scene in flight on four HIP streams (what bench.py times) against the same
     views rendered alone: num_rendered, radii and the whole C = 512 feature map, bit for bit, 10 rounds."""

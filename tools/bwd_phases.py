@@ -22,7 +22,7 @@ dL = torch.randn(C, H, W, device=dev)
 raster.set_backward_mode(mode)
 lib = _lib.load()
 NWG = 8192
-tr = torch.zeros(12 * 8 * NWG, dtype=torch.int64, device=dev)
+tr = torch.zeros(24 * 8 * NWG, dtype=torch.int64, device=dev)
 
 
 def fwd_bwd():
@@ -47,16 +47,19 @@ raster.rasterize_backward(s.bg, s.means3D, rad, s.features, s.scales, s.rotation
 torch.cuda.synchronize()
 lib.sgs_debug_set_sweep_trace(None)
 raster.set_backward_mode(0)
-ph = tr.cpu().numpy().reshape(NWG * 8, 12)
-ph = ph[ph[:, 10] != 0]
+ph = tr.cpu().numpy().reshape(NWG * 8, 24)
+ph = ph[ph[:, 20] != 0]
 names = ["request feature pieces", "W g^T (upper half: first)", "take slab: wait, split, transposing stores", "finish slab s-2 (lower: exchange + atomics)",
-         "request gradient", "D products", "W g^T (lower half: last)", "stage features (wait, split, store)", "barrier", "chunk prologue / epilogue"]
-tot_entries = (ph[:, 11] >> 8)[::8].sum()
-print(f"backward mode {mode}: {len(ph) // 8} workgroups, {ph[:, 10][::8].sum()} iterations, {tot_entries} work-list entries")
+         "request gradient", "D products", "W g^T (lower half: last)", "stage features (wait, split, store)", "barrier", "between iterations / chunks (rest)",
+         "chunk: first round trip (count, ids, weights, slab 0)", "chunk: barrier, ids to LDS, row pointers", "chunk: weights split",
+         "chunk: second round trip (features) + staging", "chunk: barrier", "tail: finish slab n-2", "tail: W g^T of the last slab", "tail: barrier",
+         "tail: finish the last slab", "tail: D rows out (drained)"]
+tot_entries = (ph[:, 21] >> 8)[::8].sum()
+print(f"backward mode {mode}: {len(ph) // 8} workgroups, {ph[:, 20][::8].sum()} iterations, {tot_entries} work-list entries")
 for half in (0, 1):
-    sel = ph[((ph[:, 11] & 255) >> 2) == half]
-    it = sel[:, 10].sum()
-    tot = sel[:, :10].sum()
+    sel = ph[((ph[:, 21] & 255) >> 2) == half]
+    it = sel[:, 20].sum()
+    tot = sel[:, :20].sum()
     print(f"half {half} (waves {4 * half}-{4 * half + 3}): {tot / it:8.0f} cycles per iteration")
-    for k in range(10):
-        print(f"    {names[k]:46s} {sel[:, k].sum() / it:8.0f}  ({100.0 * sel[:, k].sum() / tot:4.1f} %)")
+    for k in range(20):
+        print(f"    {names[k]:56s} {sel[:, k].sum() / it:8.0f}  ({100.0 * sel[:, k].sum() / tot:4.1f} %)")
