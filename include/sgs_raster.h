@@ -342,14 +342,17 @@ int sgs_set_stage_timing(int mode);
  * ranges and the (reconstructed) sorted keys are bit-identical in all modes; point_offsets and
  * the UNSORTED key/value arrays exist only in mode 1.  Returns the previous mode. */
 int sgs_set_binning_mode(int mode);
-/* Backward blend: 0 (default) = for num_channels >= 32 with num_channels % 32 == 0 the channel work runs
- * as two matrix products over the forward's work list (blend_bwd_mfma.hip; scratch comes from a
- * stream-ordered pool on `stream`), the per-chunk kernel otherwise; the products are split-bf16 x 3 MFMA
- * products with fp32 accumulation (two bf16 terms per operand: <= 3 * 2^-16 of sum |a||b| per product -- round 2's
- * forward arithmetic, NARROWER than the forward's current default of three exact terms / six products); 3 = the same with exact fp32 products (v_mfma_f32_32x32x2_f32), ~1.5 ms slower at
- * 1M x 512 x 968x1296; 1 = always the per-chunk VALU kernel (blend_bwd.hip); 2 = as 0 with a deliberately
- * undersized work-list arena (exercises the overflow fallback; tests only).  All within 1e-4 of the largest
- * gradient entry of the float64 oracle (tests).  Returns the previous mode. */
+/* Backward blend: 0 (default) = for num_channels >= 32 with num_channels % 32 == 0 the channel work runs as two matrix
+ * products over the forward's work list, both in ONE kernel that reads dL/dpixel once (round 5, blend_bwd_mfma.hip
+ * bwd_fused_kernel; scratch comes from a stream-ordered pool on `stream`), the per-chunk kernel otherwise.
+ * Arithmetic of the two products in mode 0: every operand (features, weights, gradient) is split into TWO bf16 terms,
+ * x = hi + lo + O(2^-16 x), the three products lo*hi + hi*lo + hi*hi run on v_mfma_f32_32x32x8_bf16 with fp32 accumulation:
+ * <= 3 * 2^-16 of sum |a||b| per product -- NARROWER than the forward's default (three exact terms, six products).
+ * 3 = the same kernel with exact fp32 products (v_mfma_f32_32x32x2_f32), ~1.3 ms slower at 1M x 512 x 968x1296;
+ * 1 = always the per-chunk VALU kernel (blend_bwd.hip); 2 = as 0 with a deliberately undersized work-list arena
+ * (exercises the overflow fallback; tests only); 4 / 5 = rounds 2-4's form of 0 / 3 (one kernel per product, each
+ * streaming the gradient; kept for A/B runs).  All within 1e-4 of the largest gradient entry of the float64 oracle
+ * (tests, also at the headline configuration's full size).  Returns the previous mode. */
 int sgs_set_backward_mode(int mode);
 int sgs_get_stage_ms(float *ms7);
 /* The depth presort of the forward (csrc/depth_sort.hip) on a bare array of 32-bit keys: perm[r] = index of the

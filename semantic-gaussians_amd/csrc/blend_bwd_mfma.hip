@@ -667,6 +667,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const int gp = 32 * wave + l31;
 	const int g_y = ty * SGS_TILE + 2 * ((gp & 127) >> 4) + (gp >> 7), g_x = tx * SGS_TILE + (gp & 15);
 	const bool g_ok = g_y < H && g_x < W;
+	const uint32_t g_okm = g_ok ? 0xFFFFFFFFu : 0u;
 	const uint32_t g_offb = 4u * ((uint32_t)(16 * h) * HW + (uint32_t)(g_y < H ? g_y : H - 1) * (uint32_t)W +
 				      (uint32_t)(g_x < W ? g_x : W - 1));   // (eligibility: 128 planes * 4 B < 2^32)
 	const int wr16 = 2 * g_row(16 * h) + gp;             // transposing store, 16-bit units: element (c = 16 h, px' = gp), hi term
@@ -793,8 +794,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
 					split_pair(pg[2 * j], pg[2 * j + 1], gh[j], gl[j]);
-					gh[j] = g_ok ? gh[j] : 0u;
-					gl[j] = g_ok ? gl[j] : 0u;
+					gh[j] &= g_okm;
+					gl[j] &= g_okm;
 					if (DBG & 8) continue;
 					gt[2 * (2 * j) * GROW] = (uint16_t)gh[j];
 					gt[2 * (2 * j + 1) * GROW] = (uint16_t)(gh[j] >> 16);
@@ -952,7 +953,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		// feature pieces are requested FIRST for the same reason: they are staged at the end of the iteration.
 		// The two waves of a SIMD (w and w + 4) run W g^T at opposite ends of the iteration, so one's VALU / LDS phases lie beside
 		// the other's matrix phases.  (One instance of every phase in program order, each behind a uniform branch: with the two
-		// halves' sequences written as two arms the compiler allocates them separately and copies ~100 registers where they join.)
+		// halves' sequences written as two arms the compiler allocates them separately and copies ~100 registers where they join.
+		// Also measured and dropped: the upper half's W g^T and slab take-over as ONE basic block, the split's VALU instructions and
+		// the transposing stores placed between the products with sched_group_barrier -- same time, profiles/r05_backward_fused.txt.)
 		for (int s = 0; s < nsl; s++) {
 			const int cur = s & 1;
 			const bool more = s + 1 < nsl;
@@ -960,9 +963,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 			if (more) fetch_f(32 * (s + 1));
 			SGS_PH(0)
 			if (kh && s >= 2) finish_e(cur, 32 * (s - 2));
-			if (DBG & 32) __builtin_amdgcn_s_setprio(2);
 			if (kh && s >= 1) prod_e(cur ^ 1);
-			if (DBG & 32) __builtin_amdgcn_s_setprio(0);
 			SGS_PH(1)
 			take_slab(cur);
 			SGS_PH(2)
@@ -970,11 +971,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 			SGS_PH(3)
 			if (more) fetch_g(32 * (s + 1));
 			SGS_PH(4)
-			if (DBG & 32) __builtin_amdgcn_s_setprio(2);
 			prod_d(cur);
 			SGS_PH(5)
 			if (!kh && s >= 1) prod_e(cur ^ 1);
-			if (DBG & 32) __builtin_amdgcn_s_setprio(0);
 			SGS_PH(6)
 			if (more) stage_f(cur ^ 1);
 			SGS_PH(7)
@@ -1199,7 +1198,7 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 		if (g_bwd_dbg != 0 && !fp32_products) {
 			switch (g_bwd_dbg) {
 #define SGS_DBG_CASE(D_) case D_: hipLaunchKernelGGL((bwd_fused_kernel<false, D_>), grid, block, 0, st, SGS_FUSED_ARGS); break;
-			SGS_DBG_CASE(2) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15) SGS_DBG_CASE(16) SGS_DBG_CASE(32)
+			SGS_DBG_CASE(2) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15) SGS_DBG_CASE(16)
 #undef SGS_DBG_CASE
 			default: break;
 			}

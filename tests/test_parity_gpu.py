@@ -355,7 +355,7 @@ def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
     if dense:
         assert fw["n_contrib"].max() > 300
     outs = {}
-    for mode in (0, 1, 2, 3):   # 0 split-bf16 products (default), 1 per-chunk kernel, 2 overflow fallback, 3 fp32 products
+    for mode in (0, 1, 2, 3, 4, 5):   # 0 fused kernel, split-bf16 products (default), 1 per-chunk kernel, 2 overflow fallback, 3 fused, fp32 products, 4 / 5 rounds 2-4's two kernels
         raster.set_backward_mode(mode)
         try:
             n, color, radii, geom, binn, img, _ = _hip_forward(scene, cam, bg=bg)
@@ -368,7 +368,7 @@ def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
         want = gr[name]
         if want.size == 0:
             continue
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 4, 5):
             ok, err = _grad_close(outs[mode][i].reshape(want.shape), want, 1e-4)
             assert ok, (name, mode, err)
     assert np.abs(outs[0][1]).max() > 0
