@@ -19,6 +19,8 @@ What one JSON line carries (rank 0):
                         the host waits for num_rendered before the call returns, after the whole frame was enqueued),
                         device ms per forward (hipEvents, median);
   single_view           one view in flight through the internal entry point (SURVEY.md 8(d)'s t_fwd): value, ms_median;
+  single_view_inference the same through raster.rasterize_forward_inference (the frame enqueued in full before the host waits for
+                        the count: what the drop-in module does under no_grad);
   deferred_count        the inference-only mode without the host read-back (SGS_OPT_DEFER_COUNT), V views in flight,
                         with the number of frames that had to be rendered twice;
   exact_f32             the bit-exact fp32-MFMA arithmetic (SGS_BLEND_EXACT=1 / variant 15);
@@ -430,7 +432,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def single_view(variant, n=24, deferred=False):
+    def single_view(variant, n=24, deferred=False, inference=False):
         """One view in flight: per-forward device time (hipEvents on the launch stream = torch's current
         stream) and the per-stage times (deferred resolution: no extra synchronisation).  deferred: the forward
         without the num_rendered read-back (each frame's counts are checked before the next one is enqueued)."""
@@ -450,7 +452,10 @@ def main():
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in evs:
             a.record()
-            h = render(0, deferred)
+            if inference:   # the whole frame enqueued against the capacity guess, THEN the host waits for the counts (raster.rasterize_forward_inference)
+                h = render(0, True).result()
+            else:
+                h = render(0, deferred)
             b.record()
             if deferred:
                 h.result()
@@ -510,6 +515,8 @@ def main():
 
     # ---- one view in flight (SURVEY 8(d)'s t_fwd), default arithmetic; its stage times feed the roofline
     sv_default, stage_ms = single_view(args.variant)
+    # the same through the inference entry point (what the drop-in module does under no_grad): no read-back hole in the GPU's timeline
+    sv_inference = single_view(args.variant, inference=True)[0]
     # integrity reference: every (slot, camera)'s num_rendered, rendered alone (concurrent forwards must reproduce it)
     ref_n = []
     for i in range(V):
@@ -556,6 +563,7 @@ def main():
     api = api_path() if world == 1 or rank == 0 else None
     if api is not None:
         api["ratio_to_single_view"] = api["ms_median"] / sv_default["ms_median"]
+        api["ratio_to_single_view_inference"] = api["ms_median"] / sv_inference["ms_median"]
         api["ms_median_with_debug_false"] = api_path(debug=False)["ms_median"]
         api["note"] = ("the events bracket the Python call: the span includes the host's own work before the first launch and "
                        "after the last (module call, autograd Function, ctypes marshalling, with debug=True one end-of-call "
@@ -778,6 +786,9 @@ def main():
             "memory": mem,
             "ms_per_view": ms_per_step / V,
             "single_view": sv_default,
+            "single_view_inference": dict(sv_inference, note="one view in flight through raster.rasterize_forward_inference: the whole frame is "
+                                          "enqueued against the stream's capacity guess before the host waits for num_rendered (what "
+                                          "GaussianRasterizer does under torch.no_grad(); single_view above keeps the reference's mid-frame wait)"),
             "api_path": api,
             "deferred_count": deferred,
             "exact_f32": exact,

@@ -354,6 +354,10 @@ int sgs_set_binning_mode(int mode);
  * streaming the gradient; kept for A/B runs).  All within 1e-4 of the largest gradient entry of the float64 oracle
  * (tests, also at the headline configuration's full size).  Returns the previous mode. */
 int sgs_set_backward_mode(int mode);
+/* Which optional parts this libsgs_hip.so was built with: bit 0 `make FUSED=1` (blend variants 32-35), bit 1 `make X16=1` (the
+ * double-rate-MFMA reproducers), bit 2 `make EXPERIMENTS=1` (development forms of the blend kernels: ablations, superseded sweeps and
+ * pre-passes, the two-kernel backward).  The product build returns 0 and answers those variants with SGS_EINVAL. */
+int sgs_build_flags(void);
 int sgs_get_stage_ms(float *ms7);
 /* The depth presort of the forward (csrc/depth_sort.hip) on a bare array of 32-bit keys: perm[r] = index of the
  * r-th smallest key, equal keys in index order (tests).  With keys / perm / scratch NULL: returns the scratch

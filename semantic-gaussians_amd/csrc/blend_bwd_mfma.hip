@@ -40,7 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr uint32_t BG_ID = 0xFFFFFFFFu;     // blend_fwd_split.hip SGS_BG_ID
 constexpr uint32_t NO_ID = 0xFFFFFFFEu;
 constexpr int CHUNK = 128;                  // work-list slots per arena chunk (blend_fwd_split.hip ACH)
-constexpr int LDP = 36;                     // LDS row pitch (floats) of the 32-wide operand slabs
+constexpr int LDP __attribute__((unused)) = 36;   // LDS row pitch (floats) of the 32-wide operand slabs (the two-kernel form)
 
 // row of the 32x32 MFMA result held in accumulator register r of a lane in half h
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -81,6 +81,7 @@ __device__ __forceinline__ float4 mask4(float4 v, bool ok)
 	return v;
 }
 
+#ifdef SGS_WITH_EXPERIMENTS   // rounds 1-4's two-kernel form (one kernel per product, each streaming the gradient): make EXPERIMENTS=1, backward modes 4 / 5
 // ---- 3. D[slot][px'] = sum_c F[id(slot)][c] * g[c][px']
 // 512 threads: wave w owns the 32 px' [32 w, 32 w + 32) for up to 128 entries (4 x 16 accumulators), so
 // two workgroups fit a CU (the any-width instantiation spills; widths that are not a multiple of 4 are
@@ -310,6 +311,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	}
 }
 
+#endif   // SGS_WITH_EXPERIMENTS
+
 // ================= split-bf16 forms of the two products (the default) =================
 // x = hi + lo + O(2^-16 x) with hi, lo bf16 (round to nearest even), and  F.G ~ Fl.Gh + Fh.Gl + Fh.Gh  on
 // v_mfma_f32_32x32x8_bf16_1k with fp32 accumulation: every product is exact in fp32, what is dropped is
@@ -351,6 +354,7 @@ __device__ __forceinline__ Op2 lds_op2(const uint32_t* p)
 }
 #define SGS_MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(A_, B_, C_, 0, 0, 0)
 
+#ifdef SGS_WITH_EXPERIMENTS
 // ---- 3'. D = F G.  The gradient slab has to be transposed on its way into LDS (k = channel is the slow
 // dimension of dL_dpix): a thread owns ONE pixel and 16 channels of the slab (16 dword loads, lanes along px':
 // four 64-byte row pieces per wave instruction) and writes its 16 k as two 16-byte pieces per half.
@@ -599,6 +603,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		}
 	}
 }
+#endif   // SGS_WITH_EXPERIMENTS
+
 // ================= 2 + 3 fused (round 5, the default): both products of a tile from ONE read of its gradient =================
 // The two products contract the gradient slab g[32 c][256 px'] over different dimensions (D = F g over c, dL/dF = W g^T over
 // px'), which is why rounds 2-4 ran them as two kernels that each streamed the 2.57 GB gradient.  One workgroup of eight waves
@@ -1161,7 +1167,9 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 
 } // namespace
 
-static const int g_bwd_dbg = getenv("SGS_BWD_DBG") ? atoi(getenv("SGS_BWD_DBG")) : 0;   // development only
+#ifdef SGS_WITH_EXPERIMENTS
+static const int g_bwd_dbg = getenv("SGS_BWD_DBG") ? atoi(getenv("SGS_BWD_DBG")) : 0;   // ablations / phase stamps of the fused kernel (tools/bwd_phases.py)
+#endif
 
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 {
@@ -1190,11 +1198,13 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	const int nch = (a.C + 127) / 128;
 	const int items = ntiles * nch;
 	const int ixcd = (items + 7) / 8, txcd = (ntiles + 7) / 8;
-	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows
+	const bool vec = (a.W & 3) == 0;   // 16-byte loads of the gradient rows (the two-kernel form)
+	(void)vec; (void)ixcd; (void)items;
 	if (!two_kernels) {   // round 5: one kernel, one read of the gradient for both products
 		const dim3 grid(txcd * 8), block(512);
 #define SGS_FUSED_ARGS a.ranges, table, nact, act_id, rows, a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, lay.capacity, a.W, a.H, a.C, a.gx, txcd, ntiles, \
 		       get_sweep_trace()
+#ifdef SGS_WITH_EXPERIMENTS
 		if (g_bwd_dbg != 0 && !fp32_products) {
 			switch (g_bwd_dbg) {
 #define SGS_DBG_CASE(D_) case D_: hipLaunchKernelGGL((bwd_fused_kernel<false, D_>), grid, block, 0, st, SGS_FUSED_ARGS); break;
@@ -1202,13 +1212,16 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 #undef SGS_DBG_CASE
 			default: break;
 			}
-		} else if (fp32_products) {
+		} else
+#endif
+		if (fp32_products) {
 			hipLaunchKernelGGL((bwd_fused_kernel<true>), grid, block, 0, st, SGS_FUSED_ARGS);
 		} else {
 			hipLaunchKernelGGL((bwd_fused_kernel<false>), grid, block, 0, st, SGS_FUSED_ARGS);
 		}
 #undef SGS_FUSED_ARGS
 	} else {
+#ifdef SGS_WITH_EXPERIMENTS
 #define SGS_LAUNCH_BWD(DCOL_, DOT_)                                                                              \
 	hipLaunchKernelGGL(DCOL_, dim3(ixcd * 8), dim3(512), 0, st, a.ranges, table, nact, act_id,                 \
 			   rows, a.dL_dpix, a.dL_dcolors, counter, a.W, a.H, a.C, a.gx, nch, ixcd, items);        \
@@ -1222,6 +1235,9 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 		else { SGS_LAUNCH_BWD(bwd_dcolor_split_kernel<false>, bwd_dot_split_kernel); }
 	}
 #undef SGS_LAUNCH_BWD
+#else
+		return hipErrorInvalidValue;   // (the two-kernel form is not in the product library: make EXPERIMENTS=1)
+#endif
 	}
 	hipLaunchKernelGGL(bwd_geom_kernel, dim3(txcd * 8), dim3(256), 0, st, a.ranges, table, nact, act_id, act_idx,
 			   rows, a.means2D, a.conic_opacity, a.final_T, a.n_contrib, a.dL_dmean2D, a.dL_dconic,

@@ -354,6 +354,16 @@ hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int varia
 	if (c_skip > 0 && !gate) {
 		c_done = c_skip;   // channels [0, c_skip) were rendered by the split path
 	} else if (!depth) {
+#ifndef SGS_WITH_EXPERIMENTS   // the product library: the 128-channel px4 form (variant 0 / 6; the gated fallback of the split path); 1-5 are make EXPERIMENTS=1
+		if (variant != 0) return hipErrorInvalidValue;
+		{
+			const int nch = a.C / 128;
+			if (nch > 0) {
+				launch_px4<32, 32>(st, a, nch, gate);
+				c_done = nch * 128;
+			}
+		}
+#else
 		if (variant == 0 || variant == 4 || variant == 5) {
 			const int width = (variant == 5) ? 64 : 128;
 			const int nch = a.C / width;
@@ -373,6 +383,7 @@ hipError_t launch_blend_forward(hipStream_t st, const BlendFwdArgs& a, int varia
 				c_done = nch * width;
 			}
 		}
+#endif
 	}
 	if (gate) return hipGetLastError();   // gated call renders only the 128-aligned part
 	const int rem = a.C - c_done;

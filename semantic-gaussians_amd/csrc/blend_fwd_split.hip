@@ -1444,6 +1444,24 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		// 16-entry-batch kernels for A/B runs (0x8000: lane = pixel, 0xC000: two pixels per lane; a sweep trace needs the former:
 		// it carries the hooks).  fp32 rows (exact sweep, backward) stay with blend_weights2_kernel<3>.
 		const bool w_sb = presplit3 && (split_mode & 0x8000) == 0 && g_sweep_trace == nullptr;
+#ifndef SGS_WITH_EXPERIMENTS
+		// the product library: three-term format -> blend_weights2_sb_kernel, fp32 rows (exact sweep) -> blend_weights2_kernel<3>, two
+		// terms (variant 14) -> blend_weights_kernel<2>; the superseded pre-passes and the sweep trace are make EXPERIMENTS=1
+		(void)w_old;
+		if (flip || (split_mode & 0x8000) || g_sweep_trace != nullptr) return hipErrorInvalidValue;
+		if (presplit3) {
+			const hipError_t ew = launch_blend_weights2(st, 5, a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib,
+								    act_id, nullptr, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, ntiles,
+								    nullptr, 0, a.tile_order);
+			if (ew != hipSuccess) return ew;
+		} else if (exact || sweep2) {
+			const hipError_t ew = launch_blend_weights2(st, 3, a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib,
+								    act_id, nullptr, wgt, table, nbatches, counter, lay.capacity, a.W, a.H, a.gx, ntiles,
+								    nullptr, 0, a.tile_order);
+			if (ew != hipSuccess) return ew;
+		} else SGS_LAUNCH_W(2, st, 0, ntiles);
+		(void)w_sb;
+#else
 		if (w_sb && !flip) {   // the default: the two-pixels-per-lane kernel with the super-batch walk (blend_weights2.hip, mode 5: 0.207 ms at cfg3;
 			// bit 14 of the word selects the lane-per-pixel super-batch kernel below, 0.217-0.22)
 			const hipError_t ew = launch_blend_weights2(st, 5, a.ranges, a.point_list, a.means2D, a.conic_opacity, a.final_T, a.n_contrib,
@@ -1463,6 +1481,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 		} else if (presplit3) SGS_LAUNCH_W(4, st, 0, ntiles);
 		else if (exact || sweep2) SGS_LAUNCH_W(3, st, 0, ntiles);
 		else SGS_LAUNCH_W(2, st, 0, ntiles);
+#endif
 		if (mark) mark(mark_user);
 		// workgroup order (bits [13:12] of the variant): 0 / 3 = segments sorted by work and dealt to the XCDs
 		// (sweep_plan_kernel), 1 = row-major bands per XCD (the previous order), 2 = dealt, unsorted
@@ -1492,7 +1511,12 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 								  nbatches, act_id, (const char*)wgt, counter, nc, seg, nseg, pxcd, items,
 								  g_sweep_trace, order_arg, dealt);
 			if (e2 != hipSuccess) return e2;
-		} else if (exact) SGS_LAUNCH_SWEEP(0, true);
+		}
+#ifndef SGS_WITH_EXPERIMENTS
+		else if (exact || ((split_mode >> 8) & 15) != 0) return hipErrorInvalidValue;   // (round 2's sweep on fp32 MFMA, its ablations: make EXPERIMENTS=1)
+		else SGS_LAUNCH_SWEEP(0, false);
+#else
+		else if (exact) SGS_LAUNCH_SWEEP(0, true);
 		else
 			switch ((split_mode >> 8) & 15) {
 			case 1: SGS_LAUNCH_SWEEP(1, false); break;
@@ -1506,6 +1530,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 #endif
 			default: SGS_LAUNCH_SWEEP(0, false); break;
 			}
+#endif
 #undef SGS_LAUNCH_SWEEP
 	}
 #undef SGS_LAUNCH_W

@@ -1688,6 +1688,12 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 #else
 	if (tune != 0) return hipErrorInvalidValue;   // (the x16 forms of this sweep are not in the product library)
 #endif
+#ifndef SGS_WITH_EXPERIMENTS   // the product library holds ONE ping-pong sweep; the forms below are make EXPERIMENTS=1
+	(void)coop;
+	if (form != 0 || dbg != 0) return hipErrorInvalidValue;
+	S3_LAUNCH(0);
+	return hipGetLastError();
+#else
 	if (coop) {   // sweep nibble 5: fp32 weights handed over, split by the sweep one step ahead
 #define S3_LAUNCH_C(D_)                                                                              \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 0, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
@@ -1718,8 +1724,9 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	else if (dbg == 4) S3_LAUNCH(4);   // phase clocks (tools/sweep_phases.py)
 	else if (dbg == 8) S3_LAUNCH(8);   // transposed 16-byte stores (experiment: slower)
 	else S3_LAUNCH(0);
-#undef S3_LAUNCH
 	return hipGetLastError();
+#endif
+#undef S3_LAUNCH
 }
 
 hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFwdArgs& a, const uint32_t* table,
@@ -1734,6 +1741,13 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 	hipLaunchKernelGGL((blend_accum_sweep2_kernel<A_, D_>), dim3(pxcd * 8), dim3(256), dyn_lds, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt)
+#ifndef SGS_WITH_EXPERIMENTS   // the product library: the exact fp32 sweep (variant 15) and the norm-plane epilogues of N1; the rest is make EXPERIMENTS=1
+	if (arith == S2_EXACT && dbg == 0) S2_LAUNCH(S2_EXACT, 0);
+	else if (arith == S2_EXACT && dbg == 32) S2_LAUNCH(S2_EXACT, 32);
+	else if (arith == S2_X6P && dbg == 32) S2_LAUNCH(S2_X6P, 32);
+	else return hipErrorInvalidValue;
+	return hipGetLastError();
+#else
 	if (arith == S2_EXACT) {
 		if (dbg == 1) S2_LAUNCH(S2_EXACT, 1);
 		else if (dbg == 32) S2_LAUNCH(S2_EXACT, 32);
@@ -1777,8 +1791,9 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 		else if (dbg == 3) S2_LAUNCH(S2_X6, 3);
 		else S2_LAUNCH(S2_X6, 0);
 	}
-#undef S2_LAUNCH
 	return hipGetLastError();
+#endif
+#undef S2_LAUNCH
 }
 
 } // namespace sgs

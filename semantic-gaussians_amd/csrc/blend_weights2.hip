@@ -603,10 +603,14 @@ hipError_t launch_blend_weights2(hipStream_t st, int mode, const uint2* ranges, 
 	if (mode == 5)   // three bf16 terms, 128-entry super-batches (the forward's default pre-pass)
 		hipLaunchKernelGGL(blend_weights2_sb_kernel<SGS_W2SB_GROUP>, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
 				   n_contrib, act_id, wgt, table, nact, counter, capacity, W, H, gx, (ntiles + 7) / 8, ntiles, tile_order);
+#ifdef SGS_WITH_EXPERIMENTS   // round 3's 16-entry-batch kernel in the three-term format (variant bits 0xC000)
 	else if (mode == 4)
 		hipLaunchKernelGGL(blend_weights2_kernel<4>, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
 				   n_contrib, act_id, act_idx, wgt, table, nact, counter, capacity, W, H, gx, (ntiles + 7) / 8, ntiles,
 				   (float4*)clear_ptr, (unsigned long long)(clear_floats / 4), tile_order);
+#else
+	else if (mode == 4) return hipErrorInvalidValue;
+#endif
 	else
 		hipLaunchKernelGGL(blend_weights2_kernel<3>, grid, dim3(128), 0, st, ranges, point_list, means2D, conic_opacity, final_T,
 				   n_contrib, act_id, act_idx, wgt, table, nact, counter, capacity, W, H, gx, (ntiles + 7) / 8, ntiles,

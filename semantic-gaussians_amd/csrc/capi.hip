@@ -409,6 +409,20 @@ long long sgs_debug_depth_sort(int P, const unsigned* keys, unsigned* perm, void
 }
 void sgs_debug_set_sweep_trace(void* device_words) { sgs::set_sweep_trace(device_words); }
 int sgs_set_backward_mode(int mode) { return g_default_opt[SGS_OPT_BACKWARD_MODE].exchange(mode); }
+int sgs_build_flags(void)
+{
+	int f = 0;
+#ifdef SGS_WITH_FUSED
+	f |= 1;
+#endif
+#ifdef SGS_WITH_X16
+	f |= 2;
+#endif
+#ifdef SGS_WITH_EXPERIMENTS
+	f |= 4;
+#endif
+	return f;
+}
 
 int sgs_stream_set_option(void* stream, int option, int value)
 {
@@ -722,6 +736,17 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 			      ((variant & 15) == 6 && ((variant >> 16) & 15) != 0)))
 		return fail(SGS_EINVAL, "blend variants on v_mfma_f32_32x32x16_bf16 (sweep nibble 12 / 15, 0x8.8, 0x1..3 << 16 | ..6) are not in this build (make X16=1)");
 #endif
+#ifndef SGS_WITH_EXPERIMENTS   // (make EXPERIMENTS=1: the development forms, csrc/Makefile)
+	{
+		// what ships: 0 (default) / 6 (single-kernel px4 form, also the gated fallback) / 14 (round 2's two-term sweep) / 15 (exact fp32), and the
+		// word form  sweep nibble {0, 8: two-term | 6: default | 11: exact} | segment length [7:4] | workgroup order [13:12]  -- nothing else
+		const int nib = variant & 15;
+		const bool plain = variant == 0 || variant == 6 || variant == 14 || variant == 15;
+		const bool word = variant >= 16 && variant < 0x4000 && ((variant >> 8) & 15) == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11);
+		if (!plain && !word && !want_fused)
+			return fail(SGS_EINVAL, "this blend variant is a development form that is not in this build (make EXPERIMENTS=1)");
+	}
+#endif
 	const bool use_split = !want_fused && (variant == 0 || variant == 14 || variant == 15 || variant >= 16) && !out_depth && num_channels >= 128 && L > 0;
 	uint32_t arena_cap = 0;
 	uint64_t arena_max = 0;
@@ -900,7 +925,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		}
 	} else {
 		tm.mark();   // (no weights pre-pass on this path)
-		e = sgs::launch_blend_forward(st, a, variant == 6 ? 0 : variant);   // 6 = px4 without the split
+		e = sgs::launch_blend_forward(st, a, (variant >= 1 && variant <= 5) ? variant : 0);   // 1-5: single-kernel forms (make EXPERIMENTS=1); everything else: px4 + remainder
 	}
 	if (e != hipSuccess) return fail_hip(e, "blend forward");
 	SGS_CHECK_STAGE("blend forward");
@@ -980,6 +1005,9 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 		hipError_t e = hipSuccess;
 		bool done = false;
 		const int bw_mode = cx->option(SGS_OPT_BACKWARD_MODE);
+#ifndef SGS_WITH_EXPERIMENTS
+		if (bw_mode == 4 || bw_mode == 5) return fail(SGS_EINVAL, "backward modes 4 / 5 (rounds 2-4's two-kernel form) are not in this build (make EXPERIMENTS=1)");
+#endif
 		if (bw_mode != 1 && sgs::blend_backward_mfma_eligible(a)) {
 			// the forward's work list again, in stream-ordered scratch.  Its capacity adapts to what THIS
 			// stream's previous backward used (the forward's hint is only the starting point: below 128

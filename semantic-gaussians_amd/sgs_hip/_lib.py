@@ -37,7 +37,7 @@ EXPORTS = (
     "sgs_abi_version", "sgs_last_error", "sgs_rasterize_forward", "sgs_rasterize_backward",
     "sgs_mark_visible", "sgs_knn_mean_dist2", "sgs_geometry_layout_of", "sgs_binning_layout_of",
     "sgs_image_layout_of", "sgs_sort_bits", "sgs_debug_expf", "sgs_debug_sorted_keys", "sgs_set_blend_variant",
-    "sgs_set_stage_timing", "sgs_get_stage_ms", "sgs_set_binning_mode", "sgs_set_backward_mode", "sgs_fusion_compute_mapping", "sgs_fusion_accumulate", "sgs_composite_over",
+    "sgs_set_stage_timing", "sgs_get_stage_ms", "sgs_set_binning_mode", "sgs_set_backward_mode", "sgs_build_flags", "sgs_fusion_compute_mapping", "sgs_fusion_accumulate", "sgs_composite_over",
     "sgs_stream_set_option", "sgs_stream_get_stat", "sgs_stream_release", "sgs_debug_set_sweep_trace",
     "sgs_forward_result", "sgs_debug_depth_sort",
 )
@@ -111,6 +111,8 @@ def load():
     lib.sgs_set_binning_mode.argtypes = [i]
     lib.sgs_set_backward_mode.restype = i
     lib.sgs_set_backward_mode.argtypes = [i]
+    lib.sgs_build_flags.restype = i
+    lib.sgs_build_flags.argtypes = []
     lib.sgs_fusion_compute_mapping.restype = i
     lib.sgs_fusion_compute_mapping.argtypes = [i, p, p, C.POINTER(C.c_double), i, i, i, C.c_double, i, p, p, p, p, p]
     lib.sgs_composite_over.restype = i

@@ -206,6 +206,14 @@ def rasterize_forward_deferred(*args, **kwargs):
     return DeferredForward(args, kwargs, stream, out)
 
 
+def rasterize_forward_inference(*args, **kwargs):
+    """rasterize_forward for a frame nobody will differentiate (what GaussianRasterizer does under torch.no_grad()): same
+    arguments, same tuple, num_rendered known when it returns -- but the whole frame is enqueued against the stream's capacity
+    guess BEFORE the host waits for the counts, so the GPU's timeline has no read-back hole (a frame that outgrew
+    the guess is rendered again).  The state buffers are laid out for the capacity: not for rasterize_backward."""
+    return rasterize_forward_deferred(*args, **kwargs).result()
+
+
 def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                       image_width, sh, degree, campos, prefiltered, debug, num_channels,
@@ -519,6 +527,11 @@ def set_binning_mode(mode):
     """0 = depth-presorted emission (default); 1 = reference order of operations (also makes
     point_offsets and the unsorted key/value arrays follow the reference's emission order)."""
     return int(_lib.load().sgs_set_binning_mode(int(mode)))
+
+
+def build_flags():
+    """Optional parts of the loaded library: 1 = make FUSED=1, 2 = make X16=1, 4 = make EXPERIMENTS=1 (include/sgs_raster.h)."""
+    return int(_lib.load().sgs_build_flags())
 
 
 def set_backward_mode(mode):

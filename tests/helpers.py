@@ -35,3 +35,15 @@ def oracle_forward(orc, scene, cam, want_depth=False, colors=None, shs=None, sh_
                        cam.camera_center.numpy(), cam.image_width, cam.image_height, cam.tanfovx,
                        cam.tanfovy, bg, C, scale_modifier=scale_modifier, want_depth=want_depth,
                        **kw)
+
+
+def has_experiments():
+    """The loaded libsgs_hip.so was built with `make EXPERIMENTS=1` (development forms of the blend kernels, csrc/Makefile)."""
+    from sgs_hip import raster
+    return bool(raster.build_flags() & 4)
+
+
+def need_experiments(what="this blend variant"):
+    import pytest
+    if not has_experiments():
+        pytest.skip(f"{what} is a development form built only by `make EXPERIMENTS=1` (the product library answers it with SGS_EINVAL)")

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import small_scene, oracle_forward
+from helpers import small_scene, oracle_forward, has_experiments, need_experiments
 
 pytestmark = pytest.mark.gpu
 
@@ -112,9 +112,37 @@ def test_expf_contract_bit_exact(orc):
 @pytest.mark.parametrize("variant", [15, 1, 2, 3, 4, 5, 6])
 def test_forward_c128_all_variants(orc, variant):
     """Every bit-exact blend variant (15 = SGS_BLEND_EXACT: fp32 MFMA accumulate; 1-6 single-kernel forms)."""
+    if 1 <= variant <= 5:
+        need_experiments("single-kernel blend forms 1-5")
     scene, cam = small_scene(P=3000, C=128, W=200, H=120, fx=170.0, seed=1)
     fw = _check_forward(orc, scene, cam, variant=variant)
     assert fw["n_contrib"].max() > 20 and (fw["final_T"] < 1e-3).any()   # early stop exercised
+
+
+def test_development_forms_are_not_in_the_product_library():
+    """the default libsgs_hip.so holds the kernels that ship (default, exact, round 2's two-term sweep, the gated
+    fallback, the remainder / RGB-D kernels, the N1 epilogues); sweep ablations, superseded sweeps and pre-passes, the single-kernel
+    forms 1-5 and the two-kernel backward answer SGS_EINVAL unless the library was built with `make EXPERIMENTS=1`."""
+    from sgs_hip import raster
+    if has_experiments():
+        pytest.skip("this library was built with make EXPERIMENTS=1")
+    scene, cam = small_scene(P=500, C=128, W=64, H=48, fx=100.0, seed=2)
+    for v in (1, 2, 3, 4, 5, 0x6A, 0x6D, 0x6E, 0x67, 0x65, 0x64, 0x69, 0x166, 0x266, 0x466, 0x4066, 0x8066, 0xC066):
+        with pytest.raises(RuntimeError, match="EXPERIMENTS"):
+            _hip_forward(scene, cam, variant=v)
+    for v in (0, 6, 14, 15, 0x66, 0x6B, 0x68, 0x16, 0x1066):   # what ships
+        _hip_forward(scene, cam, variant=v)
+    g = torch.Generator().manual_seed(1)
+    dL = torch.randn(128, 48, 64, generator=g)
+    n, color, radii, geom, binn, img, _ = _hip_forward(scene, cam)
+    for mode in (4, 5):
+        raster.set_backward_mode(mode)
+        try:
+            with pytest.raises(RuntimeError, match="EXPERIMENTS"):
+                _hip_backward(scene, cam, scene.bg.numpy(), dL, n, radii, geom, binn, img)
+        finally:
+            raster.set_backward_mode(0)
+    _hip_backward(scene, cam, scene.bg.numpy(), dL, n, radii, geom, binn, img)
 
 
 @pytest.mark.parametrize("variant", [0, 14, 8 + 16 * 1, 14 + 16 * 1])
@@ -123,6 +151,8 @@ def test_forward_split_bf16_within_tolerance(orc, variant, C, W, H):
     """Split-bf16 row-sweep accumulate (default, and with forced 8-tile segments): integer state
     bit-exact, feature map within 5e-5 of the absolute composite.  Widths cover W % 32 == 16
     (staggered pairs), W % 32 == 0, ragged W and a single tile."""
+    if variant == 14 + 16 * 1:
+        need_experiments("round 3's sweep with 8-tile segments (0x1E)")
     scene, cam = small_scene(P=3000, C=C, W=W, H=H, fx=170.0, seed=C + W)
     _check_forward(orc, scene, cam, variant=variant)
 
@@ -355,7 +385,8 @@ def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
     if dense:
         assert fw["n_contrib"].max() > 300
     outs = {}
-    for mode in (0, 1, 2, 3, 4, 5):   # 0 fused kernel, split-bf16 products (default), 1 per-chunk kernel, 2 overflow fallback, 3 fused, fp32 products, 4 / 5 rounds 2-4's two kernels
+    modes = (0, 1, 2, 3, 4, 5) if has_experiments() else (0, 1, 2, 3)
+    for mode in modes:   # 0 fused kernel, split-bf16 products (default), 1 per-chunk kernel, 2 overflow fallback, 3 fused, fp32 products, 4 / 5 rounds 2-4's two kernels
         raster.set_backward_mode(mode)
         try:
             n, color, radii, geom, binn, img, _ = _hip_forward(scene, cam, bg=bg)
@@ -368,7 +399,7 @@ def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
         want = gr[name]
         if want.size == 0:
             continue
-        for mode in (0, 1, 2, 3, 4, 5):
+        for mode in modes:
             ok, err = _grad_close(outs[mode][i].reshape(want.shape), want, 1e-4)
             assert ok, (name, mode, err)
     assert np.abs(outs[0][1]).max() > 0
@@ -823,6 +854,8 @@ def _sparse_scene():
 
 @pytest.mark.parametrize("variant", [0, 15, 0x6A, 0x6B, 0x6E, 0x66, 14])
 def test_empty_tiles_get_the_background(orc, variant):
+    if variant in (0x6A, 0x6E):
+        need_experiments("round 3's sweep (0x6A / 0x6E)")
     scene, cam = _sparse_scene()
     fw = oracle_forward(orc, scene, cam)
     r = fw["ranges"].reshape(-1, 2)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import small_scene, oracle_forward
+from helpers import small_scene, oracle_forward, need_experiments
 from test_parity_gpu import _hip_forward
 
 pytestmark = pytest.mark.gpu
@@ -20,6 +20,12 @@ DEV = "cuda:0"
 V_X6, V_EXACT, V_X6W, V_X6S, V_X6P, V_X6PW = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E, 0x6F
 V_PP = 0x66       # round 4: ping-pong sweep (the default kernel; 0x6_ pins 48-tile segments like the others)
 V_X6C = 0x67      # six products, fp32 weights handed over, split once per workgroup into LDS: bit-identical to V_X6P
+SHIPS = (0, 14, 15, V_EXACT, V_PP)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
+
+
+def _gate(variant):
+    if variant not in SHIPS:
+        need_experiments(f"blend variant {variant:#x}")
 # Against the fp32 ORACLE the difference is dominated by the oracle's own roundings: its multiply-add chain rounds once
 # per contribution (<= 2^-24 |partial sum| each, K ~ 50-300 contributions), the six-product path drops
 # F2 W3 + F3 W2 + F3 W3 <= 2^-23 |f w| per term and rounds once per MFMA.  4e-6 of the ABSOLUTE composite
@@ -66,6 +72,7 @@ SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128,
 def test_sweep2_shapes(orc, variant, C, W, H):
     """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
     (guarded edge pairs), a single tile, an odd tile count (trailing unpaired left half)."""
+    _gate(variant)
     scene, cam = small_scene(P=3000, C=C, W=W, H=H, fx=170.0, seed=C + W)
     check(orc, scene, cam, variant)
     check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
@@ -74,6 +81,7 @@ def test_sweep2_shapes(orc, variant, C, W, H):
 @pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
 def test_sweep2_background_and_short_lists(orc, variant):
     """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
+    _gate(variant)
     scene, cam = small_scene(P=60, C=128, W=208, H=96, fx=170.0, seed=5)
     g = torch.Generator().manual_seed(3)
     scene = scene._replace(bg=torch.randn(128, generator=g), scales=scene.scales * 0.3)
@@ -86,6 +94,7 @@ def test_sweep2_background_and_short_lists(orc, variant):
 def test_sweep2_long_lists(orc, variant):
     """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
     deferred stores ride along tiles of very different lengths."""
+    _gate(variant)
     scene, cam = small_scene(P=40000, C=128, W=784, H=32, fx=600.0, seed=77)
     scene = scene._replace(scales=scene.scales * 3.0, opacities=scene.opacities * 0.05)
     check(orc, scene, cam, variant)        # (first frame may take the overflow fallback)
@@ -97,6 +106,7 @@ def test_sweep2_long_lists(orc, variant):
 @pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
 def test_sweep2_padded_pitch(orc, variant):
     """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
+    _gate(variant)
     from sgs_hip import raster
     scene, cam = small_scene(P=2500, C=128, W=203, H=90, fx=170.0, seed=9)
     raster.OUTPUT_PITCH_ALIGN = 32
@@ -110,6 +120,7 @@ def test_sweep2_padded_pitch(orc, variant):
 def test_sweep2_deterministic_under_load(orc, V):
     """The same frame 300 times with two other views in flight on other streams: every feature map bit-identical
     (a stale ring stage -- a bundle consumed before it landed -- would show up as a differing map)."""
+    _gate(V)
     from sgs_hip import raster
     scene, cam = small_scene(P=6000, C=256, W=400, H=160, fx=300.0, seed=21)
     ref = _hip_forward(scene, cam, variant=V)[1].clone()
@@ -131,6 +142,7 @@ def test_feature_scale_invariance_is_bit_exact(variant):
     scales the feature map by exactly that power of two (roundings commute with 2^k away from over / underflow) -- for the
     fp32 chain, for the three-term bf16 splits (split3(2^k x) = 2^k split3(x)) and for the two-term split.  A term that
     lost bits on the way (a non-exact split, a flushed residual) would break the identity."""
+    _gate(variant)
     scene, cam = small_scene(P=5000, C=256, W=208, H=96, fx=170.0, seed=91)
     g = torch.Generator().manual_seed(4)
     scene = scene._replace(bg=torch.randn(256, generator=g))
@@ -144,6 +156,7 @@ def test_feature_scale_invariance_is_bit_exact(variant):
 def test_cooperative_split_equals_presplit_bitwise():
     """V_X6C and V_X6P evaluate the same six products of the same three-term splits (split3 in the sweep / in the weights
     pre-pass): the feature maps are bit-identical."""
+    need_experiments("round 3's sweeps (0x6E / 0x67)")
     for (P, C, W, H, seed) in ((4000, 256, 208, 96, 1), (30000, 128, 400, 64, 2), (500, 512, 48, 40, 3)):
         scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=170.0, seed=seed)
         g = torch.Generator().manual_seed(seed)
@@ -157,6 +170,7 @@ def test_ping_pong_sweep_equals_round3_sweep_bitwise():
     """The ping-pong kernel (default) issues the same six products in the same order into the same accumulators as
     round 3's sweep: bit-identical maps, for staggered and plain pitches, several channel chunks, a non-zero background,
     short segments (seg nibble 1 = 8 tiles: many unpaired halves) and long lists (the table window slides)."""
+    need_experiments("round 3's sweep and the ping-pong experiments (nibbles 14 / 5 / 4)")
     cases = [(4000, 256, 208, 96, 170.0, 1, 1.0), (30000, 128, 400, 64, 170.0, 2, 1.0), (500, 512, 48, 40, 170.0, 3, 1.0),
              (3000, 128, 336, 48, 170.0, 4, 1.0), (40000, 128, 784, 32, 600.0, 77, 3.0)]
     for (P, C, W, H, fx, seed, sc) in cases:
@@ -185,6 +199,7 @@ def test_superbatch_weights_prepass_equals_batch16_bitwise():
     contributor counts are bit-identical across all four kernels.  Cases: lists shorter than one super-batch, lists of thousands
     of entries with most of them rejected at tile level, more than 128 active entries per tile (the work list crosses chunk
     boundaries), more than 16 kept per super-batch (several groups), a non-zero background."""
+    need_experiments("the superseded weights pre-passes (variant bits 14 / 15)")
     from sgs_hip import raster
     cases = [(300, 128, 64, 48, 100.0, 2, 1.0, 1.0), (6000, 256, 400, 160, 300.0, 21, 1.0, 1.0),
              (40000, 128, 784, 32, 600.0, 77, 3.0, 0.05), (60000, 128, 96, 64, 90.0, 5, 0.6, 0.08),
