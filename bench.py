@@ -525,6 +525,12 @@ def main():
             row.append(render(i, False, k)[0])
             torch.cuda.synchronize(dev)
         ref_n.append(row)
+    if world > 1:   # a mis-sharded run shows at a glance: every rank's device, its view numbers and their num_rendered
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "device": f"cuda{local_rank}:{torch.cuda.get_device_name(dev)}",
+                                          "views": [(rank * V + i) * NCAM for i in range(V)],
+                                          "num_rendered_first_camera": [row[0] for row in ref_n]})
+        rccl["per_rank"] = per_rank
 
     # ---- what a user of the reference gets: the drop-in module, called as model/renderer.py:169-185,228 calls it
     def api_path(n=24, debug=True):

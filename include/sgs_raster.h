@@ -281,7 +281,9 @@ int sgs_stream_set_option(void *stream, int option, int value);
 #define SGS_STAT_BWD_POOL_FALLBACKS 6  /* work-list backwards that got no scratch from the stream-ordered pool and ran on the
                                          per-chunk kernel instead (the pool keeps up to SGS_BWD_POOL_RELEASE_MB, default
                                          4096, resident outside the caller's allocator) */
-#define SGS_STAT_COUNT 7
+#define SGS_STAT_TILE_ORDER_ALLOC_FAILURES 7   /* forwards that could not get the stream's tile-order feedback buffer (4 B per tile): they
+                                                  run without the longest-first schedule of the weights pre-pass -- same results */
+#define SGS_STAT_COUNT 8
 int sgs_stream_get_stat(void *stream, int stat, uint64_t *out);
 /* The counts of the last forward on `stream` (see SGS_OPT_DEFER_COUNT): the deferred form of the reference's blocking
  * `cudaMemcpy(&num_rendered, geomState.point_offsets + P - 1, sizeof(int), cudaMemcpyDeviceToHost)`

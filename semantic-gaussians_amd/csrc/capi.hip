@@ -176,6 +176,7 @@ struct Carver {
 struct GeomLayout {
 	sgs_geometry_layout pub;
 	size_t scan_temp, scan_temp_bytes, trap_flag, count_rec, total;
+	size_t totals64, stage_a_tab;   // inside trap_flag's 128-byte block (geom_layout)
 	size_t ds;                     // depth_sort.hip scratch, directly behind trap_flag's 128 bytes (one memset clears both)
 	sgs::DepthSortLayout ds_lay;
 	// depth presort of the Gaussians (binning modes 0 and 2)
@@ -201,7 +202,10 @@ GeomLayout geom_layout(int P)
 	g.scan_temp_bytes = sgs::scan_temp_bytes(P);
 	g.scan_temp = c.take(g.scan_temp_bytes);
 	g.count_rec = c.take(16);   // deferred-count forward: {num_rendered, major instances, trap, abort}
-	g.trap_flag = c.take(128);
+	g.trap_flag = c.take(128);   // one 128-byte block, cleared by one memset: [0] trap word | [64] 64-bit totals (major instances << 32 | instances) | [80] stage A's six table words
+	g.totals64 = g.trap_flag + 64;
+	g.stage_a_tab = g.trap_flag + 80;
+	static_assert(80 + 6 * 4 <= 128 && 64 + 8 <= 80, "the trap block's fields overlap");
 	sgs::depth_sort_layout(P, &g.ds_lay);
 	g.ds = c.take(g.ds_lay.total);   // (128-aligned: starts right behind trap_flag; its count matrices come first)
 	g.perm = c.take(p * 4);
@@ -635,8 +639,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
 	if (presort) {
 		sgs::DepthSortSpanOut span{radii, means2D, gx, gy, gx >= gy, (uint64_t*)(gchunk + gl.counts64),
-					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.trap_flag + 64),
-					   (uint32_t*)(gchunk + gl.trap_flag + 80), 0u, 0u};   // (+80: six spare words of the trap block)
+					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.totals64),
+					   (uint32_t*)(gchunk + gl.stage_a_tab), 0u, 0u};
 		sgs::row_binning_stage_a_counts(P, &span.stage_a_chunks, &span.stage_a_groups);
 		e = sgs::launch_depth_sort(st, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm, rows ? &span : nullptr);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
@@ -663,7 +667,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// thread can keep several streams fed.  The return value is then the CAPACITY the binning buffer was laid out
 	// for, not num_rendered -- such a forward cannot be handed to sgs_rasterize_backward.
 	// sum over the Gaussians of (major instances << 32 | instances): the scan's last element, or the own sort's total
-	const uint64_t* totals64 = (const uint64_t*)(gchunk + gl.trap_flag + 64);   // (rows)
+	const uint64_t* totals64 = (const uint64_t*)(gchunk + gl.totals64);   // (rows)
 	const int defer_opt = cx->option(SGS_OPT_DEFER_COUNT);
 	if (cx->count_pending && cx->count_ev && hipEventQuery(cx->count_ev) == hipSuccess) {
 		// a deferred frame nobody asked about: still learn from it
@@ -794,7 +798,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
 					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list,
 					    abort_word, use_split ? (uint32_t*)(bchunk + bl.arena + bl.arena_lay.counter) : nullptr,
-					    (uint32_t)ntiles * 128u, (const uint32_t*)(gchunk + gl.trap_flag + 80));
+					    (uint32_t)ntiles * 128u, (const uint32_t*)(gchunk + gl.stage_a_tab));
 		counter_reset_done = use_split && Rrows != 0;   // (launch_row_binning with R == 0 is just a memset)
 		if (e != hipSuccess) return fail_hip(e, "row binning");
 		SGS_CHECK_STAGE("row binning");
@@ -890,20 +894,25 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 			if (e != hipSuccess) return fail_hip(e, "memset (norm plane)");
 		}
 		struct MarkCtx { StageTimer* t; } mctx{&tm};
-		// the stream's tile-order feedback buffer (allocated when the tile grid first appears / grows; hipFree waits for the
-		// device, so a buffer still in use by an earlier frame is never pulled away).  SGS_NO_TILE_ORDER=1: A/B switch.
+		// the stream's tile-order feedback buffer: stream-ordered allocations on `st` (hipMalloc / hipFree inside a
+		// forward synchronise the whole device -- every other stream's frames in flight stall -- and are illegal under stream
+		// capture), grown in powers of two so that a growing grid reallocates log(n) times; the old block is freed in stream
+		// order behind the frames that still read it.  A failure is counted and costs only the schedule.  SGS_NO_TILE_ORDER=1: A/B switch.
 		static const bool no_tile_order = getenv("SGS_NO_TILE_ORDER") && atoi(getenv("SGS_NO_TILE_ORDER")) != 0;
 		if (!no_tile_order && cx->tile_order_cap < (size_t)ntiles) {
-			if (cx->tile_order) (void)hipFree(cx->tile_order);
+			if (cx->tile_order) (void)hipFreeAsync(cx->tile_order, st);
 			cx->tile_order = nullptr;
 			cx->tile_order_cap = 0;
-			if (hipMalloc((void**)&cx->tile_order, ((size_t)ntiles + 1) * 4) == hipSuccess &&
+			size_t want = 8192;
+			while (want < (size_t)ntiles) want *= 2;
+			if (hipMallocAsync((void**)&cx->tile_order, (want + 1) * 4, st) == hipSuccess && cx->tile_order &&
 			    hipMemsetAsync(cx->tile_order, 0, 4, st) == hipSuccess)
-				cx->tile_order_cap = (size_t)ntiles;
+				cx->tile_order_cap = want;
 			else {
 				(void)hipGetLastError();
-				if (cx->tile_order) (void)hipFree(cx->tile_order);
+				if (cx->tile_order) (void)hipFreeAsync(cx->tile_order, st);
 				cx->tile_order = nullptr;
+				cx->stat[SGS_STAT_TILE_ORDER_ALLOC_FAILURES]++;
 			}
 		}
 		a.tile_order = no_tile_order ? nullptr : cx->tile_order;

@@ -2,11 +2,11 @@
 
 The rasteriser consumes the *transposed* world->view and full projection
 matrices, flattened row-major (element m[4*col+row] of the column-vector
-convention).  This restates how the reference builds them
-(scene/camera.py:81-94, utils/graphics_utils.py:38-78) so that synthetic
-benchmarks and tests can run without the reference's scene loaders; the
-values are pinned against fixtures generated from the reference's own helpers
-(tests/golden/cameras.json).
+convention).  Input generator for the synthetic benchmarks and tests -- the
+reference builds the same matrices in scene/camera.py:81-94 with the helpers of
+utils/graphics_utils.py; the outputs here are pinned bit for bit against fixtures
+generated from those helpers (tests/golden/reference_fixtures.json,
+tests/test_oracle_kat.py::test_cameras_match_reference_fixtures).
 """
 import math
 from typing import NamedTuple
@@ -20,36 +20,28 @@ def focal2fov(focal, pixels):
 
 
 def world2view(R, t, translate=(0.0, 0.0, 0.0), scale=1.0):
-    """utils/graphics_utils.py:38-50 (getWorld2View2)."""
-    Rt = np.zeros((4, 4))
-    Rt[:3, :3] = np.asarray(R, dtype=np.float64).transpose()
-    Rt[:3, 3] = np.asarray(t, dtype=np.float64)
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    cam_center = C2W[:3, 3]
-    cam_center = (cam_center + np.asarray(translate, dtype=np.float64)) * scale
-    C2W[:3, 3] = cam_center
-    Rt = np.linalg.inv(C2W)
-    return np.float32(Rt)
+    """The 4 x 4 world -> view matrix of a camera given the way the reference's loaders give it: R = the camera-to-world rotation, t = the
+    world-to-view translation, i.e.  x_view = R^T x_world + t  (same convention and outputs as utils/graphics_utils.py:38-50; pinned
+    by tests/golden/reference_fixtures.json).  `translate` / `scale` move the camera CENTRE, c -> (c + translate) * scale (the
+    reference's scene normalisation); the rotation is untouched, so only the last column changes: t' = -R^T c'."""
+    Rm = np.asarray(R, dtype=np.float64)
+    centre = -Rm @ np.asarray(t, dtype=np.float64)                      # x_view = 0  <=>  x_world = -R t
+    centre = (centre + np.asarray(translate, dtype=np.float64)) * scale
+    m = np.eye(4)
+    m[:3, :3] = Rm.T
+    m[:3, 3] = -Rm.T @ centre
+    return m.astype(np.float32)
 
 
 def projection_matrix(znear, zfar, fovX, fovY):
-    """utils/graphics_utils.py:53-78 (getProjectionMatrix)."""
-    tanHalfFovY = math.tan(fovY / 2)
-    tanHalfFovX = math.tan(fovX / 2)
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
+    """Perspective projection of a symmetric frustum, z_view in [znear, zfar] -> depth in [0, 1], w = z_view (the reference's
+    utils/graphics_utils.py:53-78 reduces to this for its symmetric left / right, top / bottom): five non-zero entries."""
     P = torch.zeros(4, 4)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[0, 0] = 1.0 / math.tan(0.5 * fovX)
+    P[1, 1] = 1.0 / math.tan(0.5 * fovY)
+    P[2, 2] = zfar / (zfar - znear)
     P[2, 3] = -(zfar * znear) / (zfar - znear)
+    P[3, 2] = 1.0
     return P
 
 
@@ -80,9 +72,9 @@ class PinholeCamera(NamedTuple):
 def make_camera(R, T, FoVx, FoVy, width, height, znear=0.01, zfar=100.0,
                 trans=(0.0, 0.0, 0.0), scale=1.0):
     """scene/camera.py:81-94."""
-    wvt = torch.tensor(world2view(R, T, trans, scale)).transpose(0, 1)
-    proj = projection_matrix(znear=znear, zfar=zfar, fovX=FoVx, fovY=FoVy).transpose(0, 1)
-    full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+    # the rasteriser takes both matrices TRANSPOSED (row-vector convention: x_clip = x_world . full)
+    wvt = torch.from_numpy(world2view(R, T, trans, scale)).t()
+    full = wvt @ projection_matrix(znear, zfar, FoVx, FoVy).t()
     center = wvt.inverse()[3, :3]
     return PinholeCamera(int(width), int(height), float(FoVx), float(FoVy), wvt.contiguous(),
                          full.contiguous(), center.contiguous())

@@ -2,6 +2,7 @@
 Parity unpinned against a reference-WRITTEN file (the reference's reader / writer needs `plyfile`, absent here); the layout its
 code defines is pinned by a hand-derived byte fixture (tests/golden/gaussians_deg1.ply): header text against the PLY 1.0 layout the
 reference's attribute list implies, round trips, and reading by NAME like load_ply."""
+import os
 import struct
 
 import numpy as np
@@ -87,6 +88,30 @@ def test_fusion_pt_round_trip(tmp_path):
     assert d["feat"].shape == (int(mask.sum()), 16) and torch.equal(d["mask_full"], mask)
     back, m2 = sio.load_fusion_features(p2)
     assert torch.equal(m2, mask) and torch.equal(back[mask], feat[mask].half().float()) and float(back[~mask].abs().sum()) == 0
+
+
+def test_fusion_pt_fixture_in_the_reference_format(tmp_path):
+    """The fusion `.pt` format pinned the way the PLY is: tests/golden/gen_fusion_pt_fixture.py writes what fusion.py:234-257 writes
+    (torch.save of {"feat": fp16 rows, "mask_full": bool}; masked files hold only the masked rows) with torch alone; the reader
+    returns the closed-form values with zeros for unmasked points, and the writer's files load into dicts equal to the fixtures'
+    (keys in the same order, dtypes, shapes, values).  Not a file written BY the reference (it needs omegaconf / a scene) -- its
+    two torch.save statements are what the generator executes."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    P, C = 12, 8
+    want = (torch.arange(P, dtype=torch.float32)[:, None] - 3.0) / 4.0 + torch.arange(C, dtype=torch.float32)[None, :] / 64.0
+    sel = torch.zeros(P, dtype=torch.bool)
+    sel[[1, 4, 5, 9, 11]] = True
+    for name, mask in (("fusion_full.pt", None), ("fusion_masked.pt", sel)):
+        feat, m = sio.load_fusion_features(os.path.join(gold, name))
+        ref_mask = torch.ones(P, dtype=torch.bool) if mask is None else mask
+        assert m.dtype == torch.bool and torch.equal(m, ref_mask)
+        assert feat.dtype == torch.float32 and torch.equal(feat[ref_mask], want[ref_mask]) and float(feat[~ref_mask].abs().sum()) == 0
+        out = str(tmp_path / name)
+        sio.save_fusion_features(out, want, mask)
+        a, b = torch.load(out), torch.load(os.path.join(gold, name))
+        assert list(a.keys()) == list(b.keys()) == ["feat", "mask_full"]
+        for k in a:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (name, k)
 
 
 def test_ascii_ply_is_read_too(tmp_path):

@@ -44,6 +44,37 @@ def test_cameras_match_reference_fixtures():
         assert np.array_equal(cam.camera_center.numpy().astype(np.float64), np.array(c["camera_center"]))
 
 
+def test_sh_dense_directions_match_reference_eval_sh(orc):
+    """kernel and oracle evaluate the same GENERATED monomial table (tools/gen_sh_table.py), so their bit-exact agreement
+    cannot catch a generator bug.  1 024 known answers of the reference's own eval_sh (utils/sh_utils.py, float64; fixture
+    tests/golden/sh_dense.npz, generator beside it): the oracle's SH -> RGB within a few fp32 ulps of the value's scale
+    (sum_n |Y_n sh_n| + 0.5), the clamp flags equal wherever the unclamped value is not within that bound of zero."""
+    z = np.load(os.path.join(GOLD, "sh_dense.npz"))
+    cam = pinhole(64, 64, 3.0)   # (a very wide view: the directions cover most of the front hemisphere)
+    worst = 0.0
+    for deg in range(4):
+        sh, pos, ref = z[f"sh{deg}"], z[f"pos{deg}"], z[f"res{deg}"]
+        n = sh.shape[0]
+        shs = np.ascontiguousarray(sh.transpose(0, 2, 1))   # rasteriser layout (P, M, 3)
+        pre = orc.preprocess(pos, np.full((n, 1), 0.5, np.float32), cam.world_view_transform.numpy(),
+                             cam.full_proj_transform.numpy(), np.zeros(3, np.float32), 64, 64, cam.tanfovx, cam.tanfovy,
+                             scales=np.full((n, 3), 0.05, np.float32), rotations=np.tile(np.array([[1, 0, 0, 0]], np.float32), (n, 1)),
+                             shs=shs, sh_degree=deg)
+        vis = pre["radii"] > 0
+        assert vis.sum() > n // 2
+        nb = (deg + 1) ** 2
+        scale = np.abs(sh[:, :, :nb]).sum(axis=2) + 0.5       # |Y_n| <= ~1.5: the terms' magnitude
+        want = ref + 0.5
+        got = pre["rgb"]
+        tol = 6.0 * 2.0 ** -23 * scale
+        err = np.abs(got.astype(np.float64) - np.maximum(want, 0.0))
+        assert (err[vis] <= tol[vis]).all(), (deg, float((err[vis] / scale[vis]).max()))
+        worst = max(worst, float((err[vis] / scale[vis]).max()))
+        sure = np.abs(want) > tol
+        assert np.array_equal(pre["clamped"].astype(bool)[vis & sure.all(axis=1)], (want < 0)[vis & sure.all(axis=1)])
+    print(f"dense SH known answers: worst |oracle - reference| = {worst:.2e} of the terms' magnitude")
+
+
 def test_sh_matches_reference_eval_sh(orc):
     """oracle SH->RGB (before +0.5/clamp) == utils/sh_utils.py eval_sh (fixture)."""
     fx = json.load(open(os.path.join(GOLD, "reference_fixtures.json")))
