@@ -8,8 +8,10 @@ Metric (BASELINE.json): Gpixel*channels/s of the FORWARD feature render,
 
 What one JSON line carries (rank 0):
   value / ms_per_step   the contract's number: K timed steps between barriers, a step = `--views` (default 4) views of
-                        the scene in flight on as many HIP streams, every forward with the reference's blocking
-                        num_rendered read-back (rasterizer_impl.cu:283) and a different camera every step; DEFAULT
+                        the scene in flight on as many HIP streams, every forward returning its num_rendered to the host
+                        as the reference's does (round 5: through raster.rasterize_forward_inference -- the frame is enqueued
+                        in full before the host waits for the count, what the drop-in module does under torch.no_grad();
+                        `classic_count` = the reference's mid-frame wait, rounds 1-4's headline) and a different camera every step; DEFAULT
                         arithmetic of the C >= 128 blend: "f32-equivalent" -- features and weights split exactly into
                         three bf16 terms, six MFMA products, fp32 accumulate (as accurate as the reference's fp32 chain
                         against the exact composite: tests/test_configs_gpu.py) -- `dtype` says so.  The default K keeps
@@ -333,6 +335,10 @@ def main():
     ap.add_argument("--views", type=int, default=4,
                     help="views in flight per GPU: a step renders this many views of the scene, one per HIP "
                          "stream, so one view's front-end and host round trip overlap another view's blend")
+    ap.add_argument("--classic-count", action="store_true",
+                    help="headline with the host waiting for num_rendered in the MIDDLE of every forward (the reference's own host pattern, "
+                         "rasterizer_impl.cu:283, and rounds 1-4's headline); default: the inference entry point -- the frame is enqueued in "
+                         "full against the stream's capacity guess, then the host waits for the count (what GaussianRasterizer does under no_grad)")
     ap.add_argument("--deferred-count", action="store_true",
                     help="headline with deferred counts (SGS_OPT_DEFER_COUNT, inference only) instead of the reference's "
                          "blocking num_rendered read-back in every forward")
@@ -404,7 +410,8 @@ def main():
                       c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, empty, 0,
                       c.camera_center, False, False, C, False, pool=pools[i])
 
-    DEFER = args.deferred_count
+    # host pattern of a forward: "speculative" (default: raster.rasterize_forward_inference), "classic" (mid-frame wait), True = deferred counts
+    DEFER = True if args.deferred_count else ("classic" if args.classic_count else "speculative")
 
     def step(k=0, defer=None, prev=None):   # one batch: V views of the scene (camera k of every slot), all in flight together
         # `prev`: the previous step's results.  Slot i's old feature map is released right before slot i renders again: the
@@ -413,11 +420,18 @@ def main():
         def drop(i):
             if prev is not None:
                 prev[i] = None
-        if not (DEFER if defer is None else defer):   # the reference's host pattern: every forward blocks on its num_rendered read-back
+        mode = DEFER if defer is None else defer
+        if mode in (False, "classic"):   # the reference's host pattern: every forward blocks on its num_rendered read-back in the middle of the frame
             res = []
             for i in range(V):
                 drop(i)
                 res.append(render(i, False, k))
+            return res
+        if mode == "speculative":   # every forward still returns its num_rendered (the host waits for it), but only after the whole frame is enqueued
+            res = []
+            for i in range(V):
+                drop(i)
+                res.append(render(i, True, k).result())
             return res
         # deferred counts (SGS_OPT_DEFER_COUNT): all V forwards are enqueued without the host waiting for the GPU,
         # then every frame's counts are checked (a frame that outgrew its capacity guess is rendered again there)
@@ -621,11 +635,11 @@ def main():
     del out, color
 
     # ---- other arithmetics / host patterns, the backward (N = 1 extras; skipped under --no-extras)
-    exact = backward = two_term = deferred = None
+    exact = backward = two_term = deferred = classic = None
     kx = max(8, min(args.steps, 60))
 
     def extra_leg(variant, what, defer=None):
-        sv, stg = single_view(variant, deferred=bool(defer))
+        sv, stg = single_view(variant, deferred=defer is True)
         ms_e, ms_e_med, mism_e, out_e, retr = in_flight(variant, kx, max(3, NCAM + 2), defer=defer)   # every camera of a slot and the wrap-around seen once: buffers at their steady size
         del out_e
         return {"arithmetic": what, "value": world * V * H * W * C / (ms_e * 1e-3) / 1e9, "unit": "Gpixel*channels/s",
@@ -636,6 +650,8 @@ def main():
         exact = extra_leg(EXACT, "fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate: bit-identical to the contract")
         two_term = extra_leg(TWO_TERM, "round 2's default: two bf16 terms per operand, three MFMA products "
                                        "(<= 3 * 2^-16 of sum |f| w per term): NOT fp32-class, kept selectable (blend variant 14)")
+        classic = extra_leg(args.variant, "default arithmetic, the host waits for num_rendered in the MIDDLE of every forward (the reference's host "
+                                          "pattern, rasterizer_impl.cu:283; rounds 1-4's headline)", defer="classic")
         deferred = extra_leg(args.variant, "default arithmetic, deferred counts (SGS_OPT_DEFER_COUNT, inference only): no host "
                                            "read-back inside the forward", defer=True)
         raster.set_blend_variant(args.variant)
@@ -773,7 +789,11 @@ def main():
                                       f"scene replicated, no collective",
                        "rccl": rccl,
                        "cameras": f"each of the {V} view slots cycles through {NCAM} cameras: a different view every step",
-                       "num_rendered": ("blocking read-back in every forward (the reference's host pattern, rasterizer_impl.cu:283)" if not DEFER else
+                       "num_rendered": ("blocking read-back in the middle of every forward (the reference's host pattern, rasterizer_impl.cu:283)" if DEFER == "classic" else
+                                        "every forward returns its num_rendered as the reference's does (the host waits for it), after the whole frame was "
+                                        "enqueued against the stream's capacity guess: raster.rasterize_forward_inference, what the drop-in module does under "
+                                        "torch.no_grad() (a frame that outgrew the guess is rendered again; every num_rendered is compared with the serial render); "
+                                        "classic_count below = rounds 1-4's headline pattern" if DEFER == "speculative" else
                                         "deferred (SGS_OPT_DEFER_COUNT): buffers sized from the stream's previous frame, counts "
                                         "checked on the device and on the host once per step; every step's num_rendered is "
                                         "compared with the serial render (integrity)"),
@@ -796,6 +816,7 @@ def main():
                                           "enqueued against the stream's capacity guess before the host waits for num_rendered (what "
                                           "GaussianRasterizer does under torch.no_grad(); single_view above keeps the reference's mid-frame wait)"),
             "api_path": api,
+            "classic_count": classic,
             "deferred_count": deferred,
             "exact_f32": exact,
             "two_term": two_term,

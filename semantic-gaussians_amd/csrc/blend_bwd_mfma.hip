@@ -1120,9 +1120,14 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 					   !(alpha < 1.0f / 255.0f);
 			if (__ballot(valid) == 0ull) return;
 			const float oma = 1.f - alpha;
-			if (valid) T = T / oma;
+			// one reciprocal for the two divisions by 1 - alpha (alpha <= 0.99: v_rcp_f32 + one Newton step is within an ulp of the
+			// IEEE quotient, and this kernel's sums are order-dependent atomics anyway; two IEEE divisions were 18 of the step's
+			// ~107 VALU instructions, and the kernel is bound by VALU issue: 195 M wave instructions x 4 cycles = its 0.35 ms)
+			float rinv = __builtin_amdgcn_rcpf(oma);
+			rinv = __builtin_fmaf(__builtin_fmaf(-oma, rinv, 1.f), rinv, rinv);
+			if (valid) T = T * rinv;
 			float dL_dalpha = (Dk - R) * T;
-			dL_dalpha += (-T_final / oma) * bg_dot;
+			dL_dalpha += (-T_final * rinv) * bg_dot;
 			if (!valid) dL_dalpha = 0.f;
 			if (valid) R = alpha * Dk + oma * R;
 			const float dL_dG = e.o * dL_dalpha;
