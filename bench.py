@@ -801,7 +801,8 @@ def main():
                        "blend_arithmetic": ("fp32 MFMA, bit-exact" if not split else
                                             "every weight, decision and integer output in contract fp32 (bit-exact); the C >= 128 "
                                             "weighted sum with features and weights split EXACTLY into three bf16 terms each, the six "
-                                            "products with i + j <= 4 on v_mfma_f32_32x32x8_bf16, fp32 accumulate.  tests: against the "
+                                            "products with i + j <= 4 on v_mfma_f32_32x32x16_bf16 (round 5: the double-rate MFMA in the ping-pong sweep, whose workgroups own "
+                                            "their compute units -- DESIGN.md 5.10), fp32 accumulate.  tests: against the "
                                             "exact (float64) composite it is as accurate as the oracle's fp32 fma chain (max and rms "
                                             "of the element-wise error |x - exact| / max(|exact|, 1e-3 |pixel|_inf)); against the oracle "
                                             "itself |out - oracle| <= 5e-6 |pixel|_inf everywhere, and the element-wise form exceeds 1e-4 "

@@ -297,36 +297,20 @@ int sgs_forward_result(void *stream, int wait, int *num_rendered);
  * context alive until they return. */
 int sgs_stream_release(void *stream);
 
-/* Selects the forward blend kernels (tuning / A-B measurements).
- *   0 (default) = for num_channels >= 128: weights pre-pass + row-sweep accumulate for the 128-channel-aligned part in
- *                 "f32-equivalent" arithmetic: features and weights split EXACTLY into three bf16 terms each, the six
- *                 products with i + j <= 4 on v_mfma_f32_32x32x8_bf16, fp32 accumulate -- measured against the exact
- *                 (float64) composite it is as accurate as the reference's fp32 multiply-add chain
- *                 (CR/cuda_rasterizer/forward.cu:355-356), every integer output bit-exact; px1 for the remainder
- *                 channels; px1 below 128 channels / RGB-D;
- *  15           = as 0 but the accumulate is the fp32-input MFMA kernel: the feature map is BIT-IDENTICAL to the
- *                 contract's fp32 fma chain (what SGS_BLEND_EXACT=1 selects in the Python layer);
- *  14           = round 2's arithmetic: two bf16 terms per operand, three products (<= 3 * 2^-16 of sum |f| w):
- *                 the fastest, NOT fp32-class;
- *  1/2/3        = single-kernel px1 with 64/128/32 channels per workgroup; 4/5/6 = single-kernel px4
- *                 forms (all bit-identical);
- *  >= 16        = sweep tuning word: bits [3:0] accumulate kernel (6 = round 4's ping-pong sweep -- one 8-wave workgroup per
- *                 (segment, 128 channels) for both row parities, six products with pre-split weights: THE DEFAULT; 5 = the same
- *                 with fp32 weights handed over and split one step ahead inside the sweep (experiment, bit-identical,
- *                 slower: DESIGN.md 5.11), 4 = the same without its barriers (the halves run free on per-stage counters:
- *                 experiment, bit-identical, slower); 8 =
- *                 variant 14's, 9 = its fp32-MFMA form; blend_sweep2.hip: 10 six products with the weights split in the
- *                 sweep, 11 fp32 MFMA, 13 as 10 block by block, 14 round 3's sweep (two workgroups per CU; the same
- *                 arithmetic as 6, bit-identical), 7 as 14 with fp32 weights handed over and split once per workgroup into
- *                 LDS (experiment, bit-identical); 12 / 15 = 10 / 14 on the double-rate v_mfma_f32_32x32x16_bf16, and bits
- *                 [19:16] = 1..3 with kernel 6 = the ping-pong sweep on it -- NOT IN THE PRODUCT LIBRARY (`make X16=1`; the
- *                 default build answers SGS_EINVAL): forwards running beside these kernels come out damaged on some boxes,
- *                 a library GEMM beside the same victim does not do that), [7:4] segment length / 8
- *                 (0 = adaptive), [11:8] development ablations (1 = no stores, 2 = no matrix work, 4 / 8 = phase clocks /
- *                 store forms), [13:12] workgroup order (0 / 3 = segments sorted by work and dealt to the XCDs, 1 = row-major,
- *                 2 = dealt unsorted), [14] / [15] A/B switches of the weights pre-pass (three-term format: 0 = two pixels per
- *                 lane, super-batches: the default; 0x4000 = lane per pixel, super-batches; 0x8000 / 0xC000 = the
- *                 16-entry-batch kernels of rounds 2 / 3; all bit-identical).
+/* Selects the forward blend kernels.  The product library (sgs_build_flags() == 0) knows:
+ *   0  (default) num_channels >= 128: weights pre-pass + ping-pong row sweep for the 128-channel-aligned part in "f32-equivalent"
+ *      arithmetic -- features and weights split EXACTLY into three bf16 terms each, the six products with i + j <= 4 on
+ *      v_mfma_f32_32x32x8_bf16, fp32 accumulate: against the exact (float64) composite as accurate as the reference's fp32
+ *      multiply-add chain (CR/cuda_rasterizer/forward.cu:355-356), every integer output bit-exact; the px1 kernel for the
+ *      remainder channels, below 128 channels and for RGB-D;
+ *   15 as 0 with the fp32-input MFMA sweep: the feature map is BIT-IDENTICAL to the contract's fp32 fma chain (SGS_BLEND_EXACT=1);
+ *   14 round 2's arithmetic: two bf16 terms per operand, three products (<= 3 * 2^-16 of sum |f| w): the fastest, NOT fp32-class;
+ *   6  the single-kernel px4 form for the 128-aligned part (the gated fallback of 0 when its work list overflows);
+ *   >= 16, the word form:  bits [3:0] sweep (6 = 0's, 11 = 15's, 0 / 8 = 14's) | [7:4] segment length / 8 tiles (0 = adaptive)
+ *      | [13:12] workgroup order (0 / 3 = segments sorted by work and dealt to the XCDs, 1 = row-major, 2 = dealt unsorted).
+ * Everything else -- sweep nibbles 4 / 5 / 7 / 9 / 10 / 13 / 14, ablation bits [11:8], pre-pass switches [15:14], single-kernel
+ * forms 1-5 -- is a development form (`make EXPERIMENTS=1`; DESIGN.md 5.x has the measurements), 12 / 15 / [19:16] the
+ * double-rate-MFMA reproducers (`make X16=1`), 32-35 round 2's fused kernels (`make FUSED=1`): SGS_EINVAL here.
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
 /* Device time (ms, hipEvents on `stream`) of each stage of the forward.

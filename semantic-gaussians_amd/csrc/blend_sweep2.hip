@@ -1151,6 +1151,10 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int PW,
 	unsigned long long* __restrict__ trace, const uint32_t* __restrict__ order, int dealt, int tune)
 {
+	// (x16 forms) 144 AGPRs + 112 VGPRs = 256 registers per wave: two waves per SIMD fill its register file, so that NO foreign wave --
+	// not even an 8-register fill kernel -- can be resident on this workgroup's compute unit between its first and its last matrix
+	// instruction (all eight waves are resident from dispatch; the last matrix phase lies before the final barrier every wave passes)
+	if constexpr (MM != 0) asm volatile("" : : : "a143");
 	if (counter[1] != 0u) return;   // arena overflowed / frame aborted
 	(void)tune;   // (tuning word, bits [19:16] of the blend variant: unused -- call E's placement / priority experiments are settled,
 	// profiles/r04_sweep_dma_placement.txt: pieces issued in PREP cost 300-400 cycles each, per-phase priorities change nothing)
@@ -1673,21 +1677,25 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt, tune)
-#ifdef SGS_WITH_X16   // (make X16=1) bits [19:16] of the variant: 1 = x16 dense, 2 = x16 + s_nop filler, 3 = x16 + VALU filler
-	if (tune >= 1 && tune <= 3) {
+	// bits [19:16] of the variant: 1 = the sweep on the double-rate v_mfma_f32_32x32x16_bf16, dense (round 5: THE DEFAULT -- the workgroup
+	// owns its compute unit); (make X16=1) 2 = x16 + s_nop filler, 3 = x16 + VALU filler
 #define S3_LAUNCH_MM(M_)                                                                             \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, M_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt, tune)
-		if (tune == 1) S3_LAUNCH_MM(1);
-		else if (tune == 2) S3_LAUNCH_MM(2);
-		else S3_LAUNCH_MM(3);
-#undef S3_LAUNCH_MM
+	if (tune == 1 && dbg == 0 && form == 0) {
+		S3_LAUNCH_MM(1);
 		return hipGetLastError();
 	}
-#else
-	if (tune != 0) return hipErrorInvalidValue;   // (the x16 forms of this sweep are not in the product library)
+#ifdef SGS_WITH_X16
+	if (tune == 2 || tune == 3) {
+		if (tune == 2) S3_LAUNCH_MM(2);
+		else S3_LAUNCH_MM(3);
+		return hipGetLastError();
+	}
 #endif
+#undef S3_LAUNCH_MM
+	if (tune != 0) return hipErrorInvalidValue;
 #ifndef SGS_WITH_EXPERIMENTS   // the product library holds ONE ping-pong sweep; the forms below are make EXPERIMENTS=1
 	(void)coop;
 	if (form != 0 || dbg != 0) return hipErrorInvalidValue;

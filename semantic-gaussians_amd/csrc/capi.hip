@@ -736,17 +736,22 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		return fail(SGS_EINVAL, "blend variants 32-35 (fused single-kernel experiments) are not in this build (make FUSED=1)");
 #endif
 #ifndef SGS_WITH_X16   // (make X16=1: the double-rate-MFMA experiments, DESIGN.md 5.10 -- reproducers, not product)
+	// (the x16 forms whose workgroups leave room for foreign waves on their compute unit -- round 2's and round 3's sweeps -- and the
+	// filler forms of the ping-pong sweep; the DENSE x16 ping-pong sweep, 0x1 << 16 | ..6, ships: it is the default)
 	if (variant >= 16 && ((variant & 15) == 12 || (variant & 15) == 15 || ((variant & 15) == 8 && ((variant >> 8) & 15) == 8) ||
-			      ((variant & 15) == 6 && ((variant >> 16) & 15) != 0)))
-		return fail(SGS_EINVAL, "blend variants on v_mfma_f32_32x32x16_bf16 (sweep nibble 12 / 15, 0x8.8, 0x1..3 << 16 | ..6) are not in this build (make X16=1)");
+			      ((variant & 15) == 6 && ((variant >> 16) & 15) > 1)))
+		return fail(SGS_EINVAL, "blend variants on v_mfma_f32_32x32x16_bf16 other than the ping-pong sweep (sweep nibble 12 / 15, 0x8.8, 0x2..3 << 16 | ..6) are not in this build (make X16=1)");
 #endif
 #ifndef SGS_WITH_EXPERIMENTS   // (make EXPERIMENTS=1: the development forms, csrc/Makefile)
 	{
 		// what ships: 0 (default) / 6 (single-kernel px4 form, also the gated fallback) / 14 (round 2's two-term sweep) / 15 (exact fp32), and the
-		// word form  sweep nibble {0, 8: two-term | 6: default | 11: exact} | segment length [7:4] | workgroup order [13:12]  -- nothing else
+		// word form  sweep nibble {0, 8: two-term | 6: ping-pong | 11: exact} | segment length [7:4] | workgroup order [13:12] |
+		// [19:16] 1 = the ping-pong sweep on the x16 MFMA (the default), 0 = on x8  -- nothing else
 		const int nib = variant & 15;
 		const bool plain = variant == 0 || variant == 6 || variant == 14 || variant == 15;
-		const bool word = variant >= 16 && variant < 0x4000 && ((variant >> 8) & 15) == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11);
+		const int tune = (variant >> 16) & 15;
+		const bool word = variant >= 16 && (variant & ~0xF30FF) == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11) &&
+				  (tune == 0 || (tune == 1 && nib == 6));   // bits [19:16] = 1: the x16 ping-pong sweep (what 0 selects)
 		if (!plain && !word && !want_fused)
 			return fail(SGS_EINVAL, "this blend variant is a development form that is not in this build (make EXPERIMENTS=1)");
 	}
@@ -885,7 +890,12 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		// products in round 3's two-workgroups-per-CU sweep, bit-identical); variant 15 = 11 = fp32-input MFMA, bit-identical to
 		// the contract; variant 14 = 8 = round 2's two-term split (three products, 3 * 2^-16 per term: the fastest, not fp32-class).
 		// SGS_DEFAULT_SWEEP=14 (environment, read once) restores round 3's kernel as the default for A/B runs.
-		static const int default_sweep = (getenv("SGS_DEFAULT_SWEEP") && atoi(getenv("SGS_DEFAULT_SWEEP")) == 14) ? 14 : 6;
+		// Round 5: the default is the ping-pong sweep on the double-rate v_mfma_f32_32x32x16_bf16 (word 0x10006: sweep nibble 6, bits [19:16]
+		// = 1).  DESIGN.md 5.10: dense x16 issue damages packed-fp32 results of FOREIGN waves resident on the same compute unit (0 events
+		// in 180 000 forwards once victim and aggressor are confined to disjoint CU masks, 557 with shared CUs) -- and the ping-pong
+		// workgroup owns its CU outright: 8 waves x 256 registers, 139 KB of LDS, every wave resident from before the first to after the
+		// last matrix instruction.  SGS_DEFAULT_SWEEP=6 (environment, read once) restores the x8 form, =14 round 3's kernel (EXPERIMENTS).
+		static const int default_sweep = !getenv("SGS_DEFAULT_SWEEP") ? 0x10006 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 14 ? 14 : 6);
 		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : default_sweep));
 		if (norm_plane) {
 			if ((split_word & 15) != 14 && (split_word & 15) != 11 && (split_word & 15) != 6)

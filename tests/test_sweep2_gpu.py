@@ -5,6 +5,8 @@ the oracle, through the C-ABI.  Variants (low nibble of the blend variant; 0x60 
   0x6E  the same with the weights pre-split by the weights pre-pass (round 3's default);
   0x66  round 4's default: the 0x6E arithmetic in the ping-pong sweep (one 8-wave workgroup for both row parities,
         MFMA phase of one half beside the load / store phase of the other) -- bit-identical to 0x6E;
+  0x10066  round 5's default: the ping-pong sweep on the double-rate v_mfma_f32_32x32x16_bf16 (the same six products, 16 k per
+        instruction instead of 8: a feature map of its own, held to the same bounds);
   (0x6C / 0x6F, the double-rate-MFMA experiments, are not in the product library: make X16=1.)
 Every integer output stays bit-exact (it comes from the shared front end and weights pre-pass)."""
 import numpy as np
@@ -18,9 +20,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 V_X6, V_EXACT, V_X6W, V_X6S, V_X6P, V_X6PW = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E, 0x6F
-V_PP = 0x66       # round 4: ping-pong sweep (the default kernel; 0x6_ pins 48-tile segments like the others)
+V_PP = 0x66       # round 4: ping-pong sweep on the x8 MFMA (0x6_ pins 48-tile segments like the others)
+V_PP16 = 0x10066  # round 5, THE DEFAULT kernel: the ping-pong sweep on the double-rate v_mfma_f32_32x32x16_bf16 (same products, 16 k per instruction)
 V_X6C = 0x67      # six products, fp32 weights handed over, split once per workgroup into LDS: bit-identical to V_X6P
-SHIPS = (0, 14, 15, V_EXACT, V_PP)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
+SHIPS = (0, 14, 15, V_EXACT, V_PP, V_PP16)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
 
 
 def _gate(variant):
@@ -67,7 +70,7 @@ def check(orc, scene, cam, variant, seg=None, **kw):
 SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64), (128, 336, 48)]
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6S, V_X6P, V_X6C, V_PP])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6S, V_X6P, V_X6C, V_PP, V_PP16])
 @pytest.mark.parametrize("C,W,H", SHAPES)
 def test_sweep2_shapes(orc, variant, C, W, H):
     """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
@@ -78,7 +81,7 @@ def test_sweep2_shapes(orc, variant, C, W, H):
     check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16])
 def test_sweep2_background_and_short_lists(orc, variant):
     """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
     _gate(variant)
@@ -90,7 +93,7 @@ def test_sweep2_background_and_short_lists(orc, variant):
     assert (r[:, 0] == r[:, 1]).any()   # empty tiles exist
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16])
 def test_sweep2_long_lists(orc, variant):
     """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
     deferred stores ride along tiles of very different lengths."""
@@ -103,7 +106,7 @@ def test_sweep2_long_lists(orc, variant):
     check(orc, scene, cam, variant, seg=6)   # one 49-tile segment: ~2900 batches
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16])
 def test_sweep2_padded_pitch(orc, variant):
     """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
     _gate(variant)
@@ -116,7 +119,7 @@ def test_sweep2_padded_pitch(orc, variant):
         raster.OUTPUT_PITCH_ALIGN = 0
 
 
-@pytest.mark.parametrize("V", [V_X6P, V_PP])
+@pytest.mark.parametrize("V", [V_X6P, V_PP, V_PP16])
 def test_sweep2_deterministic_under_load(orc, V):
     """The same frame 300 times with two other views in flight on other streams: every feature map bit-identical
     (a stale ring stage -- a bundle consumed before it landed -- would show up as a differing map)."""
@@ -136,7 +139,7 @@ def test_sweep2_deterministic_under_load(orc, V):
     assert bad == 0
 
 
-@pytest.mark.parametrize("variant", [0, V_EXACT, V_X6P, V_PP, 14])
+@pytest.mark.parametrize("variant", [0, V_EXACT, V_X6P, V_PP, V_PP16, 14])
 def test_feature_scale_invariance_is_bit_exact(variant):
     """A size-independent property of every accumulate arithmetic: scaling the features and the background by a power of two
     scales the feature map by exactly that power of two (roundings commute with 2^k away from over / underflow) -- for the
@@ -188,8 +191,8 @@ def test_ping_pong_sweep_equals_round3_sweep_bitwise():
             # nibble 4 (experiment): no barriers, the halves run free on per-stage arrival / consumption counters
             f = _hip_forward(scene, cam, variant=0x4 | (segn << 4))[1]
             assert torch.equal(f, b), ("free-running halves", P, C, W, H, segn)
-        d = _hip_forward(scene, cam, variant=0)[1]      # the default: the same kernel with its own segment length
-        assert torch.equal(d, _hip_forward(scene, cam, variant=0x6E)[1]), (P, C, W, H)
+        # the default is the same sweep on the x16 MFMA: a map of its own (16 k per accumulate instead of 8), the same for every segment length
+        assert torch.equal(_hip_forward(scene, cam, variant=0)[1], _hip_forward(scene, cam, variant=V_PP16)[1]), (P, C, W, H)
 
 
 def test_superbatch_weights_prepass_equals_batch16_bitwise():
@@ -224,11 +227,12 @@ def test_superbatch_weights_prepass_equals_batch16_bitwise():
 
 
 def test_x16_experiments_are_not_in_the_product_library():
-    """DESIGN.md 5.10 / profiles/r04_x16_gemm_aggressor.txt: the double-rate-MFMA sweeps damage forwards running beside them
-    on some boxes (a library GEMM beside the same victim does not): they are built only by `make X16=1`; the default library
-    answers their variants with an error instead of running them."""
+    """dense v_mfma_f32_32x32x16_bf16 issue damages packed-fp32 results of FOREIGN waves resident on the same compute
+    unit (round 5: 0 events with victim and aggressor on disjoint CU masks, hundreds with shared CUs).  The x16 sweeps whose
+    workgroups leave room for foreign waves on their CU (round 2's, round 3's) and the filler experiments are built only by
+    `make X16=1`; the default library answers their variants with an error.  (The ping-pong sweep owns its CU: its x16 form ships.)"""
     scene, cam = small_scene(P=500, C=128, W=64, H=48, fx=100.0, seed=2)
-    for v in (0x6C, 0x6F, 0x16F, 0x808, 0x1F, 0x10036, 0x30066):   # (the last two: x16 forms of the ping-pong sweep)
+    for v in (0x6C, 0x6F, 0x16F, 0x808, 0x1F, 0x20036, 0x30066):   # (the last two: the filler forms of the x16 ping-pong sweep; its dense form is the default)
         with pytest.raises(RuntimeError, match="X16"):
             _hip_forward(scene, cam, variant=v)
     _hip_forward(scene, cam, variant=0)   # (and the stream is usable afterwards)
