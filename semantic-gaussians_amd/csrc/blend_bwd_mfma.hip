@@ -353,6 +353,15 @@ __device__ __forceinline__ Op2 lds_op2(const uint32_t* p)
 	return r;
 }
 #define SGS_MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(A_, B_, C_, 0, 0, 0)
+// the double-rate form (fused kernel only): an Op2 -- the lane's 8 consecutive k positions -- IS one operand of
+// v_mfma_f32_32x32x16_bf16 (lane half h supplies k = 8 h .. 8 h + 7 of the instruction's 16)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 op16(const Op2& o)
+{
+	return __builtin_bit_cast(bf16x8, uint4{__builtin_bit_cast(uint2, o.k0).x, __builtin_bit_cast(uint2, o.k0).y,
+						 __builtin_bit_cast(uint2, o.k1).x, __builtin_bit_cast(uint2, o.k1).y});
+}
+#define SGS_MFMA_X16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(op16(A_), op16(B_), C_, 0, 0, 0)
 
 #ifdef SGS_WITH_EXPERIMENTS
 // ---- 3'. D = F G.  The gradient slab has to be transposed on its way into LDS (k = channel is the slow
@@ -638,6 +647,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const uint32_t* __restrict__ counter, uint32_t capacity, int W, int H, int C, int gx, int per_xcd, int ntiles,
 	unsigned long long* __restrict__ trace)
 {
+	// (split form: double-rate MFMAs) 256 registers per wave, pinned: with two waves per SIMD the workgroup owns its compute unit's register
+	// files outright -- no foreign wave can be resident beside its matrix instructions; all eight waves are resident from
+	// dispatch, and the last products of a tile lie before a barrier that every wave passes before it can leave
+	if constexpr (!FP32) asm volatile("" : : : "v255");
 	const int b = blockIdx.x;
 	// (XCD bands, not the forward's longest-first order: measured, that order is 1.5 % slower here too -- neighbouring tiles share
 	// feature rows in an XCD's L2 -- profiles/r05_backward_fused.txt)
@@ -851,12 +864,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 								nah = lds_op2(fn);
 								nal = lds_op2(fn + 16);
 							}
-							acc[m] = SGS_MFMA_BF16(al.k0, bh.k0, acc[m]);
-							acc[m] = SGS_MFMA_BF16(ah.k0, bl.k0, acc[m]);
-							acc[m] = SGS_MFMA_BF16(ah.k0, bh.k0, acc[m]);
-							acc[m] = SGS_MFMA_BF16(al.k1, bh.k1, acc[m]);
-							acc[m] = SGS_MFMA_BF16(ah.k1, bl.k1, acc[m]);
-							acc[m] = SGS_MFMA_BF16(ah.k1, bh.k1, acc[m]);
+							acc[m] = SGS_MFMA_X16(al, bh, acc[m]);
+							acc[m] = SGS_MFMA_X16(ah, bl, acc[m]);
+							acc[m] = SGS_MFMA_X16(ah, bh, acc[m]);
 						}
 				}
 			}
@@ -900,12 +910,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 					ah.k1 = __builtin_bit_cast(s16x4, uint2{wh[j][4 * sp + 2], wh[j][4 * sp + 3]});
 					al.k0 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp], wl[j][4 * sp + 1]});
 					al.k1 = __builtin_bit_cast(s16x4, uint2{wl[j][4 * sp + 2], wl[j][4 * sp + 3]});
-					a2 = SGS_MFMA_BF16(al.k0, bh.k0, a2);
-					a2 = SGS_MFMA_BF16(ah.k0, bl.k0, a2);
-					a2 = SGS_MFMA_BF16(ah.k0, bh.k0, a2);
-					a2 = SGS_MFMA_BF16(al.k1, bh.k1, a2);
-					a2 = SGS_MFMA_BF16(ah.k1, bl.k1, a2);
-					a2 = SGS_MFMA_BF16(ah.k1, bh.k1, a2);
+					a2 = SGS_MFMA_X16(al, bh, a2);
+					a2 = SGS_MFMA_X16(ah, bl, a2);
+					a2 = SGS_MFMA_X16(ah, bh, a2);
 				}
 			}
 			float* xo = &sX[buf][mblk][kh ^ 1][lane];
@@ -1019,6 +1026,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef SGS_PH
 }
 #undef SGS_MFMA_BF16
+#undef SGS_MFMA_X16
 
 struct StagedEntryG {
 	float a2, b2, c2, o;

@@ -6,7 +6,7 @@ was ever seen in) runs beside view k's x16 sweep, and every view's num_rendered 
   disjoint  the streams are created with hipExtStreamCreateWithCUMask, stream k with bits [k n / NF, (k + 1) n / NF) of the CU mask: a view's kernels only ever
             run on its stream's share of the chip's CUs, views in flight together on different shares -- victim and aggressor never share a CU.
 Events under `shared` and none under `disjoint` = a same-CU resource; events under both = something chip-wide (power, clocks, fabric).
-Needs a library built with `make X16=1 EXPERIMENTS=1`.   usage: x16_cu_mask.py [rounds=3000] [variant=0x6F] [in_flight=4] [x8 control=1]"""
+Needs a library built with `make X16=1 EXPERIMENTS=1`.   usage: x16_cu_mask.py [rounds=3000] [variant=0x6F] [in_flight=4] [x8 control=1] [backward too=0]"""
 import ctypes as C
 import os
 import sys
@@ -23,6 +23,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 VAR = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0x6F
 NF = int(sys.argv[3]) if len(sys.argv) > 3 else 4          # views in flight = streams (the events of rounds 2-4 were seen with four)
 CONTROL = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
+BWD = (sys.argv[5] != "0") if len(sys.argv) > 5 else False   # every view also runs its backward (the fused kernel issues x16 products too) on its stream
 scene, _ = small_scene(P=5000, C=128, W=208, H=128, fx=170.0, seed=5)
 s = scene.to(DEV)
 cams = [pinhole(208, 128, fx).to(DEV) for fx in (150.0, 160.0, 170.0, 180.0, 190.0, 200.0)]
@@ -43,10 +44,16 @@ def masked_stream(lo, hi):
     return torch.cuda.ExternalStream(st.value, device=DEV)
 
 
+dL = torch.randn(128, 128, 208, device=DEV)
+
+
 def render(c, slot):
     out = raster.rasterize_forward(s.bg, s.means3D, s.features, s.opacities, s.scales, s.rotations, 1.0, e, c.world_view_transform,
                                    c.full_proj_transform, c.tanfovx, c.tanfovy, 128, 208, e, 0, c.camera_center, False, False, 128, False,
-                                   pool=pools[slot])
+                                   pool=None if BWD else pools[slot])
+    if BWD:
+        raster.rasterize_backward(s.bg, s.means3D, out[2], s.features, s.scales, s.rotations, 1.0, e, c.world_view_transform,
+                                  c.full_proj_transform, c.tanfovx, c.tanfovy, dL, e, 0, c.camera_center, out[3], out[0], out[4], out[5], False)
     return out[0], out[2].clone()
 
 
