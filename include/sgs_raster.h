@@ -300,14 +300,16 @@ int sgs_stream_release(void *stream);
 /* Selects the forward blend kernels.  The product library (sgs_build_flags() == 0) knows:
  *   0  (default) num_channels >= 128: weights pre-pass + ping-pong row sweep for the 128-channel-aligned part in "f32-equivalent"
  *      arithmetic -- features and weights split EXACTLY into three bf16 terms each, the six products with i + j <= 4 on
- *      v_mfma_f32_32x32x8_bf16, fp32 accumulate: against the exact (float64) composite as accurate as the reference's fp32
+ *      v_mfma_f32_32x32x16_bf16 (the sweep's workgroups own their compute units; bits [19:16] = 0 in the word form: on
+ *      v_mfma_f32_32x32x8_bf16), fp32 accumulate: against the exact (float64) composite as accurate as the reference's fp32
  *      multiply-add chain (CR/cuda_rasterizer/forward.cu:355-356), every integer output bit-exact; the px1 kernel for the
  *      remainder channels, below 128 channels and for RGB-D;
  *   15 as 0 with the fp32-input MFMA sweep: the feature map is BIT-IDENTICAL to the contract's fp32 fma chain (SGS_BLEND_EXACT=1);
  *   14 round 2's arithmetic: two bf16 terms per operand, three products (<= 3 * 2^-16 of sum |f| w): the fastest, NOT fp32-class;
  *   6  the single-kernel px4 form for the 128-aligned part (the gated fallback of 0 when its work list overflows);
  *   >= 16, the word form:  bits [3:0] sweep (6 = 0's, 11 = 15's, 0 / 8 = 14's) | [7:4] segment length / 8 tiles (0 = adaptive)
- *      | [13:12] workgroup order (0 / 3 = segments sorted by work and dealt to the XCDs, 1 = row-major, 2 = dealt unsorted).
+ *      | [13:12] workgroup order (0 / 3 = segments sorted by work and dealt to the XCDs, 1 = row-major, 2 = dealt unsorted)
+ *      | [19:16] with sweep 6: 1 = on the x16 MFMA (what 0 selects), 0 = on the x8 MFMA (round 4's default, bit-identical to round 3's).
  * Everything else -- sweep nibbles 4 / 5 / 7 / 9 / 10 / 13 / 14, ablation bits [11:8], pre-pass switches [15:14], single-kernel
  * forms 1-5 -- is a development form (`make EXPERIMENTS=1`; DESIGN.md 5.x has the measurements), 12 / 15 / [19:16] the
  * double-rate-MFMA reproducers (`make X16=1`), 32-35 round 2's fused kernels (`make FUSED=1`): SGS_EINVAL here.
@@ -332,7 +334,7 @@ int sgs_set_binning_mode(int mode);
  * products over the forward's work list, both in ONE kernel that reads dL/dpixel once (round 5, blend_bwd_mfma.hip
  * bwd_fused_kernel; scratch comes from a stream-ordered pool on `stream`), the per-chunk kernel otherwise.
  * Arithmetic of the two products in mode 0: every operand (features, weights, gradient) is split into TWO bf16 terms,
- * x = hi + lo + O(2^-16 x), the three products lo*hi + hi*lo + hi*hi run on v_mfma_f32_32x32x8_bf16 with fp32 accumulation:
+ * x = hi + lo + O(2^-16 x), the three products lo*hi + hi*lo + hi*hi run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
  * <= 3 * 2^-16 of sum |a||b| per product -- NARROWER than the forward's default (three exact terms, six products).
  * 3 = the same kernel with exact fp32 products (v_mfma_f32_32x32x2_f32), ~1.3 ms slower at 1M x 512 x 968x1296;
  * 1 = always the per-chunk VALU kernel (blend_bwd.hip); 2 = as 0 with a deliberately undersized work-list arena
