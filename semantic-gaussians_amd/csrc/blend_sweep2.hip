@@ -1565,11 +1565,13 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			} else {   /* (make X16=1) the double-rate forms */                                     \
 				u32x4 aw_[3];                                                                        \
 				for (int t_ = 0; t_ < 3; t_++) aw_[t_] = u32x4{A_.t[t_][0].x, A_.t[t_][0].y, A_.t[t_][1].x, A_.t[t_][1].y}; \
+				if constexpr (FREE) flag_peek(flag_a + 16u + ((j + 3u) & 3u) * 4u, fc_v_);            \
 				if constexpr (MM == 1) mfma_dense_wide<b0_, b1_>(aw_, x_, y_);                        \
 				else mfma_dense_wide_sp<MM - 1, b0_, b1_>(aw_, x_, y_);                               \
+				if constexpr (FREE) flag_check(flag_a + 16u + ((j + 3u) & 3u) * 4u, fc_v_, 8u * ((j + 3u) >> 2)); \
 				S3_HALF2W(b2_, b3_, 0); S3_HALF2W(b2_, b3_, 1); S3_HALF2W(b2_, b3_, 2);              \
 				S3_HALF2W(b2_, b3_, 3); S3_HALF2W(b2_, b3_, 4);                                      \
-				if (!g) poll_issue(stn_, pw_, pid_);                                                 \
+				if (!g || FREE) poll_issue(stn_, pw_, pid_);                                         \
 				S3_HALF2W(b2_, b3_, 5);                                                              \
 			}                                                                                        \
 		} else if (!g || FREE) poll_issue(stn_, pw_, pid_);                                          \
@@ -1694,6 +1696,13 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 		return hipGetLastError();
 	}
 #endif
+	// the free-running halves (flags instead of barriers, nibble 4) on the x16 MFMA: round 5's default
+	if (tune == 1 && form == 2 && dbg == 0) {
+		hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, 1, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table,
+				   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg,
+				   pxcd, items, a.pitch, trace, order, dealt, tune);
+		return hipGetLastError();
+	}
 #undef S3_LAUNCH_MM
 	if (tune != 0) return hipErrorInvalidValue;
 #ifndef SGS_WITH_EXPERIMENTS   // the product library holds ONE ping-pong sweep; the forms below are make EXPERIMENTS=1

@@ -739,19 +739,20 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// (the x16 forms whose workgroups leave room for foreign waves on their compute unit -- round 2's and round 3's sweeps -- and the
 	// filler forms of the ping-pong sweep; the DENSE x16 ping-pong sweep, 0x1 << 16 | ..6, ships: it is the default)
 	if (variant >= 16 && ((variant & 15) == 12 || (variant & 15) == 15 || ((variant & 15) == 8 && ((variant >> 8) & 15) == 8) ||
-			      ((variant & 15) == 6 && ((variant >> 16) & 15) > 1)))
+			      (((variant & 15) == 6 || (variant & 15) == 4) && ((variant >> 16) & 15) > 1)))
 		return fail(SGS_EINVAL, "blend variants on v_mfma_f32_32x32x16_bf16 other than the ping-pong sweep (sweep nibble 12 / 15, 0x8.8, 0x2..3 << 16 | ..6) are not in this build (make X16=1)");
 #endif
 #ifndef SGS_WITH_EXPERIMENTS   // (make EXPERIMENTS=1: the development forms, csrc/Makefile)
 	{
 		// what ships: 0 (default) / 6 (single-kernel px4 form, also the gated fallback) / 14 (round 2's two-term sweep) / 15 (exact fp32), and the
 		// word form  sweep nibble {0, 8: two-term | 6: ping-pong | 11: exact} | segment length [7:4] | workgroup order [13:12] |
-		// [19:16] 1 = the ping-pong sweep on the x16 MFMA (the default), 0 = on x8  -- nothing else
+		// [19:16] 1 = the ping-pong sweep on the x16 MFMA (nibble 4: free running, the default; 6: lock step), 0 = on x8  -- nothing else
 		const int nib = variant & 15;
 		const bool plain = variant == 0 || variant == 6 || variant == 14 || variant == 15;
 		const int tune = (variant >> 16) & 15;
-		const bool word = variant >= 16 && (variant & ~0xF30FF) == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11) &&
-				  (tune == 0 || (tune == 1 && nib == 6));   // bits [19:16] = 1: the x16 ping-pong sweep (what 0 selects)
+		const bool word = variant >= 16 && (variant & ~0xF30FF) == 0 &&
+				  ((tune == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11)) ||
+				   (tune == 1 && (nib == 6 || nib == 4)));   // bits [19:16] = 1: the ping-pong sweep on x16, lock step (6) / free running (4: what 0 selects)
 		if (!plain && !word && !want_fused)
 			return fail(SGS_EINVAL, "this blend variant is a development form that is not in this build (make EXPERIMENTS=1)");
 	}
@@ -895,10 +896,15 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		// in 180 000 forwards once victim and aggressor are confined to disjoint CU masks, 557 with shared CUs) -- and the ping-pong
 		// workgroup owns its CU outright: 8 waves x 256 registers, 139 KB of LDS, every wave resident from before the first to after the
 		// last matrix instruction.  SGS_DEFAULT_SWEEP=6 (environment, read once) restores the x8 form, =14 round 3's kernel (EXPERIMENTS).
-		static const int default_sweep = !getenv("SGS_DEFAULT_SWEEP") ? 0x10006 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 14 ? 14 : 6);
+		// The default of the default: its FREE-RUNNING form (word 0x10004: the two halves of the workgroup hand the ring stages over through LDS
+		// counters instead of two barriers per step) -- on x8 that form lost (the lock step kept the halves' matrix phases apart);
+		// with the products at half the time it wins: sweep 1.05 -> 1.01 ms alone, equal with four views in flight, bit-identical maps.
+		// SGS_DEFAULT_SWEEP = 16: the lock-step x16 form (0x10006), 6: lock step on x8 (round 4's default), 14: round 3's kernel (EXPERIMENTS).
+		static const int default_sweep = !getenv("SGS_DEFAULT_SWEEP") ? 0x10004
+						 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 14 ? 14 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 16 ? 0x10006 : 6));
 		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : default_sweep));
 		if (norm_plane) {
-			if ((split_word & 15) != 14 && (split_word & 15) != 11 && (split_word & 15) != 6)
+			if ((split_word & 15) != 14 && (split_word & 15) != 11 && (split_word & 15) != 6 && (split_word & 15) != 4)
 				return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs the default blend (variants 0 / 15)");
 			e = hipMemsetAsync(out_color, 0, (size_t)height * a.pitch * sizeof(float), st);
 			if (e != hipSuccess) return fail_hip(e, "memset (norm plane)");

@@ -21,9 +21,10 @@ DEV = "cuda:0"
 
 V_X6, V_EXACT, V_X6W, V_X6S, V_X6P, V_X6PW = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E, 0x6F
 V_PP = 0x66       # round 4: ping-pong sweep on the x8 MFMA (0x6_ pins 48-tile segments like the others)
-V_PP16 = 0x10066  # round 5, THE DEFAULT kernel: the ping-pong sweep on the double-rate v_mfma_f32_32x32x16_bf16 (same products, 16 k per instruction)
+V_PP16 = 0x10066  # round 5: the ping-pong sweep on the double-rate v_mfma_f32_32x32x16_bf16 (same products, 16 k per instruction), lock step
+V_FR16 = 0x10064  # round 5, THE DEFAULT kernel: the same with the halves free-running on per-stage LDS counters instead of two barriers per step (bit-identical to V_PP16)
 V_X6C = 0x67      # six products, fp32 weights handed over, split once per workgroup into LDS: bit-identical to V_X6P
-SHIPS = (0, 14, 15, V_EXACT, V_PP, V_PP16)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
+SHIPS = (0, 14, 15, V_EXACT, V_PP, V_PP16, V_FR16)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
 
 
 def _gate(variant):
@@ -38,7 +39,7 @@ X6_TOL = 4e-6
 
 
 def check(orc, scene, cam, variant, seg=None, **kw):
-    v = variant if seg is None else (variant & 15) | (seg << 4)
+    v = variant if seg is None else (variant & ~0xF0) | (seg << 4)   # (the segment nibble only: the word's other fields stay)
     fw = oracle_forward(orc, scene, cam, **kw)
     n, color, radii, geom, binn, img, depth = _hip_forward(scene, cam, variant=v, **kw)
     from sgs_hip import raster
@@ -70,7 +71,7 @@ def check(orc, scene, cam, variant, seg=None, **kw):
 SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64), (128, 336, 48)]
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6S, V_X6P, V_X6C, V_PP, V_PP16])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6S, V_X6P, V_X6C, V_PP, V_PP16, V_FR16])
 @pytest.mark.parametrize("C,W,H", SHAPES)
 def test_sweep2_shapes(orc, variant, C, W, H):
     """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
@@ -81,7 +82,7 @@ def test_sweep2_shapes(orc, variant, C, W, H):
     check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16])
 def test_sweep2_background_and_short_lists(orc, variant):
     """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
     _gate(variant)
@@ -93,7 +94,7 @@ def test_sweep2_background_and_short_lists(orc, variant):
     assert (r[:, 0] == r[:, 1]).any()   # empty tiles exist
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16])
 def test_sweep2_long_lists(orc, variant):
     """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
     deferred stores ride along tiles of very different lengths."""
@@ -106,7 +107,7 @@ def test_sweep2_long_lists(orc, variant):
     check(orc, scene, cam, variant, seg=6)   # one 49-tile segment: ~2900 batches
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16])
 def test_sweep2_padded_pitch(orc, variant):
     """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
     _gate(variant)
@@ -119,7 +120,7 @@ def test_sweep2_padded_pitch(orc, variant):
         raster.OUTPUT_PITCH_ALIGN = 0
 
 
-@pytest.mark.parametrize("V", [V_X6P, V_PP, V_PP16])
+@pytest.mark.parametrize("V", [V_X6P, V_PP, V_PP16, V_FR16])
 def test_sweep2_deterministic_under_load(orc, V):
     """The same frame 300 times with two other views in flight on other streams: every feature map bit-identical
     (a stale ring stage -- a bundle consumed before it landed -- would show up as a differing map)."""
@@ -139,7 +140,7 @@ def test_sweep2_deterministic_under_load(orc, V):
     assert bad == 0
 
 
-@pytest.mark.parametrize("variant", [0, V_EXACT, V_X6P, V_PP, V_PP16, 14])
+@pytest.mark.parametrize("variant", [0, V_EXACT, V_X6P, V_PP, V_PP16, V_FR16, 14])
 def test_feature_scale_invariance_is_bit_exact(variant):
     """A size-independent property of every accumulate arithmetic: scaling the features and the background by a power of two
     scales the feature map by exactly that power of two (roundings commute with 2^k away from over / underflow) -- for the
@@ -154,6 +155,24 @@ def test_feature_scale_invariance_is_bit_exact(variant):
         s2 = scene._replace(features=scene.features * 2.0 ** k, bg=scene.bg * 2.0 ** k)
         out = _hip_forward(s2, cam, variant=variant)[1]
         assert torch.equal(out, base * 2.0 ** k), k
+
+
+def test_x16_sweep_forms_agree_bitwise():
+    """The default (free-running halves on the x16 MFMA, its own segment length), the same with pinned segment lengths and the lock-step x16
+    form issue the same products in the same order into the same accumulators: bit-identical maps -- staggered and plain pitches, several
+    channel chunks, a non-zero background, short segments (8 tiles: many unpaired halves) and long lists (the table window slides)."""
+    cases = [(4000, 256, 208, 96, 170.0, 1, 1.0), (30000, 128, 400, 64, 170.0, 2, 1.0), (500, 512, 48, 40, 170.0, 3, 1.0),
+             (3000, 128, 336, 48, 170.0, 4, 1.0), (40000, 128, 784, 32, 600.0, 77, 3.0)]
+    for (P, C, W, H, fx, seed, sc) in cases:
+        scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=fx, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        scene = scene._replace(bg=torch.randn(C, generator=g), scales=scene.scales * sc, opacities=scene.opacities * (0.05 if sc > 1 else 1.0))
+        for _ in range(2):   # (let the stream's work-list arena grow to this scene)
+            _hip_forward(scene, cam, variant=0)
+        d = _hip_forward(scene, cam, variant=0)[1]
+        for segn in (6, 1, 3):
+            assert torch.equal(d, _hip_forward(scene, cam, variant=0x10006 | (segn << 4))[1]), ("lock step", P, C, W, H, segn)
+            assert torch.equal(d, _hip_forward(scene, cam, variant=0x10004 | (segn << 4))[1]), ("free running", P, C, W, H, segn)
 
 
 def test_cooperative_split_equals_presplit_bitwise():
@@ -193,6 +212,7 @@ def test_ping_pong_sweep_equals_round3_sweep_bitwise():
             assert torch.equal(f, b), ("free-running halves", P, C, W, H, segn)
         # the default is the same sweep on the x16 MFMA: a map of its own (16 k per accumulate instead of 8), the same for every segment length
         assert torch.equal(_hip_forward(scene, cam, variant=0)[1], _hip_forward(scene, cam, variant=V_PP16)[1]), (P, C, W, H)
+        assert torch.equal(_hip_forward(scene, cam, variant=0)[1], _hip_forward(scene, cam, variant=V_FR16)[1]), (P, C, W, H)
 
 
 def test_superbatch_weights_prepass_equals_batch16_bitwise():
