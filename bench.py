@@ -296,7 +296,8 @@ def extra_config_legs(rank, world, dev, dist, red_dev=None):
 
         def partial():
             A, T, _ = raster.render_partial(sh[0], feats, sh[1], sh[2], sh[3], cam.world_view_transform, cam.full_proj_transform,
-                                            cam.tanfovx, cam.tanfovy, H, W, cam.camera_center, pool=pool)
+                                            cam.tanfovx, cam.tanfovy, H, W, cam.camera_center, pool=pool,
+                                            bands=world if C % 128 == 0 else 0)   # band-major: every band is sent as it lies
             return A, T
         log(f"[rank {rank}] config 5: slab of {n_loc} Gaussians resident, first frame")
         band = sdist.render_gaussian_sharded(partial, bg, all_gather=False)

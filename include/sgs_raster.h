@@ -268,7 +268,14 @@ int sgs_debug_expf(int n, const float *in, float *out, void *stream);
  * Needs num_channels % 128 == 0, no depth plane and the default blend (variants 0 / 15); SGS_EINVAL otherwise.
  * A frame whose work list overflows is rendered by the same gated fallback as always; its epilogue adds the squares. */
 #define SGS_OPT_NORM_PLANE 7
-#define SGS_OPT_COUNT 8
+/* n > 1: the NEXT forward on this stream (ONE call, like SGS_OPT_OUT_PITCH) writes its feature map BAND-major for an image-partitioned
+ * exchange between n ranks (Gaussian-sharded rendering, sgs_hip.dist.render_gaussian_sharded): band b = image rows [lo_b, hi_b),
+ * lo_b = min(H, 16 * (ceil(H / 16) * b / n)), stored as a contiguous (num_channels, hi_b - lo_b, pitch) block, the blocks one behind the
+ * other in out_color (band b starts num_channels * pitch * lo_b floats in; the buffer's size is unchanged).  Every band is then one
+ * contiguous message -- no staging copy per peer.  Needs num_channels % 128 == 0, no depth plane, no SGS_OPT_NORM_PLANE and the default /
+ * ping-pong sweep (variants 0, 6, word nibbles 4 / 6); SGS_EINVAL otherwise. */
+#define SGS_OPT_OUT_BANDS 8
+#define SGS_OPT_COUNT 9
 /* value < 0 removes the override (the stream follows the process default again).  Returns the previous override,
  * or 0x7fffffff if there was none. */
 int sgs_stream_set_option(void *stream, int option, int value);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 	const float4* __restrict__ conic_opacity, const float* __restrict__ bg,
 	float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out, int W,
 	int H, int C, int gx, int nchunks, int per_xcd, int total, const uint32_t* __restrict__ gate, int pitch,
-	const uint32_t* __restrict__ abort, int norm)
+	const uint32_t* __restrict__ abort, int norm, int bands)
 {
 	if (gate && gate[1] != 1u) return;   // fallback instance: runs only if the split path's work list overflowed (1; 2 = aborted frame)
 	if (abort && *abort != 0u) return;
@@ -283,13 +283,24 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 		n_contrib[pix] = last;
 	}
 	__syncthreads();
+	// SGS_OPT_OUT_BANDS: the tile row's band is a (C, rows, pitch) image of its own
+	float* outb = out;
+	size_t HWb = HW;
+	int row0 = 0;
+	if (bands > 1) {
+		int lo_tile, rows;
+		sgs_band_of(ty, (H + SGS_TILE - 1) / SGS_TILE, bands, H, lo_tile, rows);
+		row0 = SGS_TILE * lo_tile;
+		outb = out + (size_t)C * (size_t)pitch * (size_t)row0;
+		HWb = (size_t)rows * pitch;
+	}
 #pragma unroll
 	for (int p = 0; p < 4; p++) {
 		const int qx = tx * SGS_TILE + (lane & 15);
 		const int qy = ty * SGS_TILE + p * 4 + (lane >> 4);
 		if (qx < W && qy < H) {
 			const float Tp = s_T[p * 64 + lane];
-			const size_t pix = (size_t)qy * pitch + qx;
+			const size_t pix = (size_t)(qy - row0) * pitch + qx;
 			if (norm) {   // SGS_OPT_NORM_PLANE: `out` is one (H, pitch) plane that receives sum_c out[c]^2 (blend_sweep2.hip)
 				float ss = 0.f;
 #pragma unroll
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(256) void blend_fwd_px4_kernel(
 			}
 #pragma unroll
 			for (int c = 0; c < CW; c++)
-				out[(size_t)(c0 + c) * HW + pix] = __builtin_fmaf(Tp, bg[c0 + c], acc[p][c >> 1][c & 1]);
+				outb[(size_t)(c0 + c) * HWb + pix] = __builtin_fmaf(Tp, bg[c0 + c], acc[p][c >> 1][c & 1]);
 		}
 	}
 	};
@@ -338,7 +349,7 @@ static void launch_px4(hipStream_t st, const BlendFwdArgs& a, int nchunks, const
 	const int grid = gate && per_xcd * 8 > SGS_GATED_GRID ? SGS_GATED_GRID : per_xcd * 8;   // (gated fallback: see the kernel)
 	hipLaunchKernelGGL((blend_fwd_px4_kernel<CW, BATCH>), dim3(grid), dim3(256), 0, st,
 			   a.ranges, a.point_list, a.means2D, a.features, a.conic_opacity, a.bg,
-			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate, a.pitch, a.abort, a.norm_plane ? 1 : 0);
+			   a.final_T, a.n_contrib, a.out, a.W, a.H, a.C, a.gx, nchunks, per_xcd, total, gate, a.pitch, a.abort, a.norm_plane ? 1 : 0, a.bands);
 }
 
 // variant: 0 = default (px4 CW=32 for the 128-channel-aligned part, px1 for the rest)

@@ -1147,9 +1147,9 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const char* __restrict__ wgt, const float* __restrict__ features,
-	const float* __restrict__ bg, float* __restrict__ out, const uint32_t* __restrict__ counter,
-	int W, int H, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int PW,
-	unsigned long long* __restrict__ trace, const uint32_t* __restrict__ order, int dealt, int tune)
+	const float* __restrict__ bg, float* __restrict__ out_img, const uint32_t* __restrict__ counter,
+	int W, int H_img, int C, int gx, int nchunks_c, int seg, int nseg, int per_xcd, int total_items, int PW,
+	unsigned long long* __restrict__ trace, const uint32_t* __restrict__ order, int dealt, int tune, int bands)
 {
 	// (x16 forms) 144 AGPRs + 112 VGPRs = 256 registers per wave: two waves per SIMD fill its register file, so that NO foreign wave --
 	// not even an 8-register fill kernel -- can be resident on this workgroup's compute unit between its first and its last matrix
@@ -1176,6 +1176,17 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const unsigned long long t_begin = trace ? wall_clock64() : 0ull;
 	const int stagger = (PW & 31) == 16 ? 1 : 0;   // odd rows start 64 B into a line
 	const int sg = rest % nseg, ty = rest / nseg;
+	// SGS_OPT_OUT_BANDS: this tile row's band is a (C, rows, PW) image of its own -- from here on `out` / `H` / `ty_out` are the band's base,
+	// height and the tile row inside it; the lists are still the frame's (ty)
+	float* __restrict__ out = out_img;
+	int H = H_img, ty_out = ty;
+	if (bands > 1) {
+		int lo_tile, rows;
+		sgs_band_of(ty, (H_img + SGS_TILE - 1) / SGS_TILE, bands, H_img, lo_tile, rows);
+		out = out_img + (size_t)C * (size_t)PW * (size_t)(SGS_TILE * lo_tile);
+		H = rows;
+		ty_out = ty - lo_tile;
+	}
 	const int tx0 = sg * seg;   // even
 	const int nt = (gx - tx0) < seg ? (gx - tx0) : seg;
 	const int lane = threadIdx.x & 63;
@@ -1606,7 +1617,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	} while (0)
 
 	constexpr bool NORM = false;
-	const int y0 = ty * SGS_TILE + g;   // first image row of this parity in the tile row
+	const int y0 = ty_out * SGS_TILE + g;   // first image row of this parity in the tile row (inside its band, SGS_OPT_OUT_BANDS)
 	const int hi = (l31 >> 4) & 1;
 
 	// ---- the sweep.  Even rows: even tiles are left halves; odd rows of a staggered pitch: odd tiles.  (The two halves of
@@ -1678,13 +1689,13 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 #define S3_LAUNCH(D_)                                                                                \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
-			   pxcd, items, a.pitch, trace, order, dealt, tune)
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
 	// bits [19:16] of the variant: 1 = the sweep on the double-rate v_mfma_f32_32x32x16_bf16, dense (round 5: THE DEFAULT -- the workgroup
 	// owns its compute unit); (make X16=1) 2 = x16 + s_nop filler, 3 = x16 + VALU filler
 #define S3_LAUNCH_MM(M_)                                                                             \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, M_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
-			   pxcd, items, a.pitch, trace, order, dealt, tune)
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
 	if (tune == 1 && dbg == 0 && form == 0) {
 		S3_LAUNCH_MM(1);
 		return hipGetLastError();
@@ -1700,7 +1711,7 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	if (tune == 1 && form == 2 && dbg == 0) {
 		hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, 1, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table,
 				   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg,
-				   pxcd, items, a.pitch, trace, order, dealt, tune);
+				   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands);
 		return hipGetLastError();
 	}
 #undef S3_LAUNCH_MM
@@ -1715,7 +1726,7 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 #define S3_LAUNCH_C(D_)                                                                              \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 0, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
-			   pxcd, items, a.pitch, trace, order, dealt, tune)
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
 		if (dbg == 1) S3_LAUNCH_C(1);
 		else if (dbg == 2) S3_LAUNCH_C(2);
 		else if (dbg == 4) S3_LAUNCH_C(4);
@@ -1727,7 +1738,7 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 #define S3_LAUNCH_F(D_)                                                                              \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 0, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
-			   pxcd, items, a.pitch, trace, order, dealt, tune)
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
 		if (dbg == 1) S3_LAUNCH_F(1);
 		else if (dbg == 2) S3_LAUNCH_F(2);
 		else if (dbg == 4) S3_LAUNCH_F(4);

@@ -567,6 +567,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	cx->opt[SGS_OPT_OUT_PITCH] = -1;
 	const bool norm_plane = cx->option(SGS_OPT_NORM_PLANE) > 0;   // out_color is ONE (H, pitch) plane that receives sum_c out[c]^2
 	cx->opt[SGS_OPT_NORM_PLANE] = -1;
+	const int out_bands = cx->opt[SGS_OPT_OUT_BANDS];   // (one shot, stream only: there is no process default for it)
+	cx->opt[SGS_OPT_OUT_BANDS] = -1;
 	if (P < 0 || width <= 0 || height <= 0 || num_channels <= 0)
 		return fail(SGS_EINVAL, "bad sizes");
 	if (!geometry_buffer || !binning_buffer || !image_buffer || !out_color)
@@ -868,6 +870,13 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	a.usage_host = nullptr;
 	a.counter_reset_done = counter_reset_done;
 	a.norm_plane = norm_plane;
+	a.bands = out_bands > 1 ? out_bands : 0;
+	if (a.bands) {
+		const int nibv = variant >= 16 ? (variant & 15) : -1;
+		if ((num_channels & 127) || out_depth || norm_plane || a.bands > 4096 ||
+		    !(variant == 0 || variant == 6 || nibv == 4 || nibv == 6))
+			return fail(SGS_EINVAL, "SGS_OPT_OUT_BANDS needs num_channels % 128 == 0, no depth plane, no norm plane and the default / ping-pong sweep");
+	}
 	if (a.pitch < width) return fail(SGS_EINVAL, "output pitch smaller than the image width");
 #ifdef SGS_WITH_FUSED
 	if (want_fused && (variant & 0xff) >= 34 && sgs::blend_forward_fused_pc_eligible(a)) {

@@ -254,6 +254,22 @@ __device__ __forceinline__ float sh_eval(int n, int q, const float px[4], const 
 // non-empty tiles (consecutive lists satisfy floor((x+n)/128) + 1 >= floor(x/128) + ceil(n/128)); an EMPTY tile has
 // range (0, 0) like the reference's, so its index would be `tile` and can coincide with an early tile's -- which is why
 // chunk 0 never touches the table (round 3: an empty tile next to a short-offset tile rendered that tile's first entry).
+// SGS_OPT_OUT_BANDS (include/sgs_raster.h): the feature map written BAND-major for an image-partitioned exchange between `nb` ranks -- band b holds the
+// image rows [lo_b, hi_b), lo_b = min(H, 16 * (gy * b / nb)) (sgs_hip.dist.band_rows), as a contiguous (C, hi_b - lo_b, pitch) block; the bands
+// follow each other in the buffer, so band b starts C * pitch * lo_b floats in.  For the tile row `ty`: its band's first tile row and row count.
+__host__ __device__ __forceinline__ void sgs_band_of(int ty, int gy, int nb, int H, int& lo_tile, int& rows)
+{
+	int b = (int)(((long long)(ty + 1) * nb - 1) / gy);
+	if (b < 0) b = 0;
+	if (b > nb - 1) b = nb - 1;
+	while (b > 0 && (long long)gy * b / nb > ty) b--;
+	while (b < nb - 1 && (long long)gy * (b + 1) / nb <= ty) b++;
+	lo_tile = (int)((long long)gy * b / nb);
+	const int hi_tile = (int)((long long)gy * (b + 1) / nb);
+	const int lo_row = 16 * lo_tile < H ? 16 * lo_tile : H, hi_row = 16 * hi_tile < H ? 16 * hi_tile : H;
+	rows = hi_row - lo_row;
+}
+
 __device__ __forceinline__ uint32_t sgs_chunk_start(const uint32_t* __restrict__ table, uint32_t chunk_base, uint32_t tile, uint32_t ci)
 {
 	return ci == 0u ? tile * 128u : table[chunk_base + ci];

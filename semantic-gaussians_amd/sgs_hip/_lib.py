@@ -44,6 +44,7 @@ EXPORTS = (
 
 # sgs_stream_set_option / sgs_stream_get_stat selectors (include/sgs_raster.h)
 OPT_BLEND_VARIANT, OPT_BINNING_MODE, OPT_BACKWARD_MODE, OPT_STAGE_TIMING, OPT_OUT_PITCH, OPT_DEFER_COUNT = 0, 1, 2, 3, 4, 5
+OPT_OUT_BANDS = 8
 OPT_BWD_CLEARS_DCOLOR = 6
 OPT_NORM_PLANE = 7
 STAT_ARENA_SLOTS, STAT_FWD_OVERFLOWS, STAT_BWD_OVERFLOWS, STAT_FORWARDS, STAT_DEFERRED_FORWARDS, STAT_DEFERRED_RETRIES, STAT_BWD_POOL_FALLBACKS, STAT_TILE_ORDER_ALLOC_FAILURES = 0, 1, 2, 3, 4, 5, 6, 7

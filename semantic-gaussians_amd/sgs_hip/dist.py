@@ -216,22 +216,32 @@ def render_gaussian_sharded(render_partial_fn, bg, order=None, all_gather=True):
     Returns the full (C,H,W) map (all_gather=True) or this rank's band of rows."""
     rank, w = world()
     a, t = render_partial_fn()
+    # A as a LIST of the w image bands (raster.render_partial(..., bands=w): the kernels wrote the map band-major): every band is already
+    # one contiguous message.  A (C,H,W) tensor is sliced and each band copied once (the transport needs contiguous buffers).
+    banded = isinstance(a, (list, tuple))
     if w == 1:
-        return composite_over([(a, t)], bg)[0]
+        return composite_over([(torch.cat(list(a), dim=1) if banded else a, t)], bg)[0]
+    if banded and len(a) != w:
+        raise ValueError(f"the partial comes in {len(a)} bands, the job has {w} ranks")
     order = list(range(w)) if order is None else list(order)
-    H = a.shape[1]
+    H = t.shape[0]
+    a0 = a[0] if banded else a
+    Cn, Wd = a0.shape[0], a0.shape[2]
     # image-partitioned all-to-all of the (A, T) partials: grouped point-to-point send / recv
     mine = band_rows(H, rank, w)
     recv = {}
     ops, keep = [], []
     for peer in range(w):
         lo, hi = band_rows(H, peer, w)
+        sa = a[peer] if banded else a[:, lo:hi].contiguous()
+        st = t[lo:hi]   # (rows of an (H,W) plane: contiguous as it is)
+        if banded and tuple(sa.shape) != (Cn, hi - lo, Wd):
+            raise ValueError(f"band {peer} has shape {tuple(sa.shape)}, expected {(Cn, hi - lo, Wd)}")
         if peer == rank:
-            recv[rank] = (a[:, lo:hi].contiguous(), t[lo:hi].contiguous())
+            recv[rank] = (sa, st)
             continue
-        sa, st = a[:, lo:hi].contiguous(), t[lo:hi].contiguous()
-        ra = torch.empty((a.shape[0], mine[1] - mine[0], a.shape[2]), dtype=a.dtype, device=a.device)
-        rt = torch.empty((mine[1] - mine[0], a.shape[2]), dtype=t.dtype, device=t.device)
+        ra = torch.empty((Cn, mine[1] - mine[0], Wd), dtype=a0.dtype, device=a0.device)
+        rt = torch.empty((mine[1] - mine[0], Wd), dtype=t.dtype, device=t.device)
         keep += [sa, st]
         recv[peer] = (ra, rt)
         if sa.numel():
@@ -239,7 +249,7 @@ def render_gaussian_sharded(render_partial_fn, bg, order=None, all_gather=True):
         if ra.numel():
             ops += [dist.P2POp(dist.irecv, ra, peer), dist.P2POp(dist.irecv, rt, peer)]
     if ops:
-        _host_transport_fence(a)   # (the contiguous send copies above are complete, too)
+        _host_transport_fence(a0)   # (the contiguous send copies above are complete, too)
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     band, _ = composite_over([recv[r] for r in order], bg)

@@ -217,12 +217,14 @@ def rasterize_forward_inference(*args, **kwargs):
 def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                       image_width, sh, degree, campos, prefiltered, debug, num_channels,
-                      want_depth, pool=None, norm_plane=False):
+                      want_depth, pool=None, norm_plane=False, out_bands=0):
     """RasterizeGaussiansCUDA (CR/rasterize_points.cu:38-121; RR variant returns depth too).
     Returns (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth).
     pool: optional ScratchPool for the three state buffers (inference; see ScratchPool).
     norm_plane: out_color is the (H,W) plane sum_c render[c]^2 instead of the (C,H,W) render (SGS_OPT_NORM_PLANE,
-    include/sgs_raster.h; C % 128 == 0, inference only)."""
+    include/sgs_raster.h; C % 128 == 0, inference only).
+    out_bands = n > 1: out_color is a LIST of n contiguous (C, rows_b, W) tensors, the image bands of sgs_hip.dist.band_rows (views of one
+    buffer the kernels wrote band-major, SGS_OPT_OUT_BANDS; C % 128 == 0, no depth): each band is one message of an image-partitioned exchange."""
     lib = _lib.load()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -235,9 +237,20 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         bufs = _Buffers(dev, pool)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         depth = None
+        def band_views(flat):
+            tiles = (H + 15) // 16
+            views = []
+            for b in range(out_bands):
+                lo, hi = min(H, 16 * (tiles * b // out_bands)), min(H, 16 * (tiles * (b + 1) // out_bands))
+                views.append(flat[Cn * W * lo:Cn * W * hi].view(Cn, hi - lo, W))
+            return views
+        if out_bands > 1 and (Cn % 128 or want_depth or norm_plane):
+            raise RuntimeError("out_bands needs a multiple of 128 channels, no depth plane and no norm plane")
         if P == 0:
             # reference returns zero-filled outputs without touching bg (rasterize_points.cu:85)
             color = torch.zeros((H, W) if norm_plane else (Cn, H, W), dtype=torch.float32, device=dev)
+            if out_bands > 1:
+                color = band_views(color.view(-1))
             if want_depth:
                 depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
             bufs.release()
@@ -246,7 +259,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         if norm_plane:
             if Cn % 128 or want_depth:
                 raise RuntimeError("norm_plane needs a multiple of 128 channels and no depth plane")
-        elif OUTPUT_PITCH_ALIGN > 1 and W % OUTPUT_PITCH_ALIGN and Cn >= 128 and not want_depth:
+        elif OUTPUT_PITCH_ALIGN > 1 and W % OUTPUT_PITCH_ALIGN and Cn >= 128 and not want_depth and out_bands <= 1:
             pitch = -(-W // OUTPUT_PITCH_ALIGN) * OUTPUT_PITCH_ALIGN
         color = torch.empty((H, W) if norm_plane else (Cn, H, pitch), dtype=torch.float32, device=dev)   # fully overwritten
         if want_depth:
@@ -274,9 +287,13 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
                 lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, pitch)
             if norm_plane:
                 lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_NORM_PLANE, 1)
+            if out_bands > 1:
+                lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_BANDS, int(out_bands))
             rc = lib.sgs_rasterize_forward(*args)
         finally:
             bufs.release()
+            if out_bands > 1:
+                lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_BANDS, -1)
             if pitch != W:
                 lib.sgs_stream_set_option(_stream_ptr(dev), _lib.OPT_OUT_PITCH, -1)
             if norm_plane:
@@ -284,6 +301,8 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         if pitch != W:
             color = color[:, :, :W]
         num_rendered = _lib.check(rc, "rasterize_gaussians failed")
+        if out_bands > 1:
+            color = band_views(color.view(-1))
     return num_rendered, color, radii, bufs.get("g"), bufs.get("b"), bufs.get("i"), depth
 
 
@@ -346,17 +365,19 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
 
 
 def render_partial(means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                   image_height, image_width, campos, scale_modifier=1.0, pool=None):
+                   image_height, image_width, campos, scale_modifier=1.0, pool=None, bands=0):
     """One Gaussian SHARD of a view as a compositing partial (A, T): A = the (C,H,W) feature map rendered with a
     ZERO background, T = the (H,W) transmittance left behind the shard.  Partials of depth-ordered shards combine
     with the "over" operator (sgs_hip.dist.composite_over / render_gaussian_sharded, BASELINE config 5):
-    (A1, T1) o (A2, T2) = (A1 + T1 A2, T1 T2).  -> (A, T, radii)"""
+    (A1, T1) o (A2, T2) = (A1 + T1 A2, T1 T2).  -> (A, T, radii)
+    bands = n > 1 (C % 128 == 0): A is the list of the n image bands of dist.band_rows, each a contiguous (C, rows, W) tensor the kernels wrote in
+    place (SGS_OPT_OUT_BANDS) -- what render_gaussian_sharded sends without a staging copy."""
     Cn = colors.size(1)
     bg = torch.zeros(Cn, dtype=torch.float32, device=means3D.device)
     e = torch.Tensor([])
     _, color, radii, _, _, img, _ = rasterize_forward(
         bg, means3D, colors, opacity, scales, rotations, scale_modifier, e, viewmatrix, projmatrix, tan_fovx,
-        tan_fovy, image_height, image_width, e, 0, campos, False, False, Cn, False, pool=pool)
+        tan_fovy, image_height, image_width, e, 0, campos, False, False, Cn, False, pool=pool, out_bands=bands if Cn % 128 == 0 else 0)
     if means3D.size(0) == 0:
         T = torch.ones(image_height, image_width, dtype=torch.float32, device=means3D.device)
     else:

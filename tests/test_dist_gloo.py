@@ -91,6 +91,12 @@ def _worker(rank, world, port, q):
         assert gs.shape == gs_ref.shape
         assert float((gs - gs_ref).abs().max()) < 2e-4 * (float(gs_ref.abs().max()) + 1.0)
         assert sd.band_rows(48, 0, 2) == (0, 16) and sd.band_rows(48, 1, 2) == (16, 48)
+        # the same partial handed over BAND-major (what raster.render_partial(..., bands=w) returns: a list of contiguous (C, rows, W)
+        # bands the kernels wrote in place): no staging copies, the same map bit for bit
+        def partial_banded():
+            a, t = partial()
+            return [a[:, lo:hi].contiguous() for lo, hi in (sd.band_rows(a.shape[1], r, 2) for r in range(2))], t
+        assert torch.equal(sd.render_gaussian_sharded(partial_banded, scene.bg), gs)
         # --- timing contract: max over ranks
         import time
         t = sd.timed_steps(lambda: time.sleep(0.02 * (rank + 1)), steps=3, warmup=1)
@@ -161,5 +167,7 @@ def test_composite_over_is_associative_and_handles_one_rank():
     assert torch.allclose(all3, grouped, atol=1e-6) and torch.allclose(t3, tg, atol=1e-7)
     swapped, _ = sd.composite_over([parts[1], parts[0], parts[2]], bg)
     assert not torch.allclose(all3, swapped, atol=1e-3)          # the operator is not commutative
+    one_b = sd.render_gaussian_sharded(lambda: ([parts[0][0]], parts[0][1]), bg)   # (a one-band list is the same partial)
     one = sd.render_gaussian_sharded(lambda: parts[0], bg)       # world size 1: partial + bg * T
+    assert torch.equal(one, one_b)
     assert torch.allclose(one, parts[0][0] + bg.reshape(-1, 1, 1) * parts[0][1], atol=1e-7)

@@ -29,6 +29,44 @@ def test_composite_over_kernel_equals_the_torch_chain(S, C, h, W):
         assert torch.equal(out, ref) and torch.equal(t, tr)
 
 
+@pytest.mark.parametrize("P,C,W,H,fx,nb,dense", [(4000, 128, 208, 160, 170.0, 2, False), (3000, 256, 205, 117, 170.0, 3, False),
+                                                  (3000, 128, 100, 70, 90.0, 8, False), (40000, 128, 400, 96, 300.0, 4, True)])
+def test_band_major_partials_equal_the_plain_partial(P, C, W, H, fx, nb, dense):
+    """SGS_OPT_OUT_BANDS (raster.render_partial(..., bands=n)): the kernels write the shard's feature map band-major -- band b of
+    dist.band_rows as one contiguous (C, rows, W) block -- so that the image-partitioned exchange of a Gaussian-sharded view sends every
+    band as it lies.  Each band must hold exactly the bits of the plain (C,H,W) partial's rows: the sweep, and (dense scene: first frame
+    on a cold stream) the gated single-kernel fallback that renders a frame whose work list overflowed; more bands than tile rows give
+    empty bands; widths that are not a multiple of 16."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import small_scene
+    from sgs_hip import raster, dist as sdist
+    scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=fx, seed=P + nb)
+    if dense:
+        scene = scene._replace(scales=scene.scales * 3.0, opacities=scene.opacities * 0.05)
+    s, c = scene.to(DEV), cam.to(DEV)
+    args = (s.means3D, s.features, s.opacities, s.scales, s.rotations, c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy,
+            H, W, c.camera_center)
+    st = torch.cuda.Stream(DEV)   # a cold stream: the dense scene's first frame overflows its work list (the fallback renders it)
+    with torch.cuda.stream(st):
+        for rep in range(3):
+            bands, tb, rb = raster.render_partial(*args, bands=nb)
+            plain, tp, rp = raster.render_partial(*args)
+            torch.cuda.synchronize()
+            assert isinstance(bands, list) and len(bands) == nb
+            assert torch.equal(tb, tp) and torch.equal(rb, rp)
+            for b in range(nb):
+                lo, hi = sdist.band_rows(H, b, nb)
+                assert bands[b].is_contiguous() and tuple(bands[b].shape) == (C, hi - lo, W), (b, bands[b].shape)
+                if dense and rep == 0:   # this frame was rendered by the fallback's fp32 chain, the plain one behind it by the sweep's six products
+                    assert float((bands[b] - plain[:, lo:hi]).abs().max()) <= 2e-5 * float(plain.abs().max()), (rep, b)
+                else:
+                    assert torch.equal(bands[b], plain[:, lo:hi]), (rep, b)
+            assert bands[0].untyped_storage().data_ptr() == bands[-1].untyped_storage().data_ptr()   # views of ONE buffer
+        if dense:
+            assert raster.stream_stat(__import__("sgs_hip._lib", fromlist=["x"]).STAT_FWD_OVERFLOWS) >= 1
+        raster.release_stream()
+
+
 def test_gaussian_sharded_render_over_rccl_two_gpus():
     """torchrun --nproc 2: each rank renders one depth slab with the HIP rasteriser (raster.render_partial), the bands
     travel as grouped point-to-point sends / receives over RCCL, every rank composites its band with the HIP kernel;

@@ -37,7 +37,7 @@ def main():
 
     def partial():
         A, T, _ = raster.render_partial(sh[0], sh[1], sh[2], sh[3], sh[4], cam.world_view_transform, cam.full_proj_transform,
-                                        cam.tanfovx, cam.tanfovy, H, W, cam.camera_center)
+                                        cam.tanfovx, cam.tanfovy, H, W, cam.camera_center, bands=world if C % 128 == 0 else 0)
         return A, T
     full = sdist.render_gaussian_sharded(partial, bg, all_gather=True)
     torch.cuda.synchronize(dev)
