@@ -741,8 +741,9 @@ def main():
                     "roofline": {"bound": "hbm", "algorithmic_bytes": bytes_bwd, "achieved": bytes_bwd / (t_b * 1e-3) / 1e9,
                                  "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_bwd / (t_b * 1e-3) / HBM_PEAK,
                                  "note": "4 C H W (dL/dpixel once) + 2 x 4 C sum n_t_eff (feature rows in, colour-gradient rows "
-                                         "out) + 28 sum n_t_eff + 8 H W + 104 P_vis; the kernels read the gradient once per 128 "
-                                         "entries of a tile and per product (DESIGN.md 5.5), which is the gap to close"},
+                                         "out) + 28 sum n_t_eff + 8 H W + 104 P_vis; since round 5 one kernel reads the gradient once per "
+                                         "128 entries of a tile for BOTH products (DESIGN.md 5.5, 5.14); fabric bytes by PMC: "
+                                         "profiles/r05_backward_pmc.txt"},
                     "includes": "output / gradient allocation through the caching allocator (no resident pool: the "
                                 "state buffers belong to the autograd graph)"}
         del dL
@@ -835,12 +836,12 @@ def main():
                          "secondary_ceilings": {
                              "algorithmic_gflop": flops_alg / 1e9,
                              "fp32_fma_frac": flops_alg / (blend_ms * 1e-3) / FP32_FMA_PEAK,
-                             "bf16_mfma_x8_frac_6_products": 6 * 2.0 * C * 256 * sum_neff * 0.55 / (blend_ms * 1e-3) / (BF16_MFMA_PEAK / 2),
+                             "bf16_mfma_frac_6_products": 6 * 2.0 * C * 256 * sum_neff * 0.55 / (blend_ms * 1e-3) / BF16_MFMA_PEAK,
                              "note": "algorithmic flops / blend time against the fp32 vector (= fp32 MFMA) peak 157.3 TF; the six "
-                                     "bf16 products (all 256 pixels of every active entry, ~55 % of sum n_t_eff) against HALF the "
-                                     "dense bf16 peak: the legacy 32x32x8 instruction the sweep issues runs at 512 FLOP/clk/SIMD "
-                                     "(the double-rate x16 form is not in the product library, DESIGN.md 5.10) -- PMC: profiles/r04_blend_pmc.txt "
-                                     "(SQ_VALU_MFMA_BUSY_CYCLES)"},
+                                     "bf16 products (all 256 pixels of every active entry, ~55 % of sum n_t_eff) against the "
+                                     "dense bf16 peak: since round 5 the sweep issues the double-rate 32x32x16 instruction "
+                                     "(1024 FLOP/clk/SIMD; DESIGN.md 5.10 for why that needed eight-wave workgroups that own "
+                                     "their compute unit) -- PMC: profiles/r05_blend_pmc.txt (SQ_VALU_MFMA_BUSY_CYCLES)"},
                          "measured": f"hipEvents on the launch stream over {sv_default['forwards']} forwards with one view "
                                      f"in flight; the timed region keeps {V} in flight (stage_ms_timed_region)"},
             # bytes_alg of the WHOLE forward (blend + binning front end) over the frame time
