@@ -447,7 +447,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def single_view(variant, n=24, deferred=False, inference=False):
+    def single_view(variant, n=24, deferred=False, inference=False, stage_events=True):
         """One view in flight: per-forward device time (hipEvents on the launch stream = torch's current
         stream) and the per-stage times (deferred resolution: no extra synchronisation).  deferred: the forward
         without the num_rendered read-back (each frame's counts are checked before the next one is enqueued)."""
@@ -463,7 +463,7 @@ def main():
                 torch.cuda.synchronize(dev)
         torch.cuda.synchronize(dev)
         raster.get_stage_ms()
-        raster.set_stage_timing(2)
+        raster.set_stage_timing(2 if stage_events else 0)   # (the eight per-stage event records of a frame are ~45 us of launch gaps)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in evs:
             a.record()
@@ -532,6 +532,10 @@ def main():
     sv_default, stage_ms = single_view(args.variant)
     # the same through the inference entry point (what the drop-in module does under no_grad): no read-back hole in the GPU's timeline
     sv_inference = single_view(args.variant, inference=True)[0]
+    # ... and as the product runs it: without the library's per-stage event records (instrumentation the two legs above switch on)
+    sv_untimed = single_view(args.variant, inference=True, stage_events=False)[0]
+    sv_inference["ms_median_without_stage_events"] = sv_untimed["ms_median"]
+    sv_inference["value_without_stage_events"] = sv_untimed["value"]
     # integrity reference: every (slot, camera)'s num_rendered, rendered alone (concurrent forwards must reproduce it)
     ref_n = []
     for i in range(V):

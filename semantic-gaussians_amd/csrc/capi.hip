@@ -311,7 +311,9 @@ struct StageTimer {
 	{
 		es.n = 0;
 		if (mode)
-			for (auto& e : es.ev) (void)hipEventCreate(&e);
+			// (timing only: nobody reads memory behind these events, so their records need no system-scope fence -- the eight of a frame
+			// cost 37 instead of 47 us of launch gaps, gpurun_out r05ad)
+			for (auto& e : es.ev) (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
 	}
 	void mark()
 	{

@@ -67,6 +67,31 @@ def test_band_major_partials_equal_the_plain_partial(P, C, W, H, fx, nb, dense):
         raster.release_stream()
 
 
+def test_band_major_partial_of_an_empty_shard():
+    """A depth slab with nothing in front of the camera (num_rendered == 0: the forward takes its no-work-list path) still hands over
+    band-major zeros with transmittance one -- the shape the exchange expects from every rank."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import small_scene
+    from sgs_hip import raster, dist as sdist
+    C, W, H, nb = 128, 120, 100, 3
+    scene, cam = small_scene(P=500, C=C, W=W, H=H, fx=100.0, seed=5)
+    s, c = scene.to(DEV), cam.to(DEV)
+    view_z = (torch.cat([s.means3D, torch.ones_like(s.means3D[:, :1])], 1) @ c.world_view_transform)[:, 2]
+    keep = view_z < 0.0   # behind the camera: culled by the frustum test
+    means = s.means3D.clone()
+    if int(keep.sum()) == 0:   # none there: mirror every Gaussian through the camera centre
+        means = 2.0 * c.camera_center.reshape(1, 3) - means
+        keep = torch.ones_like(keep)
+    bands, tb, rb = raster.render_partial(means[keep], s.features[keep], s.opacities[keep], s.scales[keep], s.rotations[keep],
+                                          c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, c.camera_center, bands=nb)
+    torch.cuda.synchronize()
+    assert len(bands) == nb and float(tb.min()) == 1.0 and float(tb.max()) == 1.0
+    for b in range(nb):
+        lo, hi = sdist.band_rows(H, b, nb)
+        assert tuple(bands[b].shape) == (C, hi - lo, W) and bands[b].is_contiguous() and float(bands[b].abs().max()) == 0.0
+    raster.release_stream()
+
+
 def test_gaussian_sharded_render_over_rccl_two_gpus():
     """torchrun --nproc 2: each rank renders one depth slab with the HIP rasteriser (raster.render_partial), the bands
     travel as grouped point-to-point sends / receives over RCCL, every rank composites its band with the HIP kernel;
