@@ -1130,9 +1130,8 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 			const float oma = 1.f - alpha;
 			// one reciprocal for the two divisions by 1 - alpha (alpha <= 0.99: v_rcp_f32 + one Newton step is within an ulp of the
 			// IEEE quotient, and this kernel's sums are order-dependent atomics anyway; two IEEE divisions were 18 of the step's
-			// ~107 VALU instructions -- and a long piece of its dependent chain: the kernel is bound by the LATENCY of a step, ~1 000
-			// cycles with 8 waves per SIMD, not by VALU issue -- a packed two-pixels-per-lane form with half the instructions was
-			// no faster)
+			// ~107 VALU instructions, and the kernel is bound by VALU issue: 195 M wave instructions x 4 cycles = its 0.35 ms.
+			// A packed two-pixels-per-lane form was no faster: it loses this form's per-wave skips)
 			float rinv = __builtin_amdgcn_rcpf(oma);
 			rinv = __builtin_fmaf(__builtin_fmaf(-oma, rinv, 1.f), rinv, rinv);
 			if (valid) T = T * rinv;
