@@ -1112,11 +1112,47 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 			s_e[threadIdx.x] = e;
 		}
 		__syncthreads();
+		// Which staged entries can touch THIS wave's 4 x 16 pixels at all: lane l bounds entry l's power over the wave's rectangle (the
+		// maximum of the quadratic over its edges when the centre lies outside -- blend_weights2.hip's tile-level rejection, on a quarter
+		// tile) against the alpha test's threshold log(1 / (255 o)).  Conservative by 0.01 on every side, so a cleared bit is an entry whose
+		// step would have left at its ballot after ~35 instructions with nothing changed; now the step is skipped by two scalar instructions
+		// and its D row is not loaded.  One ballot per 64 entries and wave.  Measured (call AF): few of a tile's kept entries miss a whole quarter
+		// tile -- 2.6 % fewer VALU instructions, 7 % fewer row loads, 3.5 % of the kernel's time (307 -> 296 us).
+		unsigned long long hit;
+		{
+			bool keep = lane < n;
+			if (keep) {
+				const float ea = s_e[lane].a2, eb = s_e[lane].b2, ec = s_e[lane].c2;
+				if (ea < 0.f && ec < 0.f && 4.f * ea * ec - eb * eb > 0.f) {
+					const float thr = __logf(1.0f / (255.0f * s_e[lane].o)) - 0.01f;
+					const float ex0 = s_e[lane].x, ey0 = s_e[lane].y;
+					const float dxl = ex0 - (float)(tx * SGS_TILE + SGS_TILE - 1) - 0.01f;
+					const float dxh = ex0 - (float)(tx * SGS_TILE) + 0.01f;
+					const float dyl = ey0 - (float)(ty * SGS_TILE + wave * 4 + 3) - 0.01f;
+					const float dyh = ey0 - (float)(ty * SGS_TILE + wave * 4) + 0.01f;
+					if (!(dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f)) {
+						float qmax = -__builtin_inff();
+#pragma unroll
+						for (int k = 0; k < 2; k++) {
+							const float ex = k ? dxh : dxl;
+							const float sy = fmin_(fmax_(-eb * ex / (2.f * ec), dyl), dyh);
+							qmax = fmax_(qmax, ea * ex * ex + eb * ex * sy + ec * sy * sy);
+							const float ey = k ? dyh : dyl;
+							const float sx = fmin_(fmax_(-eb * ey / (2.f * ea), dxl), dxh);
+							qmax = fmax_(qmax, ea * sx * sx + eb * sx * ey + ec * ey * ey);
+						}
+						keep = !(qmax < thr - 0.01f);
+					}
+				}
+			}
+			hit = __ballot(keep);
+		}
 		// One entry of the walk.  Dk (this pixel's D of the entry) arrives prefetched: the load is the only global
 		// access of a step and its address does not depend on the recurrence, so a group of 8 is requested while the
 		// previous group is processed (as written before -- one dependent load per step -- the kernel was bound by
 		// that latency: 0.73 ms for 455 k entries).
 		auto step = [&](const StagedEntryG& e, float Dk, int kslot) __attribute__((always_inline)) {
+			if (!((hit >> kslot) & 1ull)) return;
 			const int idx = (int)e.idx1 - 1;
 			if (idx >= wave_max) return;
 			const float dx = e.x - pxf, dy = e.y - pyf;
@@ -1153,12 +1189,12 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 		constexpr int PF = 8;
 		float dcur[PF], dnext[PF];
 #pragma unroll
-		for (int u = 0; u < PF; u++) dcur[u] = u < n ? Drows[(size_t)s_e[u].slot * 256 + pxp] : 0.f;
+		for (int u = 0; u < PF; u++) dcur[u] = (u < n && ((hit >> u) & 1ull)) ? Drows[(size_t)s_e[u].slot * 256 + pxp] : 0.f;
 		for (int k0 = 0; k0 < n; k0 += PF) {
 #pragma unroll
 			for (int u = 0; u < PF; u++) {
 				const int kk = k0 + PF + u;
-				dnext[u] = kk < n ? Drows[(size_t)s_e[kk].slot * 256 + pxp] : 0.f;
+				dnext[u] = (kk < n && ((hit >> kk) & 1ull)) ? Drows[(size_t)s_e[kk].slot * 256 + pxp] : 0.f;
 			}
 #pragma unroll
 			for (int u = 0; u < PF; u++)
