@@ -914,6 +914,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		static const int default_sweep = !getenv("SGS_DEFAULT_SWEEP") ? 0x10004
 						 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 14 ? 14 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 16 ? 0x10006 : 6));
 		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : default_sweep));
+		if (a.bands && (split_word & 15) != 4 && (split_word & 15) != 6)   // (the word the default resolves to: SGS_DEFAULT_SWEEP=14 selects a kernel without bands)
+			return fail(SGS_EINVAL, "SGS_OPT_OUT_BANDS needs the ping-pong sweep (the default)");
 		if (norm_plane) {
 			if ((split_word & 15) != 14 && (split_word & 15) != 11 && (split_word & 15) != 6 && (split_word & 15) != 4)
 				return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs the default blend (variants 0 / 15)");
