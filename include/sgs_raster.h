@@ -346,7 +346,7 @@ int sgs_set_binning_mode(int mode);
  * 3 = the same kernel with exact fp32 products (v_mfma_f32_32x32x2_f32), ~1.3 ms slower at 1M x 512 x 968x1296;
  * 1 = always the per-chunk VALU kernel (blend_bwd.hip); 2 = as 0 with a deliberately undersized work-list arena
  * (exercises the overflow fallback; tests only); 4 / 5 = rounds 2-4's form of 0 / 3 (one kernel per product, each
- * streaming the gradient; kept for A/B runs).  All within 1e-4 of the largest gradient entry of the float64 oracle
+ * streaming the gradient; `make EXPERIMENTS=1` builds only, SGS_EINVAL otherwise).  All within 1e-4 of the largest gradient entry of the float64 oracle
  * (tests, also at the headline configuration's full size).  Returns the previous mode. */
 int sgs_set_backward_mode(int mode);
 /* Which optional parts this libsgs_hip.so was built with: bit 0 `make FUSED=1` (blend variants 32-35), bit 1 `make X16=1` (the
