@@ -1154,7 +1154,10 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	// (x16 forms) 144 AGPRs + 112 VGPRs = 256 registers per wave: two waves per SIMD fill its register file, so that NO foreign wave --
 	// not even an 8-register fill kernel -- can be resident on this workgroup's compute unit between its first and its last matrix
 	// instruction (all eight waves are resident from dispatch; the last matrix phase lies before the final barrier every wave passes)
+	// (both halves of the count are pinned: the lock-step form happens to need 112 VGPRs, the free-running one 104 -- 248 would leave 16
+	// registers per SIMD lane for a foreign wave; tests/test_code_object.py reads the counts back from the built library)
 	if constexpr (MM != 0) asm volatile("" : : : "a143");
+	if constexpr (MM != 0 && FREE) asm volatile("" : : : "v111");
 	if (counter[1] != 0u) return;   // arena overflowed / frame aborted
 	(void)tune;   // (tuning word, bits [19:16] of the blend variant: unused -- call E's placement / priority experiments are settled,
 	// profiles/r04_sweep_dma_placement.txt: pieces issued in PREP cost 300-400 cycles each, per-phase priorities change nothing)
