@@ -238,10 +238,10 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         depth = None
         def band_views(flat):
-            tiles = (H + 15) // 16
+            from .dist import band_rows   # the one definition of the bands (the kernels' sgs_band_of restates it: tests/test_multigpu.py)
             views = []
             for b in range(out_bands):
-                lo, hi = min(H, 16 * (tiles * b // out_bands)), min(H, 16 * (tiles * (b + 1) // out_bands))
+                lo, hi = band_rows(H, b, out_bands)
                 views.append(flat[Cn * W * lo:Cn * W * hi].view(Cn, hi - lo, W))
             return views
         if out_bands > 1 and (Cn % 128 or want_depth or norm_plane):
