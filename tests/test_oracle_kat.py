@@ -75,6 +75,32 @@ def test_sh_dense_directions_match_reference_eval_sh(orc):
     print(f"dense SH known answers: worst |oracle - reference| = {worst:.2e} of the terms' magnitude")
 
 
+def test_cov3d_matches_reference_python_route(orc):
+    """One more formula of the path pinned by the reference itself: the 3-D covariance.  The reference has two routes to it -- the kernel's
+    computeCov3D (CR/cuda_rasterizer/forward.cu:115-150) and `pipe.compute_cov3D_python` = GaussianModel.get_covariance
+    (model/gaussian_model.py:34-38: strip_symmetric(L L^T), L = R(q) diag(modifier * s), utils/general_utils.py:66-115), which must agree.
+    512 known answers of the Python route (fixture tests/golden/cov3d_reference.npz, generator beside it: the reference's helpers imported,
+    scales over four decades, three scale modifiers): the oracle's cov3D within 16 fp32 ulps of the entry's scale |R|^2 (modifier s)^2."""
+    z = np.load(os.path.join(GOLD, "cov3d_reference.npz"))
+    scales, rots = z["scales"], z["rotations"]
+    n = scales.shape[0]
+    cam = pinhole(64, 64, 30.0)
+    pos = np.tile(np.array([[0.0, 0.0, 3.0]], np.float32), (n, 1))   # on the axis: nothing is culled
+    worst = 0.0
+    for i, m in enumerate(z["modifiers"]):
+        pre = orc.preprocess(pos, np.full((n, 1), 0.5, np.float32), cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(),
+                             np.zeros(3, np.float32), 64, 64, cam.tanfovx, cam.tanfovy, scales=scales, rotations=rots,
+                             scale_modifier=float(m), colors_precomp=np.ones((n, 3), np.float32))
+        vis = pre["radii"] > 0
+        assert vis.sum() > n * 3 // 4   # (the smallest Gaussians project to a zero radius: their record is not written)
+        want = z[f"cov3D_{i}"].astype(np.float64)
+        mag = (float(m) * scales.astype(np.float64).max(axis=1, keepdims=True)) ** 2   # every entry is a sum of products of (m s_k) R_ik R_jk, |R| <= 1
+        err = np.abs(pre["cov3D"].astype(np.float64) - want) / mag
+        assert (err[vis] <= 16.0 * 2.0 ** -23).all(), (float(m), float(err[vis].max()))   # (measured: 7.8 ulp -- two fp32 routes with different operation orders)
+        worst = max(worst, float(err[vis].max()))
+    print(f"cov3D known answers: worst |oracle - reference| = {worst:.2e} of (modifier * largest scale)^2")
+
+
 def test_sh_matches_reference_eval_sh(orc):
     """oracle SH->RGB (before +0.5/clamp) == utils/sh_utils.py eval_sh (fixture)."""
     fx = json.load(open(os.path.join(GOLD, "reference_fixtures.json")))
