@@ -650,7 +650,7 @@ def main():
         return {"arithmetic": what, "value": world * V * H * W * C / (ms_e * 1e-3) / 1e9, "unit": "Gpixel*channels/s",
                 "ms_per_step": ms_e, "ms_per_view": ms_e / V, "steps": kx, "views_in_flight": V,
                 "num_rendered_mismatches_vs_serial": mism_e, "deferred_retries": retr, "single_view": sv,
-                "roofline_frac": bytes_blend / ((stg[5] + stg[6]) * 1e-3) / HBM_PEAK}
+                "roofline_frac": (bytes_blend / ((stg[5] + stg[6]) * 1e-3) / HBM_PEAK) if stg[5] + stg[6] > 0 else None}
     if not args.no_extras:
         exact = extra_leg(EXACT, "fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate: bit-identical to the contract")
         two_term = extra_leg(TWO_TERM, "round 2's default: two bf16 terms per operand, three MFMA products "
@@ -839,8 +839,8 @@ def main():
                          "kernels_ms": {"blend_weights": round(stage_ms[5], 4), "blend_accum": round(stage_ms[6], 4)},
                          "secondary_ceilings": {
                              "algorithmic_gflop": flops_alg / 1e9,
-                             "fp32_fma_frac": flops_alg / (blend_ms * 1e-3) / FP32_FMA_PEAK,
-                             "bf16_mfma_frac_6_products": 6 * 2.0 * C * 256 * sum_neff * 0.55 / (blend_ms * 1e-3) / BF16_MFMA_PEAK,
+                             "fp32_fma_frac": (flops_alg / (blend_ms * 1e-3) / FP32_FMA_PEAK) if blend_ms > 0 else None,
+                             "bf16_mfma_frac_6_products": (6 * 2.0 * C * 256 * sum_neff * 0.55 / (blend_ms * 1e-3) / BF16_MFMA_PEAK) if blend_ms > 0 else None,
                              "note": "algorithmic flops / blend time against the fp32 vector (= fp32 MFMA) peak 157.3 TF; the six "
                                      "bf16 products (all 256 pixels of every active entry, ~55 % of sum n_t_eff) against the "
                                      "dense bf16 peak: since round 5 the sweep issues the double-rate 32x32x16 instruction "
