@@ -100,6 +100,44 @@ def view_camera(n, W, H, fx):
     return make_camera(R, T, focal2fov(fx, W), focal2fov(fx, H), W, H)
 
 
+def pin_to_gpu_numa(dev):
+    """Pin this rank's host threads to the cores of its GPU's NUMA node (eight Python processes on a 256-thread host
+    migrate, and the >= 6x target at 8 GPUs guards against exactly that kind of host-side serialisation).  The node comes from the
+    device's PCI address in sysfs (local_cpulist of the function the runtime reports for `dev`); SGS_BENCH_NO_PIN=1 switches it off.
+    -> a dict for the bench line (what was done, or why not); never raises."""
+    info = {"pinned": False}
+    try:
+        if os.environ.get("SGS_BENCH_NO_PIN", "0") == "1":
+            info["reason"] = "SGS_BENCH_NO_PIN=1"
+            return info
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        info["pci"] = bdf
+        with open(base + "/numa_node") as f:
+            info["numa_node"] = int(f.read().strip())
+        with open(base + "/local_cpulist") as f:
+            cpulist = f.read().strip()
+        cpus = set()
+        for part_ in cpulist.split(","):
+            if "-" in part_:
+                a, b = part_.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part_:
+                cpus.add(int(part_))
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        if not cpus or cpus == allowed:
+            info["reason"] = "the device's local cpulist is the whole allowed set (one NUMA node, or no locality information)"
+            info["cpus"] = len(allowed)
+            return info
+        os.sched_setaffinity(0, cpus)
+        info.update(pinned=True, cpus=len(cpus), cpulist=cpulist)
+    except Exception as ex:   # noqa: BLE001
+        info["reason"] = f"{type(ex).__name__}: {ex}"
+    return info
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (rank 0's stdout is ours)."""
     with socket.socket() as s:
@@ -348,6 +386,9 @@ def main():
     ap.add_argument("--extra-configs", action="store_true",
                     help="also time BASELINE configs 4 (views sharded) and 5 (Gaussians sharded, RCCL exchange); on by default "
                          "when --gpus > 1")
+    ap.add_argument("--front-cus", type=int, default=int(os.environ.get("SGS_BENCH_FRONT_CUS", "32")),
+                    help="compute units set aside for the views' front ends in the headline (raster.PartitionedStreams: every view slot gets a "
+                         "blend stream on the other CUs and a front stream on these); 0 = ordinary streams, every kernel anywhere (round 5's headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-arithmetic / backward legs")
     args = ap.parse_args()
@@ -370,6 +411,8 @@ def main():
     dev = torch.device("cuda", 0 if one_dev else local_rank)
     torch.cuda.set_device(dev)
     red_dev = torch.device("cpu") if one_dev else dev   # where the scalars of the control collectives live
+    affinity = pin_to_gpu_numa(dev)
+    log(f"[rank {rank}] host affinity: {affinity}")
     rccl = None
     if world > 1:
         import torch.distributed as dist
@@ -401,7 +444,10 @@ def main():
 
     # inference: state buffers stay resident (as under torch.no_grad); one pool and stream per view in flight
     pools = [raster.ScratchPool() for _ in range(V)]
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(V - 1)]
+    plain_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(V - 1)]
+    streams = plain_streams
+    # the headline's streams: per view slot a blend stream on CUs [front_cus, n) with its front end on CUs [0, front_cus)
+    part = raster.PartitionedStreams(dev, args.front_cus, V) if args.front_cus > 0 else None
 
     def render(i, deferred=False, k=0):
         c = cams[i][k % NCAM]
@@ -492,8 +538,19 @@ def main():
 
     rank_ms = {}   # ms per step of the slowest / fastest rank in the last in_flight() (a straggler shows here)
 
-    def in_flight(variant, steps, warmup, stage_timing=False, defer=None):
+    def in_flight(variant, steps, warmup, stage_timing=False, defer=None, partitioned=True):
+        nonlocal streams
         raster.set_blend_variant(variant)
+        streams = part.streams if (part is not None and partitioned) else plain_streams
+        for st_ in streams:
+            st_.wait_stream(torch.cuda.current_stream(dev))
+        try:
+            return _in_flight(variant, steps, warmup, stage_timing, defer)
+        finally:
+            torch.cuda.synchronize(dev)
+            streams = plain_streams
+
+    def _in_flight(variant, steps, warmup, stage_timing, defer):
         out = None
         for k in range(warmup):
             out = step(k, defer, out)   # exactly like the timed loop, so that the caching allocator reaches its steady-state
@@ -546,7 +603,7 @@ def main():
         ref_n.append(row)
     if world > 1:   # a mis-sharded run shows at a glance: every rank's device, its view numbers and their num_rendered
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, {"rank": rank, "device": f"cuda{local_rank}:{torch.cuda.get_device_name(dev)}",
+        dist.all_gather_object(per_rank, {"rank": rank, "device": f"cuda{local_rank}:{torch.cuda.get_device_name(dev)}", "host_affinity": affinity,
                                           "views": [(rank * V + i) * NCAM for i in range(V)],
                                           "num_rendered_first_camera": [row[0] for row in ref_n]})
         rccl["per_rank"] = per_rank
@@ -597,6 +654,8 @@ def main():
     # ---- the headline: K timed steps, V views in flight, default arithmetic
     gc.collect()
     torch.cuda.synchronize(dev)
+    for p_ in pools:
+        p_.clear()
     torch.cuda.empty_cache()              # (the legs above leave their own cached blocks behind: the memory figures below are
     torch.cuda.reset_peak_memory_stats(dev)   # the headline's -- scene, resident state buffers, V feature maps)
     ms_per_step, ms_step_median, mismatches, out, retries = in_flight(args.variant, args.steps, max(2, args.warmup), True)
@@ -643,20 +702,27 @@ def main():
     exact = backward = two_term = deferred = classic = None
     kx = max(8, min(args.steps, 60))
 
-    def extra_leg(variant, what, defer=None):
-        sv, stg = single_view(variant, deferred=defer is True)
-        ms_e, ms_e_med, mism_e, out_e, retr = in_flight(variant, kx, max(3, NCAM + 2), defer=defer)   # every camera of a slot and the wrap-around seen once: buffers at their steady size
+    def extra_leg(variant, what, defer=None, sv=True, partitioned=True):
+        sv_, stg = single_view(variant, deferred=defer is True) if sv else (None, None)
+        ms_e, ms_e_med, mism_e, out_e, retr = in_flight(variant, kx, max(3, NCAM + 2), defer=defer, partitioned=partitioned)   # every camera of a slot and the wrap-around seen once: buffers at their steady size
         del out_e
         return {"arithmetic": what, "value": world * V * H * W * C / (ms_e * 1e-3) / 1e9, "unit": "Gpixel*channels/s",
                 "ms_per_step": ms_e, "ms_per_view": ms_e / V, "steps": kx, "views_in_flight": V,
-                "num_rendered_mismatches_vs_serial": mism_e, "deferred_retries": retr, "single_view": sv,
-                "roofline_frac": (bytes_blend / ((stg[5] + stg[6]) * 1e-3) / HBM_PEAK) if stg[5] + stg[6] > 0 else None}
+                "cu_partition": bool(part is not None and partitioned),
+                "num_rendered_mismatches_vs_serial": mism_e, "deferred_retries": retr, "single_view": sv_,
+                "roofline_frac": (bytes_blend / ((stg[5] + stg[6]) * 1e-3) / HBM_PEAK) if sv and stg[5] + stg[6] > 0 else None}
+    # the reference's own host pattern (the wait for num_rendered in the MIDDLE of the frame) always rides beside the headline, and so
+    # does round 5's stream arrangement (ordinary streams, every kernel on any compute unit)
+    classic = extra_leg(args.variant, "default arithmetic, the host waits for num_rendered in the MIDDLE of every forward (the reference's host "
+                                      "pattern, rasterizer_impl.cu:283; rounds 1-4's headline)", defer="classic", sv=not args.no_extras)
+    shared_cus = None
+    if part is not None:
+        shared_cus = extra_leg(args.variant, "default arithmetic and host pattern on ORDINARY streams: every kernel of every view on any compute unit "
+                                             "(round 5's headline arrangement)", sv=False, partitioned=False)
     if not args.no_extras:
         exact = extra_leg(EXACT, "fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate: bit-identical to the contract")
         two_term = extra_leg(TWO_TERM, "round 2's default: two bf16 terms per operand, three MFMA products "
                                        "(<= 3 * 2^-16 of sum |f| w per term): NOT fp32-class, kept selectable (blend variant 14)")
-        classic = extra_leg(args.variant, "default arithmetic, the host waits for num_rendered in the MIDDLE of every forward (the reference's host "
-                                          "pattern, rasterizer_impl.cu:283; rounds 1-4's headline)", defer="classic")
         deferred = extra_leg(args.variant, "default arithmetic, deferred counts (SGS_OPT_DEFER_COUNT, inference only): no host "
                                            "read-back inside the forward", defer=True)
         raster.set_blend_variant(args.variant)
@@ -790,7 +856,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: P={P} Gaussians, C={C}, {H}x{W} forward render "
                                    f"(BASELINE.md config 3 generator, seed 0)",
-                       "views_per_step_per_gpu": V, "hip_streams_per_gpu": V,
+                       "views_per_step_per_gpu": V, "hip_streams_per_gpu": V * (2 if part is not None else 1),
                        "parallelism": f"views x{world * V}: {V} in flight per GPU on {V} HIP streams, {world} GPU(s), "
                                       f"scene replicated, no collective",
                        "rccl": rccl,
@@ -815,6 +881,7 @@ def main():
                                             "on < 1e-5 of the elements -- as the oracle's own chain does against the exact composite "
                                             "(tests/test_configs_gpu.py); exact_f32 below is the bit-identical fp32-MFMA path")},
             "ms_per_step_median": ms_step_median,
+            "host_affinity": affinity,
             "ms_per_step_ranks": headline_rank_ms,   # slowest / fastest rank's own clock over the same timed region
             "memory": mem,
             "ms_per_view": ms_per_step / V,
@@ -823,6 +890,14 @@ def main():
                                           "enqueued against the stream's capacity guess before the host waits for num_rendered (what "
                                           "GaussianRasterizer does under torch.no_grad(); single_view above keeps the reference's mid-frame wait)"),
             "api_path": api,
+            "host_pattern": {"speculative": "speculative: the frame is enqueued in full against the stream's capacity guess, then the host waits for its num_rendered",
+                             "classic": "classic: the host waits for num_rendered in the middle of every forward (the reference's pattern)",
+                             True: "deferred counts"}[DEFER],
+            "cu_partition": ({"front_cus": part.front_cus, "blend_cus": part.cu_count - part.front_cus, "device_cus": part.cu_count,
+                              "note": "every view slot: blend stream confined to the blend CUs, front end (preprocess, depth sort, span partitions) "
+                                      "on a second stream confined to the front CUs (hipExtStreamCreateWithCUMask; sgs_stream_set_front); "
+                                      "shared_cus below = the same headline on ordinary streams"} if part is not None else None),
+            "shared_cus": shared_cus,
             "classic_count": classic,
             "deferred_count": deferred,
             "exact_f32": exact,

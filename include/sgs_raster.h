@@ -304,6 +304,31 @@ int sgs_forward_result(void *stream, int wait, int *num_rendered);
  * context alive until they return. */
 int sgs_stream_release(void *stream);
 
+/* ---- compute-unit partitions (round 6; no counterpart in the reference, which runs one frame at a time on the null stream,
+ * CR/cuda_rasterizer/rasterizer_impl.cu:198-341) ----------------------------------------------------------------------------
+ * The accumulate sweep's workgroup (8 waves x 256 registers) can only start on a compute unit that holds nothing else; with several
+ * views in flight the ~17 short, latency-bound front-end kernels of the other views keep a few waves on ALL compute units and hold
+ * every sweep workgroup off for their duration.  These calls give the front end its own small share of the chip:
+ *   sgs_device_cu_count            compute units of the current device
+ *   sgs_stream_create_cu_range     a stream whose kernels only run on compute units [cu_first, cu_first + cu_count) of the current
+ *                                  device (hipExtStreamCreateWithCUMask; the driver deals consecutive mask bits round-robin over the
+ *                                  XCDs, so a range is spread evenly over them).  Destroy it with sgs_stream_destroy.
+ *   sgs_stream_set_front           forwards issued on `stream` enqueue preprocess -> depth sort -> span partitions (and the count
+ *                                  record / read-back) on `front_stream` and only the blend on `stream`; the two are ordered by events
+ *                                  inside the call (front end behind the stream's earlier work, blend behind the front end), so the
+ *                                  caller keeps addressing ONE stream.  front_stream NULL (or == stream): one stream again.
+ * Typical use (bench.py, sgs_hip.raster.partitioned_streams): per view slot a blend stream on CUs [f, n) and a front stream on [0, f). */
+int sgs_device_cu_count(void);
+int sgs_stream_create_cu_range(int cu_first, int cu_count, void **stream_out);
+int sgs_stream_destroy(void *stream);
+int sgs_stream_set_front(void *stream, void *front_stream);
+/* The kernels that issue the double-rate MFMA (v_mfma_f32_32x32x16_bf16) must own their compute unit.  The build
+ * checks their code objects (csrc/check_code_object.py, a step of `make`); this asks the runtime about the LOADED kernels on the
+ * current device (hipFuncGetAttributes: 256 registers, 512 threads, > 80 KB LDS, no scratch), once per process:
+ * bit 0 = the forward's ping-pong sweeps, bit 1 = the fused backward.  A kernel whose bit is clear is never launched: the x8 sweep /
+ * the fp32-product backward (same interface, bit-identical / fp32-exact results) run in its place, with one line on stderr. */
+int sgs_x16_cu_ownership(void);
+
 /* Selects the forward blend kernels.  The product library (sgs_build_flags() == 0) knows:
  *   0  (default) num_channels >= 128: weights pre-pass + ping-pong row sweep for the 128-channel-aligned part in "f32-equivalent"
  *      arithmetic -- features and weights split EXACTLY into three bf16 terms each, the six products with i + j <= 4 on
@@ -314,11 +339,13 @@ int sgs_stream_release(void *stream);
  *   15 as 0 with the fp32-input MFMA sweep: the feature map is BIT-IDENTICAL to the contract's fp32 fma chain (SGS_BLEND_EXACT=1);
  *   14 round 2's arithmetic: two bf16 terms per operand, three products (<= 3 * 2^-16 of sum |f| w): the fastest, NOT fp32-class;
  *   6  the single-kernel px4 form for the 128-aligned part (the gated fallback of 0 when its work list overflows);
- *   >= 16, the word form:  bits [3:0] sweep (6 = 0's, 11 = 15's, 0 / 8 = 14's) | [7:4] segment length / 8 tiles (0 = adaptive)
+ *   >= 16, the word form:  bits [3:0] sweep (4 / 6 = 0's ping-pong sweep: 4 its free-running form, 6 its lock-step form; 11 = 15's,
+ *      0 / 8 = 14's) | [7:4] segment length / 8 tiles (0 = adaptive)
  *      | [13:12] workgroup order (0 / 3 = segments sorted by work and dealt to the XCDs, 1 = row-major, 2 = dealt unsorted)
- *      | [19:16] with sweep 6: 1 = on the x16 MFMA (what 0 selects), 0 = on the x8 MFMA (round 4's default, bit-identical to round 3's).
- * Everything else -- sweep nibbles 4 / 5 / 7 / 9 / 10 / 13 / 14, ablation bits [11:8], pre-pass switches [15:14], single-kernel
- * forms 1-5 -- is a development form (`make EXPERIMENTS=1`; DESIGN.md 5.x has the measurements), 12 / 15 / [19:16] the
+ *      | [19:16] with sweeps 4 / 6: 1 = on the x16 MFMA, 0 = on the x8 MFMA (sweep 6 only: round 4's default, bit-identical).
+ *      What 0 selects is the word 0x10004 (free-running halves on x16; 0x10006 = the same in lock step: bit-identical maps).
+ * Everything else -- sweep nibble 4 with bits [19:16] = 0, nibbles 5 / 7 / 9 / 10 / 13 / 14, ablation bits [11:8], pre-pass switches
+ * [15:14], single-kernel forms 1-5 -- is a development form (`make EXPERIMENTS=1`; DESIGN.md 5.x has the measurements), 12 / 15 / [19:16] the
  * double-rate-MFMA reproducers (`make X16=1`), 32-35 round 2's fused kernels (`make FUSED=1`): SGS_EINVAL here.
  * Returns the previous value. */
 int sgs_set_blend_variant(int variant);
@@ -330,7 +357,8 @@ int sgs_set_blend_variant(int variant);
  * forwards since the last query (no extra synchronisation inside the timed region).
  * sgs_get_stage_ms returns the number of forwards averaged (0 in mode 1). */
 int sgs_set_stage_timing(int mode);
-/* Binning algorithm: 0 (default) = Gaussians presorted by depth, per-tile lists built from row
+/* Binning algorithm (1 and 2 run on rocPRIM's scan / radix sort and are `make EXPERIMENTS=1` builds only since round 6 -- SGS_EINVAL in the
+ * product library, which carries no library kernel): 0 (default) = Gaussians presorted by depth, per-tile lists built from row
  * instances without sorting the tile instances (binning_rows.hip; 3 is accepted as an alias); 1 = the reference's order of
  * operations (emit in index order, sort on all 32+msb(tiles) key bits); 2 = depth presort,
  * instances emitted in that order, stable radix sort on the 32-bit tile id.  Lists (point_list),

@@ -26,12 +26,27 @@
 // offsets array, so every store is a fully coalesced 512-B/256-B wave store and the work
 // is perfectly balanced.  The plain scan and radix sort are rocPRIM library calls on the
 // caller's stream (the reference uses CUB for the same two steps).
+//
+// Round 6: the two rocPRIM calls (and with them ~450 library kernel instantiations, 3.2 MB of the library's 4.2 MB of device code)
+// are only reached from binning modes 1 / 2 -- the reference-order witness and round 1's default -- which no product path selects
+// (mode 0 = span partitions, binning_rows.hip, on depth_sort.hip's own radix sort).  They are built by `make EXPERIMENTS=1`; the
+// product library answers those modes with SGS_EINVAL and carries no rocprim:: symbol.
 #include "sgs_kernels.h"
+#ifdef SGS_WITH_EXPERIMENTS
 #include <cstring>   // rocPRIM's texture iterator calls host memset
 #include <rocprim/rocprim.hpp>
+#endif
 
 namespace sgs {
 
+#ifndef SGS_WITH_EXPERIMENTS
+size_t scan_temp_bytes(int) { return 0; }
+hipError_t launch_inclusive_scan(hipStream_t, void*, size_t, const uint32_t*, uint32_t*, int) { return hipErrorNotSupported; }
+size_t sort_temp_bytes(size_t, int, int) { return 0; }
+hipError_t launch_sort_pairs(hipStream_t, void*, size_t, uint64_t*, uint64_t*, uint32_t*, uint32_t*, size_t, int, int) { return hipErrorNotSupported; }
+size_t sort32_temp_bytes(size_t, int) { return 0; }
+hipError_t launch_sort32_pairs(hipStream_t, void*, size_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, size_t, int) { return hipErrorNotSupported; }
+#else
 size_t scan_temp_bytes(int P)
 {
 	size_t bytes = 0;
@@ -46,6 +61,7 @@ hipError_t launch_inclusive_scan(hipStream_t st, void* temp, size_t temp_bytes,
 	return rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)P,
 				       rocprim::plus<uint32_t>(), st);
 }
+#endif
 
 // One lane per emitted (tile, Gaussian) instance.  `perm` (optional) maps emission rank ->
 // Gaussian index: null = the reference's emission order (ascending index), else the
@@ -89,11 +105,6 @@ void launch_duplicate_with_keys(hipStream_t st, int P, const float2* means2D, co
 			   L, means2D, depths, offsets, radii, gx, gy, keys, vals, perm);
 }
 
-// ---- depth presort of the Gaussians (mode 0)
-// rocPRIM switches to a merge sort (20 small launches, 0.15 ms) at <= 1M keys; onesweep (histogram +
-// 4 passes) is 3x faster here, so the merge-sort limit is set to 0.
-using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-						   rocprim::default_config, 0>;
 __global__ __launch_bounds__(256) void gather_counts_kernel(int P, const uint32_t* __restrict__ perm,
 							     const uint32_t* __restrict__ tiles_touched,
 							     uint32_t* __restrict__ counts_sorted)
@@ -109,6 +120,7 @@ void launch_gather_counts(hipStream_t st, int P, const uint32_t* perm, const uin
 			   tiles_touched, counts_sorted);
 }
 
+#ifdef SGS_WITH_EXPERIMENTS
 size_t sort_temp_bytes(size_t L, int begin_bit, int end_bit)
 {
 	size_t bytes = 0;
@@ -126,6 +138,7 @@ hipError_t launch_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, uint
 	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, L,
 					 (unsigned)begin_bit, (unsigned)end_bit, st);
 }
+#endif
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t L,
 							   const uint64_t* __restrict__ keys,
@@ -244,6 +257,7 @@ void launch_emit_tile_keys(hipStream_t st, int P, uint32_t L, const float2* mean
 			   means2D, offsets, radii, perm, gx, gy, keys32, vals);
 }
 
+#ifdef SGS_WITH_EXPERIMENTS
 size_t sort32_temp_bytes(size_t L, int end_bit)
 {
 	size_t bytes = 0;
@@ -260,6 +274,7 @@ hipError_t launch_sort32_pairs(hipStream_t st, void* temp, size_t temp_bytes, ui
 	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, L, 0u,
 					 (unsigned)end_bit, st);
 }
+#endif
 
 __global__ __launch_bounds__(256) void tile_ranges32_kernel(uint32_t L,
 							     const uint32_t* __restrict__ tiles,

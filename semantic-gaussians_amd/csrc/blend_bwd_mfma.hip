@@ -1221,6 +1221,12 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 static const int g_bwd_dbg = getenv("SGS_BWD_DBG") ? atoi(getenv("SGS_BWD_DBG")) : 0;   // ablations / phase stamps of the fused kernel (tools/bwd_phases.py)
 #endif
 
+int bwd_fused_x16_ownership()   // (blend_sweep2.hip: x16_kernel_owns_cu)
+{
+	static const int own = x16_kernel_owns_cu((const void*)&bwd_fused_kernel<false>, "bwd_fused_kernel<false>") ? 1 : 0;
+	return own;
+}
+
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a)
 {
 	return a.C >= 32 && (a.C & 31) == 0 && (((uintptr_t)a.colors | (uintptr_t)a.bg) & 15u) == 0 &&
@@ -1264,7 +1270,7 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 			}
 		} else
 #endif
-		if (fp32_products) {
+		if (fp32_products || !bwd_fused_x16_ownership()) {   // (fp32 products: backward mode 3; also what runs when the x16 form would not own its CU)
 			hipLaunchKernelGGL((bwd_fused_kernel<true>), grid, block, 0, st, SGS_FUSED_ARGS);
 		} else {
 			hipLaunchKernelGGL((bwd_fused_kernel<false>), grid, block, 0, st, SGS_FUSED_ARGS);

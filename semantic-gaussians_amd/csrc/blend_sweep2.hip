@@ -1683,11 +1683,41 @@ hipError_t launch_norm_plane_background(hipStream_t st, float* plane, size_t n, 
 	return hipGetLastError();
 }
 
+// ADVICE r5 / DESIGN.md 5.10: a kernel that issues the double-rate MFMA must own its compute unit -- 8 waves x 256 registers = the CU's whole
+// register file, more than half of its LDS.  The build checks the code object (csrc/check_code_object.py, run by `make`); this is the same
+// question put to the LOADED code object on the device it will run on, once per process: whatever the runtime reports for the kernel that is
+// about to be launched.  false -> the caller takes the x8 form (same bits, 10 % slower) and says so once on stderr.
+bool x16_kernel_owns_cu(const void* fn, const char* name)
+{
+	hipFuncAttributes at;
+	if (hipFuncGetAttributes(&at, fn) != hipSuccess) {
+		(void)hipGetLastError();
+		fprintf(stderr, "libsgs_hip: cannot read the attributes of %s: its x16 MFMA form is not used\n", name);
+		return false;
+	}
+	const bool ok = at.numRegs == 256 && at.maxThreadsPerBlock == 512 && at.sharedSizeBytes > 80u * 1024u && at.localSizeBytes == 0;
+	if (!ok)
+		fprintf(stderr, "libsgs_hip: %s does not own its compute unit (registers %d, threads %d, LDS %zu B, scratch %zu B; needs 256 / 512 / > 80 KB / 0): "
+				"its x16 MFMA form is not used (DESIGN.md 5.10)\n", name, at.numRegs, at.maxThreadsPerBlock, (size_t)at.sharedSizeBytes, (size_t)at.localSizeBytes);
+	return ok;
+}
+
+int sweep3_x16_ownership()   // 1: both x16 ping-pong sweeps own their CU; 0: they do not (the x8 form runs instead)
+{
+	static const int own = (x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1, false, true>, "blend_accum_sweep3_kernel<0, 1, false, true>") &&
+				x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1>, "blend_accum_sweep3_kernel<0, 1>")) ? 1 : 0;
+	return own;
+}
+
 hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
 			       const uint32_t* order, int dealt, int tune, int form)
 {
+	if (tune == 1 && !sweep3_x16_ownership()) {   // (said once on stderr; sgs_x16_cu_ownership() reports it)
+		tune = 0;   // the same products on v_mfma_f32_32x32x8_bf16: bit-identical maps
+		if (form == 2) form = 0;   // (the product library's x8 sweep is the lock-step form)
+	}
 	const bool coop = form == 1;   // (form: 0 = lock step, 1 = fp32 hand-over, 2 = free-running halves)
 #define S3_LAUNCH(D_)                                                                                \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \

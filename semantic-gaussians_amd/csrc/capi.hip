@@ -59,6 +59,11 @@ struct StreamCtx {
 	hipEvent_t count_ev = nullptr;
 	bool count_pending = false;
 	bool any_forward = false;   // a forward has been issued on this (device, stream)
+	// sgs_stream_set_front: the forward's front end (preprocess -> depth sort -> span partitions) is enqueued on `front` (a stream confined to a
+	// small compute-unit partition), the blend on the context's own stream; ev_in orders the front end behind the stream's earlier work (the
+	// previous frame's blend reads the buffers the front end overwrites), ev_front the blend behind the front end
+	hipStream_t front = nullptr;
+	hipEvent_t ev_in = nullptr, ev_front = nullptr;
 	int last_num_rendered = 0;
 	uint64_t stat[SGS_STAT_COUNT];
 	StreamCtx()
@@ -75,6 +80,8 @@ struct StreamCtx {
 		if (count_ev) (void)hipEventDestroy(count_ev);
 		if (usage_ev) (void)hipEventDestroy(usage_ev);
 		if (bwd_ev) (void)hipEventDestroy(bwd_ev);
+		if (ev_in) (void)hipEventDestroy(ev_in);
+		if (ev_front) (void)hipEventDestroy(ev_front);
 	}
 	int option(int which) const { return opt[which] >= 0 ? opt[which] : g_default_opt[which].load(); }
 	// pinned word pair + event, created on first use (under `mu`)
@@ -319,6 +326,7 @@ struct StageTimer {
 	{
 		if (mode && es.n < 8) (void)hipEventRecord(es.ev[es.n++], st);
 	}
+	void on(hipStream_t s) { st = s; }   // (a frame split over two streams: every mark goes to the stream its stage runs on)
 	static void resolve(EventSet& s, float* ms)
 	{
 		(void)hipEventSynchronize(s.ev[s.n - 1]);
@@ -389,7 +397,7 @@ static const bool g_sync_every_stage = [] { const char* e = getenv("SGS_DEBUG_SY
 #define SGS_CHECK_STAGE(what)                                                             \
 	do {                                                                              \
 		hipError_t e_ = hipGetLastError();                                        \
-		if (e_ == hipSuccess && debug && g_sync_every_stage) e_ = hipStreamSynchronize(st); \
+		if (e_ == hipSuccess && debug && g_sync_every_stage) e_ = hipStreamSynchronize(cur_st); \
 		if (e_ != hipSuccess) return fail_hip(e_, what);                          \
 	} while (0)
 
@@ -496,9 +504,57 @@ int sgs_stream_release(void* stream)
 	// memory) goes away
 	std::lock_guard<std::mutex> lk(c->mu);
 	(void)hipStreamSynchronize((hipStream_t)stream);
+	if (c->front) (void)hipStreamSynchronize(c->front);   // (a deferred count record is written from the front stream)
 	(void)hipGetLastError();
 	return 1;
 }
+
+// ---- compute-unit partitions (round 6; DESIGN.md 7.0: a 256-register, 8-wave sweep workgroup can only start on a completely EMPTY compute
+// unit, so the short latency-bound kernels of other views' front ends, resident on all 256 CUs, hold it off chip-wide)
+int sgs_device_cu_count(void)
+{
+	int dev = 0, n = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(SGS_EHIP, "cannot read the device's compute-unit count");
+	}
+	return n;
+}
+
+int sgs_stream_create_cu_range(int cu_first, int cu_count, void** stream_out)
+{
+	if (!stream_out) return fail(SGS_EINVAL, "null argument");
+	*stream_out = nullptr;
+	const int ncu = sgs_device_cu_count();
+	if (ncu < 0) return ncu;
+	if (cu_first < 0 || cu_count <= 0 || cu_first + cu_count > ncu) return fail(SGS_EINVAL, "compute-unit range outside the device");
+	std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+	for (int b = cu_first; b < cu_first + cu_count; b++) mask[(size_t)b >> 5] |= 1u << (b & 31);
+	hipStream_t s = nullptr;
+	const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+	if (e != hipSuccess) return fail_hip(e, "hipExtStreamCreateWithCUMask");
+	*stream_out = (void*)s;
+	return 0;
+}
+
+int sgs_stream_destroy(void* stream)
+{
+	if (!stream) return fail(SGS_EINVAL, "the null stream cannot be destroyed");
+	(void)sgs_stream_release(stream);   // (drains it and frees its context, if any)
+	const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+	if (e != hipSuccess) return fail_hip(e, "hipStreamDestroy");
+	return 0;
+}
+
+int sgs_stream_set_front(void* stream, void* front_stream)
+{
+	const std::shared_ptr<StreamCtx> c = ctx_of(stream);
+	std::lock_guard<std::mutex> lk(c->mu);
+	c->front = (front_stream == stream) ? nullptr : (hipStream_t)front_stream;
+	return 0;
+}
+
+int sgs_x16_cu_ownership(void) { return (sgs::sweep3_x16_ownership() ? 1 : 0) | (sgs::bwd_fused_x16_ownership() ? 2 : 0); }
 
 int sgs_get_stage_ms(float* ms7)
 {
@@ -595,7 +651,18 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	cx->any_forward = true;
 	if (norm_plane && (num_channels % 128 != 0 || out_depth))
 		return fail(SGS_EINVAL, "SGS_OPT_NORM_PLANE needs a multiple of 128 channels and no depth plane");
-	StageTimer tm(cx->option(SGS_OPT_STAGE_TIMING), st);
+	// Two-stream frame (sgs_stream_set_front): everything up to and including the span partitions goes to `fs`, the blend stays on `st`.
+	hipStream_t fs = st;
+	if (cx->front && cx->front != st) {
+		if (!cx->ev_in && hipEventCreateWithFlags(&cx->ev_in, hipEventDisableTiming) != hipSuccess) cx->ev_in = nullptr;
+		if (!cx->ev_front && hipEventCreateWithFlags(&cx->ev_front, hipEventDisableTiming) != hipSuccess) cx->ev_front = nullptr;
+		if (cx->ev_in && cx->ev_front && hipEventRecord(cx->ev_in, st) == hipSuccess && hipStreamWaitEvent(cx->front, cx->ev_in, 0) == hipSuccess)
+			fs = cx->front;
+		else
+			(void)hipGetLastError();   // (no events: the frame runs on one stream, as without a front stream)
+	}
+	StageTimer tm(cx->option(SGS_OPT_STAGE_TIMING), fs);
+	hipStream_t cur_st = fs;   // (SGS_CHECK_STAGE: the stream the stage just enqueued ran on)
 
 	const GeomLayout gl = geom_layout(P);
 	char* gchunk = (char*)geometry_buffer(geometry_user, gl.total);
@@ -621,16 +688,22 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// binning mode 0: sort the P Gaussians by depth bits and emit instances in that order, so
 	// that the big instance sort only has to be stable on the tile bits (binning.hip)
 	const int bmode = cx->option(SGS_OPT_BINNING_MODE);
+#ifndef SGS_WITH_EXPERIMENTS   // (modes 1 / 2 run on rocPRIM's scan and radix sort: make EXPERIMENTS=1, csrc/binning.hip)
+	if (bmode == 1 || bmode == 2)
+		return fail(SGS_EINVAL, "binning modes 1 / 2 (the reference's order of operations / round 1's tile-key sort, on the library scan and sort) are not in this build (make EXPERIMENTS=1)");
+	if (gx > 2048 || gy > 2048)
+		return fail(SGS_EINVAL, "an image axis longer than 32768 pixels needs the tile-key sort of binning mode 2, which is not in this build (make EXPERIMENTS=1)");
+#endif
 	const bool presort = bmode == 0 || bmode == 2 || bmode == 3;   // (3: round 2's A/B mode with the library sort -- removed, an alias of 0)
 	const bool own_sort = presort;   // depth_sort.hip
 	// one clear: the trap flag and, right behind it, the depth sort's count matrices (filled by preprocess)
-	hipError_t e = hipMemsetAsync(trap_flag, 0, own_sort ? 128 + gl.ds_lay.counts_bytes : 4, st);
+	hipError_t e = hipMemsetAsync(trap_flag, 0, own_sort ? 128 + gl.ds_lay.counts_bytes : 4, fs);
 	if (e != hipSuccess) return fail_hip(e, "memset");
 	uint32_t* ds_cnt0 = own_sort ? (uint32_t*)(gchunk + gl.ds + gl.ds_lay.counts) : nullptr;
 	uint32_t* ds_gcnt0 = own_sort ? ds_cnt0 + (size_t)gl.ds_lay.tiles * 256 : nullptr;
 
 	tm.mark();
-	sgs::launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities,
+	sgs::launch_preprocess_fwd(fs, P, D, M, means3D, scales, scale_modifier, rotations, opacities,
 				   shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos,
 				   width, height, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy,
 				   prefiltered, num_channels, radii, means2D, depths, cov3D, rgb, clamped,
@@ -646,18 +719,18 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.totals64),
 					   (uint32_t*)(gchunk + gl.stage_a_tab), 0u, 0u};
 		sgs::row_binning_stage_a_counts(P, &span.stage_a_chunks, &span.stage_a_groups);
-		e = sgs::launch_depth_sort(st, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm, rows ? &span : nullptr);
+		e = sgs::launch_depth_sort(fs, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm, rows ? &span : nullptr);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
 		if (rows) {
 			// the sort's last pass has written the span counts and their total (behind the trap flag) -- no scan
 		} else {
 			uint32_t* counts_sorted = (uint32_t*)(gchunk + gl.counts_sorted);
-			sgs::launch_gather_counts(st, P, perm, tiles_touched, counts_sorted);
-			e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, counts_sorted,
+			sgs::launch_gather_counts(fs, P, perm, tiles_touched, counts_sorted);
+			e = sgs::launch_inclusive_scan(fs, gchunk + gl.scan_temp, gl.scan_temp_bytes, counts_sorted,
 						       point_offsets, P);
 		}
 	} else {
-		e = sgs::launch_inclusive_scan(st, gchunk + gl.scan_temp, gl.scan_temp_bytes, tiles_touched,
+		e = sgs::launch_inclusive_scan(fs, gchunk + gl.scan_temp, gl.scan_temp_bytes, tiles_touched,
 					       point_offsets, P);
 	}
 	if (e != hipSuccess) return fail_hip(e, "inclusive scan");
@@ -688,9 +761,9 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		L = defer_opt == 2 ? 4096u : cx->L_hint;   // (2: tests -- a capacity no real frame fits, exercises the abort)
 		Rrows = defer_opt == 2 ? 4096u : cx->R_hint;
 		uint32_t* rec = (uint32_t*)(gchunk + gl.count_rec);
-		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, st, totals64, trap_flag, L, Rrows, rec, cx->count_host);
+		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, fs, totals64, trap_flag, L, Rrows, rec, cx->count_host);
 		e = hipGetLastError();
-		if (e == hipSuccess) e = hipEventRecord(cx->count_ev, st);
+		if (e == hipSuccess) e = hipEventRecord(cx->count_ev, fs);
 		if (e != hipSuccess) return fail_hip(e, "deferred count record");
 		cx->count_pending = true;
 		cx->stat[SGS_STAT_DEFERRED_FORWARDS]++;
@@ -700,15 +773,15 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		uint64_t host_rl = 0;   // mode 0: row instances << 32 | num_rendered
 		if (own_sort && rows) {   // the trap flag and the totals share one 128-byte block: ONE copy (each is a kernel)
 			uint64_t blk[9];
-			e = hipMemcpyAsync(blk, trap_flag, sizeof(blk), hipMemcpyDeviceToHost, st);
-			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			e = hipMemcpyAsync(blk, trap_flag, sizeof(blk), hipMemcpyDeviceToHost, fs);
+			if (e == hipSuccess) e = hipStreamSynchronize(fs);
 			host_vals[1] = (int)(uint32_t)blk[0];
 			host_rl = blk[8];
 		} else {
-			if (rows) e = hipMemcpyAsync(&host_rl, totals64, 8, hipMemcpyDeviceToHost, st);
-			else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st);
-			if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, st);
-			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			if (rows) e = hipMemcpyAsync(&host_rl, totals64, 8, hipMemcpyDeviceToHost, fs);
+			else e = hipMemcpyAsync(&host_vals[0], point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, fs);
+			if (e == hipSuccess) e = hipMemcpyAsync(&host_vals[1], trap_flag, 4, hipMemcpyDeviceToHost, fs);
+			if (e == hipSuccess) e = hipStreamSynchronize(fs);
 		}
 		if (e != hipSuccess) return fail_hip(e, "num_rendered read-back");
 		if (host_vals[1] != 0)
@@ -804,7 +877,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		// mode 0: two span partitions, no instance sort (binning_rows.hip).  The 8-B-per-instance
 		// keys_unsorted area holds the major instances (8 B each, R <= L).
 		tm.mark();   // (no separate emission stage)
-		e = sgs::launch_row_binning(st, P, Rrows, gx, gy, (const uint4*)(gchunk + gl.rrec), (uint2*)keys_u,
+		e = sgs::launch_row_binning(fs, P, Rrows, gx, gy, (const uint4*)(gchunk + gl.rrec), (uint2*)keys_u,
 					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
 					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list,
 					    abort_word, use_split ? (uint32_t*)(bchunk + bl.arena + bl.arena_lay.counter) : nullptr,
@@ -819,36 +892,44 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		// 8-B-per-instance "keys_unsorted" area holds the unsorted and the sorted tile ids.
 		uint32_t* tiles_u = (uint32_t*)keys_u;
 		uint32_t* tiles_s = tiles_u + L;
-		sgs::launch_emit_tile_keys(st, P, L, means2D, point_offsets, radii, perm, gx, gy, tiles_u,
+		sgs::launch_emit_tile_keys(fs, P, L, means2D, point_offsets, radii, perm, gx, gy, tiles_u,
 					   vals_u);
 		SGS_CHECK_STAGE("emit tile keys");
 		tm.mark();
 		if (L > 0) {
-			e = sgs::launch_sort32_pairs(st, bchunk + bl.sort_temp, bl.sort_temp_bytes, tiles_u,
+			e = sgs::launch_sort32_pairs(fs, bchunk + bl.sort_temp, bl.sort_temp_bytes, tiles_u,
 						     tiles_s, vals_u, point_list, L, sort_bits - 32);
 			if (e != hipSuccess) return fail_hip(e, "radix sort");
 		}
 		SGS_CHECK_STAGE("radix sort");
 		tm.mark();
-		sgs::launch_tile_ranges32(st, L, tiles_s, ranges, ntiles);
+		sgs::launch_tile_ranges32(fs, L, tiles_s, ranges, ntiles);
 		SGS_CHECK_STAGE("identifyTileRanges");
 		tm.mark();
 	} else {
-		sgs::launch_duplicate_with_keys(st, P, means2D, depths, point_offsets, radii, gx, gy, keys_u,
+		sgs::launch_duplicate_with_keys(fs, P, means2D, depths, point_offsets, radii, gx, gy, keys_u,
 						vals_u, L, nullptr);
 		SGS_CHECK_STAGE("duplicateWithKeys");
 		tm.mark();
 		if (L > 0) {
-			e = sgs::launch_sort_pairs(st, bchunk + bl.sort_temp, bl.sort_temp_bytes, keys_u, keys_s,
+			e = sgs::launch_sort_pairs(fs, bchunk + bl.sort_temp, bl.sort_temp_bytes, keys_u, keys_s,
 						   vals_u, point_list, L, 0, sort_bits);
 			if (e != hipSuccess) return fail_hip(e, "radix sort");
 		}
 		SGS_CHECK_STAGE("radix sort");
 		tm.mark();
-		sgs::launch_tile_ranges(st, L, keys_s, ranges, ntiles);
+		sgs::launch_tile_ranges(fs, L, keys_s, ranges, ntiles);
 		SGS_CHECK_STAGE("identifyTileRanges");
 		tm.mark();
 	}
+
+	if (fs != st) {   // the blend waits for the lists; from here on every launch and mark is on the context's own stream
+		e = hipEventRecord(cx->ev_front, fs);
+		if (e == hipSuccess) e = hipStreamWaitEvent(st, cx->ev_front, 0);
+		if (e != hipSuccess) return fail_hip(e, "front-end hand-over");
+		tm.on(st);
+	}
+	cur_st = st;
 
 	sgs::BlendFwdArgs a;
 	a.ranges = ranges;
@@ -987,6 +1068,7 @@ int sgs_rasterize_backward(int P, int D, int M, int R, const float* background, 
 			   float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
 {
 	hipStream_t st = (hipStream_t)stream;
+	const hipStream_t cur_st = st;
 	if (P < 0 || R < 0 || width <= 0 || height <= 0 || num_channels <= 0)
 		return fail(SGS_EINVAL, "bad sizes");
 	if (P == 0) return 0;

@@ -194,6 +194,10 @@ hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const ui
 // forward's work list + a scalar recurrence (see the file header).  `arena` is scratch of
 // split_arena_bytes(capacity, ...) bytes.
 bool blend_backward_mfma_eligible(const BlendBwdArgs& a);
+// the x16-MFMA kernels against the loaded code object (blend_sweep2.hip / blend_bwd_mfma.hip): 1 = they own their compute unit
+bool x16_kernel_owns_cu(const void* fn, const char* name);
+int sweep3_x16_ownership();
+int bwd_fused_x16_ownership();
 // fp32_products: the two channel products on v_mfma_f32_32x32x2_f32 (exact fp32 products) instead of split bf16
 // clear_dcolor: a.dL_dcolors (P x C floats) is zero-filled by the first kernel instead of by the caller
 // two_kernels: rounds 2-4's form (bwd_dcolor + bwd_dot, each streaming the gradient) instead of the fused kernel

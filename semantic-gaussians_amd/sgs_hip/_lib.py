@@ -40,6 +40,7 @@ EXPORTS = (
     "sgs_set_stage_timing", "sgs_get_stage_ms", "sgs_set_binning_mode", "sgs_set_backward_mode", "sgs_build_flags", "sgs_fusion_compute_mapping", "sgs_fusion_accumulate", "sgs_composite_over",
     "sgs_stream_set_option", "sgs_stream_get_stat", "sgs_stream_release", "sgs_debug_set_sweep_trace",
     "sgs_forward_result", "sgs_debug_depth_sort",
+    "sgs_device_cu_count", "sgs_stream_create_cu_range", "sgs_stream_destroy", "sgs_stream_set_front", "sgs_x16_cu_ownership",
 )
 
 # sgs_stream_set_option / sgs_stream_get_stat selectors (include/sgs_raster.h)
@@ -134,6 +135,16 @@ def load():
     lib.sgs_stream_get_stat.argtypes = [p, i, C.POINTER(C.c_uint64)]
     lib.sgs_stream_release.restype = i
     lib.sgs_stream_release.argtypes = [p]
+    lib.sgs_device_cu_count.restype = i
+    lib.sgs_device_cu_count.argtypes = []
+    lib.sgs_stream_create_cu_range.restype = i
+    lib.sgs_stream_create_cu_range.argtypes = [i, i, C.POINTER(p)]
+    lib.sgs_stream_destroy.restype = i
+    lib.sgs_stream_destroy.argtypes = [p]
+    lib.sgs_stream_set_front.restype = i
+    lib.sgs_stream_set_front.argtypes = [p, p]
+    lib.sgs_x16_cu_ownership.restype = i
+    lib.sgs_x16_cu_ownership.argtypes = []
     _lib = lib
     return lib
 

@@ -375,9 +375,22 @@ def render_partial(means3D, colors, opacity, scales, rotations, viewmatrix, proj
     Cn = colors.size(1)
     bg = torch.zeros(Cn, dtype=torch.float32, device=means3D.device)
     e = torch.Tensor([])
-    _, color, radii, _, _, img, _ = rasterize_forward(
-        bg, means3D, colors, opacity, scales, rotations, scale_modifier, e, viewmatrix, projmatrix, tan_fovx,
-        tan_fovy, image_height, image_width, e, 0, campos, False, False, Cn, False, pool=pool, out_bands=bands if Cn % 128 == 0 else 0)
+    bands = bands if (Cn % 128 == 0 and bands > 1) else 0
+    out = None
+    if bands:
+        try:
+            out = rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier, e, viewmatrix, projmatrix, tan_fovx,
+                                    tan_fovy, image_height, image_width, e, 0, campos, False, False, Cn, False, pool=pool, out_bands=bands)
+        except RuntimeError as ex:   # the active blend variant has no band-major output (exact / two-term sweeps, SGS_DEFAULT_SWEEP=14):
+            if "SGS_OPT_OUT_BANDS" not in str(ex):   # row-major map, cut into the same bands (one staging copy each, as before round 5)
+                raise
+    if out is None:
+        out = rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier, e, viewmatrix, projmatrix, tan_fovx,
+                                tan_fovy, image_height, image_width, e, 0, campos, False, False, Cn, False, pool=pool)
+        if bands:
+            from .dist import band_rows
+            out = (out[0], [out[1][:, lo:hi].contiguous() for lo, hi in (band_rows(image_height, b, bands) for b in range(bands))]) + tuple(out[2:])
+    _, color, radii, _, _, img, _ = out
     if means3D.size(0) == 0:
         T = torch.ones(image_height, image_width, dtype=torch.float32, device=means3D.device)
     else:
@@ -520,6 +533,47 @@ def release_stream(device=None):
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     with torch.cuda.device(device):
         return int(_lib.load().sgs_stream_release(_stream_ptr(device)))
+
+
+def x16_cu_ownership():
+    """Bit 0: the forward's x16 ping-pong sweeps own their compute unit on the current device (they run), bit 1: the fused backward does
+    (include/sgs_raster.h sgs_x16_cu_ownership).  3 on a healthy build; anything else means the x8 / fp32-product forms run instead."""
+    return int(_lib.load().sgs_x16_cu_ownership())
+
+
+class PartitionedStreams:
+    """`slots` view slots over a chip cut in two compute-unit partitions (include/sgs_raster.h "compute-unit partitions"): slot i owns a
+    BLEND stream confined to CUs [front_cus, n) and a FRONT stream confined to CUs [0, front_cus); forwards issued on streams[i] run their
+    front end (preprocess -> depth sort -> span partitions) on the small partition and their blend on the large one, so the latency-bound
+    front-end kernels of one view never hold the 8-wave sweep workgroups of another off their compute units.  streams[i] is a
+    torch.cuda.ExternalStream: use it with torch.cuda.stream(...) like any other.  close() destroys the HIP streams."""
+
+    def __init__(self, device, front_cus, slots):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.streams, self.front, self._raw = [], [], []
+        with torch.cuda.device(self.device):
+            n = _lib.check(lib.sgs_device_cu_count(), "cu count")
+            if not 0 < front_cus < n:
+                raise ValueError(f"front_cus must be in (0, {n})")
+            self.cu_count, self.front_cus = n, int(front_cus)
+            for _ in range(int(slots)):
+                b, f = C.c_void_p(), C.c_void_p()
+                _lib.check(lib.sgs_stream_create_cu_range(self.front_cus, n - self.front_cus, C.byref(b)), "blend stream")
+                _lib.check(lib.sgs_stream_create_cu_range(0, self.front_cus, C.byref(f)), "front stream")
+                _lib.check(lib.sgs_stream_set_front(b, f), "set front")
+                self._raw.append((b, f))
+                self.streams.append(torch.cuda.ExternalStream(b.value, device=self.device))
+                self.front.append(torch.cuda.ExternalStream(f.value, device=self.device))
+
+    def close(self):
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            for b, f in self._raw:
+                lib.sgs_stream_destroy(b)
+                lib.sgs_stream_destroy(f)
+        self._raw, self.streams, self.front = [], [], []
 
 
 def set_blend_exact(exact):

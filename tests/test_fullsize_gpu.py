@@ -8,6 +8,7 @@ sum_k w_k = 1 - T_final, linearity in the features), plus the oracle itself on e
 import numpy as np
 import pytest
 import torch
+from helpers import has_experiments
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +41,8 @@ def test_cfg3_lists_sorted_consistent_and_identical_across_binning_modes(cfg3, o
     feats = s.features[:, :4].contiguous()   # the lists do not depend on the channels
     gx, gy = (W + 15) // 16, (H + 15) // 16
     got = {}
-    for mode in (0, 1, 2):
+    modes = (0, 1, 2) if has_experiments() else (0,)   # (1 / 2: the reference-order 45-bit sort / the 32-bit tile sort on rocPRIM, make EXPERIMENTS=1)
+    for mode in modes:
         raster.set_binning_mode(mode)
         try:
             n, color, radii, geom, binn, img, _ = _render(s, c, 4, W, H, feats=feats)
@@ -52,7 +54,7 @@ def test_cfg3_lists_sorted_consistent_and_identical_across_binning_modes(cfg3, o
         got[mode] = dict(n=n, keys=b["keys_sorted"].clone(), plist=b["point_list"].clone(), ranges=iv["ranges"].clone(),
                          radii=radii.clone(), color=color.clone(), n_contrib=iv["n_contrib"].clone())
     a = got[0]
-    for mode in (1, 2):   # the span-partition lists == the reference-order 45-bit sort == the 32-bit tile sort
+    for mode in modes[1:]:   # the span-partition lists == the reference-order 45-bit sort == the 32-bit tile sort
         o = got[mode]
         assert o["n"] == a["n"] and torch.equal(o["plist"], a["plist"]) and torch.equal(o["ranges"], a["ranges"])
         assert torch.equal(o["keys"], a["keys"]) and torch.equal(o["color"], a["color"])

@@ -4,7 +4,7 @@ handful of Gaussians.  Every case checks binning modes 0 and 2 and the exact ari
 import numpy as np
 import pytest
 
-from helpers import small_scene
+from helpers import has_experiments, small_scene
 from test_parity_gpu import _check_forward
 
 pytestmark = pytest.mark.gpu
@@ -22,13 +22,13 @@ def test_random_shapes(orc, i):
     scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=float(max(W, H)) * 0.9, seed=100 + i)
     if i % 3 == 0:
         scene = scene._replace(scales=scene.scales * 4.0, opacities=scene.opacities * 0.3)
-    for mode in (0, 2):
+    for mode in (0, 2) if has_experiments() else (0,):   # (mode 2 = round 1's tile-key sort on the library radix sort: make EXPERIMENTS=1)
         _check_forward(orc, scene, cam, binning_mode=mode)
     _check_forward(orc, scene, cam, variant=15)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H", [16400, 66000])
+@pytest.mark.parametrize("H", [16400, 32768])   # (32768 = 2048 tile rows: the longest axis the span partitions take)
 def test_sweep_plan_many_segments(H):
     """The sweep's workgroup order (sweep_plan_kernel): more than 1024 segments take the bitonic sort, more than 4096
     the unsorted deal -- the feature map must be the row-major order's, bit for bit (variant 0x11004: the default kernels, row-major)."""
