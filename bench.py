@@ -386,9 +386,11 @@ def main():
     ap.add_argument("--extra-configs", action="store_true",
                     help="also time BASELINE configs 4 (views sharded) and 5 (Gaussians sharded, RCCL exchange); on by default "
                          "when --gpus > 1")
-    ap.add_argument("--front-cus", type=int, default=int(os.environ.get("SGS_BENCH_FRONT_CUS", "32")),
+    ap.add_argument("--front-cus", type=int, default=int(os.environ.get("SGS_BENCH_FRONT_CUS", "0")),
                     help="compute units set aside for the views' front ends in the headline (raster.PartitionedStreams: every view slot gets a "
-                         "blend stream on the other CUs and a front stream on these); 0 = ordinary streams, every kernel anywhere (round 5's headline)")
+                         "blend stream on the other CUs and a front stream on these); 0 (default) = ordinary streams, every kernel anywhere.  Measured "
+                         "(profiles/r06_cu_partition.txt): the sweep slows in proportion to the CUs it loses -- 1.02 ms on 256, 1.17 on 224, 1.33 on 208 -- "
+                         "which costs more than the front end's interference it removes (465 vs 477 Gpx.ch/s at 32 front CUs, four views in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-arithmetic / backward legs")
     args = ap.parse_args()

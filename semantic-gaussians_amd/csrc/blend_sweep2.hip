@@ -1748,6 +1748,20 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 		return hipGetLastError();
 	}
 #undef S3_LAUNCH_MM
+#ifdef SGS_WITH_EXPERIMENTS   // round 6: the ablations / phase clocks of the DEFAULT form (free-running halves on x16), for profiles/r06_sweep_phases.txt
+	if (tune == 1 && form == 2 && (dbg == 1 || dbg == 2 || dbg == 3 || dbg == 4)) {
+#define S3_LAUNCH_FX(D_)                                                                             \
+	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
+		if (dbg == 1) S3_LAUNCH_FX(1);
+		else if (dbg == 2) S3_LAUNCH_FX(2);
+		else if (dbg == 3) S3_LAUNCH_FX(3);
+		else S3_LAUNCH_FX(4);
+#undef S3_LAUNCH_FX
+		return hipGetLastError();
+	}
+#endif
 	if (tune != 0) return hipErrorInvalidValue;
 #ifndef SGS_WITH_EXPERIMENTS   // the product library holds ONE ping-pong sweep; the forms below are make EXPERIMENTS=1
 	(void)coop;

@@ -90,6 +90,8 @@ def test_partitioned_forward_feeds_the_backward(orc):
         torch.cuda.synchronize()
         assert torch.equal(col0, col1)
         for a, b in zip(g0, g1):   # (atomics: the order of the sums is not fixed)
+            if a.numel() == 0:
+                continue
             scale = float(a.abs().max()) + 1e-30
             assert float((a - b).abs().max()) <= 1e-5 * scale
     finally:
