@@ -16,14 +16,17 @@
 //     LDS counter; the tile is reordered through LDS so that the scatter writes runs of consecutive addresses.
 // Deterministic (atomics only add counts), stable, no inter-workgroup waiting.
 #include "sgs_kernels.h"
+#include <cstdlib>
 
 namespace sgs {
 
 namespace {
 
-constexpr int DS_ITEMS = DS_TILE / 256;   // keys per thread
+constexpr int DS_ITEMS = DS_TILE / 256;   // keys per thread of the counting kernels (256 threads)
+constexpr int DS_WAVES_DEFAULT = 16;
 
-// exclusive scan of one value per thread over the 256 threads of the workgroup; *total = sum
+// exclusive scan of one value per thread over the FIRST 256 threads of the workgroup (one per digit); *total = sum.  Every thread of the
+// workgroup calls it (two barriers); the result is meaningless for threads >= 256.
 __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t* s_tmp, uint32_t* total)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -33,7 +36,7 @@ __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t* s_tmp, uint
 		const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
 		if (lane >= o) incl += u;
 	}
-	if (lane == 63) s_tmp[wave] = incl;
+	if (lane == 63 && wave < 4) s_tmp[wave] = incl;
 	__syncthreads();
 	uint32_t base = 0, tot = 0;
 #pragma unroll
@@ -53,29 +56,32 @@ __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t* s_tmp, uint
 // only the values (= perm).
 // SPAN (last pass, binning mode 0): the rank's record and span counts for binning_rows.hip are written here, where
 // (rank, Gaussian) is known, instead of by a kernel of their own (span_counts_kernel).
-template <int PASS, bool SPAN>
-__global__ __launch_bounds__(256) void depth_sort_pass_kernel(
+// NW = waves per workgroup (round 6).  A tile is 4096 keys whatever NW is; with 4 waves (rounds 2-5) a compute unit holds ONE workgroup of four
+// waves that walks through five barrier-separated phases of dependent latencies -- 17 us per pass for 8 MB of traffic.  16 waves x 4 keys per
+// lane shorten every phase (4 ballot rounds instead of 16, a quarter of the LDS reorder and of the scatter per wave) at the price of a 16-row wave prefix.
+template <int PASS, bool SPAN, int NW>
+__global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 	int P, int groups, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
 	uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ cnt,
 	const uint32_t* __restrict__ gcnt, DepthSortSpanOut so)
 {
 	constexpr int SHIFT = 8 * PASS;
+	constexpr int NT = 64 * NW, ITEMS = DS_TILE / NT;
 	const int k = blockIdx.x;
 	const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-	__shared__ uint32_t s_hist[4][256];   // per wave: keys per digit, then the wave's start inside the tile's digit run
+	__shared__ uint32_t s_hist[NW][256];  // per wave: keys per digit, then the wave's start inside the tile's digit run
 	__shared__ uint32_t s_base[256];      // output position of the tile's first key of each digit
 	__shared__ uint32_t s_excl[256];      // start of each digit's run inside the reordered tile
 	__shared__ uint32_t s_tmp[4];
 	__shared__ uint32_t s_keys[DS_TILE], s_vals[DS_TILE];
 
-#pragma unroll
-	for (int w = 0; w < 4; w++) s_hist[w][t] = 0u;
+	for (int q = t; q < NW * 256; q += NT) (&s_hist[0][0])[q] = 0u;
 
-	// ---- this tile's keys: element (wave, i, lane) = index  k * 4096 + wave * 1024 + i * 64 + lane
-	const uint32_t first = (uint32_t)k * DS_TILE + (uint32_t)wave * (DS_TILE / 4) + (uint32_t)lane;
-	uint32_t key[DS_ITEMS], val[DS_ITEMS];
+	// ---- this tile's keys: element (wave, i, lane) = index  k * 4096 + wave * (4096 / NW) + i * 64 + lane
+	const uint32_t first = (uint32_t)k * DS_TILE + (uint32_t)wave * (DS_TILE / NW) + (uint32_t)lane;
+	uint32_t key[ITEMS], val[ITEMS];
 #pragma unroll
-	for (int i = 0; i < DS_ITEMS; i++) {
+	for (int i = 0; i < ITEMS; i++) {
 		const uint32_t idx = first + 64u * i;
 		const bool ok = idx < (uint32_t)P;
 		key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
@@ -87,22 +93,24 @@ __global__ __launch_bounds__(256) void depth_sort_pass_kernel(
 	{
 		const int grp = k / DS_GRP;
 		uint32_t tot = 0, pre = 0;
-		for (int g = 0; g < groups; g++) {
-			const uint32_t c = gcnt[(size_t)g * 256 + t];
-			tot += c;
-			pre += g < grp ? c : 0u;
+		if (t < 256) {
+			for (int g = 0; g < groups; g++) {
+				const uint32_t c = gcnt[(size_t)g * 256 + t];
+				tot += c;
+				pre += g < grp ? c : 0u;
+			}
+			for (int kk = grp * DS_GRP; kk < k; kk++) pre += cnt[(size_t)kk * 256 + t];
 		}
-		for (int kk = grp * DS_GRP; kk < k; kk++) pre += cnt[(size_t)kk * 256 + t];
 		const uint32_t start = wg_scan256(tot, s_tmp, nullptr);
-		s_base[t] = start + pre;
+		if (t < 256) s_base[t] = start + pre;
 	}
 	__syncthreads();   // s_hist zeroed (wg_scan256 has barriers too; this one is for clarity)
 
 	// ---- rank of every key among the keys of its wave with the same digit (wave order = (i, lane))
-	uint32_t rank[DS_ITEMS];
+	uint32_t rank[ITEMS];
 	const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-	for (int i = 0; i < DS_ITEMS; i++) {
+	for (int i = 0; i < ITEMS; i++) {
 		const bool ok = first + 64u * i < (uint32_t)P;
 		const uint32_t d = (key[i] >> SHIFT) & 255u;
 		unsigned long long m = __ballot(ok);
@@ -126,18 +134,23 @@ __global__ __launch_bounds__(256) void depth_sort_pass_kernel(
 
 	// ---- per digit: the waves' starts inside the digit's run, the run's start inside the tile
 	{
-		const uint32_t h0 = s_hist[0][t], h1 = s_hist[1][t], h2 = s_hist[2][t], h3 = s_hist[3][t];
-		s_hist[0][t] = 0u;
-		s_hist[1][t] = h0;
-		s_hist[2][t] = h0 + h1;
-		s_hist[3][t] = h0 + h1 + h2;
-		s_excl[t] = wg_scan256(h0 + h1 + h2 + h3, s_tmp, nullptr);
+		uint32_t run = 0;
+		if (t < 256) {
+#pragma unroll
+			for (int w = 0; w < NW; w++) {
+				const uint32_t hv = s_hist[w][t];
+				s_hist[w][t] = run;
+				run += hv;
+			}
+		}
+		const uint32_t ex = wg_scan256(run, s_tmp, nullptr);
+		if (t < 256) s_excl[t] = ex;
 	}
 	__syncthreads();
 
 	// ---- reorder the tile in LDS
 #pragma unroll
-	for (int i = 0; i < DS_ITEMS; i++) {
+	for (int i = 0; i < ITEMS; i++) {
 		if (first + 64u * i < (uint32_t)P) {
 			const uint32_t d = (key[i] >> SHIFT) & 255u;
 			const uint32_t lp = s_excl[d] + s_hist[wave][d] + rank[i];
@@ -152,8 +165,8 @@ __global__ __launch_bounds__(256) void depth_sort_pass_kernel(
 										 : (uint32_t)DS_TILE;
 	unsigned long long csum = 0;   // (SPAN) this thread's share of sum(counts64) = major instances << 32 | instances
 #pragma unroll
-	for (int i = 0; i < DS_ITEMS; i++) {
-		const uint32_t j = (uint32_t)t + 256u * i;
+	for (int i = 0; i < ITEMS; i++) {
+		const uint32_t j = (uint32_t)t + (uint32_t)NT * i;
 		const bool ok = j < nvalid;
 		uint32_t kv = 0, pos = 0;
 		if (ok) {
@@ -199,10 +212,15 @@ __global__ __launch_bounds__(256) void depth_sort_pass_kernel(
 			const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)csum, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(csum >> 32), o);
 			csum += ((unsigned long long)hi << 32) | lo;
 		}
-		__shared__ unsigned long long s_sum[4];
+		__shared__ unsigned long long s_sum[NW];
 		if (lane == 0) s_sum[wave] = csum;
 		__syncthreads();
-		if (t == 0) atomicAdd(so.total, (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+		if (t == 0) {
+			unsigned long long tot = 0;
+#pragma unroll
+			for (int w = 0; w < NW; w++) tot += s_sum[w];
+			atomicAdd(so.total, tot);
+		}
 	}
 }
 
@@ -295,19 +313,23 @@ hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, 
 	uint32_t* vB = (uint32_t*)(scratch + lay.vals[1]);
 	const dim3 grid(lay.tiles), block(256);
 	const DepthSortSpanOut none{};
-	hipLaunchKernelGGL((depth_sort_pass_kernel<0, false>), grid, block, 0, st, P, lay.groups, depth_bits, (const uint32_t*)nullptr,
-			   kA, vA, cnt[0], gcnt[0], none);
+	// waves per workgroup of the passes: SGS_DS_WAVES = 4 (rounds 2-5) | 8 | 16 (read once); default in DS_WAVES_DEFAULT
+	static const int nw = [] { const char* e = getenv("SGS_DS_WAVES"); const int v = e ? atoi(e) : DS_WAVES_DEFAULT; return (v == 4 || v == 8 || v == 16) ? v : DS_WAVES_DEFAULT; }();
+#define DS_PASS(PASS_, SPAN_, KI_, VI_, KO_, VO_, C_, G_, SO_)                                                                        \
+	do {                                                                                                                               \
+		if (nw == 16) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_); \
+		else if (nw == 8) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 8>), grid, dim3(512), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_); \
+		else hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 4>), grid, dim3(256), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_); \
+	} while (0)
+	DS_PASS(0, false, depth_bits, (const uint32_t*)nullptr, kA, vA, cnt[0], gcnt[0], none);
 	hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1]);
-	hipLaunchKernelGGL((depth_sort_pass_kernel<1, false>), grid, block, 0, st, P, lay.groups, kA, vA, kB, vB, cnt[1], gcnt[1], none);
+	DS_PASS(1, false, kA, vA, kB, vB, cnt[1], gcnt[1], none);
 	hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2]);
-	hipLaunchKernelGGL((depth_sort_pass_kernel<2, false>), grid, block, 0, st, P, lay.groups, kB, vB, kA, vA, cnt[2], gcnt[2], none);
+	DS_PASS(2, false, kB, vB, kA, vA, cnt[2], gcnt[2], none);
 	hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3]);
-	if (span)
-		hipLaunchKernelGGL((depth_sort_pass_kernel<3, true>), grid, block, 0, st, P, lay.groups, kA, vA, (uint32_t*)nullptr,
-				   perm, cnt[3], gcnt[3], *span);
-	else
-		hipLaunchKernelGGL((depth_sort_pass_kernel<3, false>), grid, block, 0, st, P, lay.groups, kA, vA, (uint32_t*)nullptr,
-				   perm, cnt[3], gcnt[3], none);
+	if (span) DS_PASS(3, true, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], *span);
+	else DS_PASS(3, false, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], none);
+#undef DS_PASS
 	return hipGetLastError();
 }
 

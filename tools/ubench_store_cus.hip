@@ -37,6 +37,7 @@ __global__ __launch_bounds__(FAT ? 512 : 256) void store_kernel(float* __restric
 
 int main(int argc, char** argv)
 {
+	setvbuf(stdout, nullptr, _IONBF, 0);
 	float* out;
 	if (hipMalloc(&out, BYTES + (64 << 20)) != hipSuccess) return 1;
 	hipDeviceProp_t pr;
@@ -56,7 +57,7 @@ int main(int argc, char** argv)
 				std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
 				for (int b = ncu - n; b < ncu; b++) mask[b >> 5] |= 1u << (b & 31);
 				hipStream_t st;
-				if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) return 2;
+				if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { printf("stream creation failed\n"); return 2; }
 				const size_t per_wg = 128 * 1024 / 4 * (fat ? 2 : 1);   // floats: 256 KB per fat workgroup (a tile pair's share), 128 KB per thin one
 				const int nwg = (int)(BYTES / 4 / per_wg);
 				float best = 1e9f;
@@ -65,7 +66,8 @@ int main(int argc, char** argv)
 					if (fat) hipLaunchKernelGGL(store_kernel<true>, dim3(nwg), dim3(512), 128 * 1024, st, out, per_wg, gap);
 					else hipLaunchKernelGGL(store_kernel<false>, dim3(nwg), dim3(256), 0, st, out, per_wg, gap);
 					hipEventRecord(e1, st);
-					hipEventSynchronize(e1);
+					const hipError_t es = hipEventSynchronize(e1);
+					if (es != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(es)); return 3; }
 					float ms;
 					hipEventElapsedTime(&ms, e0, e1);
 					if (rep > 0 && ms < best) best = ms;
