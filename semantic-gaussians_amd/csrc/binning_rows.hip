@@ -420,6 +420,14 @@ __global__ __launch_bounds__(1024) void stage_a_lists_kernel(int nb, const uint3
 // lists needs every list's length.  span_scan_lists_fin_kernel is span_scan_lists_kernel whose LAST workgroup to finish (one device-scope
 // counter per stage in the frame's cleared 128-byte block; release / acquire fences around it) runs that scan with its 256 threads.
 
+// The hand-over inside span_scan_lists_fin_kernel is made of single words, so it needs no fence: the lengths are written and read with
+// device-scope relaxed atomics (write-through / L2-bypassing accesses: an XCD's L2 is not coherent with the other seven), the writer waits
+// for its stores to be acknowledged (s_waitcnt vmcnt(0)) before it takes its ticket.  (First form, measured in call C of round 6: a
+// __threadfence() pair around the ticket -- a whole-L2 write-back + invalidate per workgroup -- made the 1 236-workgroup stage-B kernel
+// 129 us instead of 14.)
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // exclusive scan of one value per thread over the 256 threads of the workgroup (all of them call it); *total = the sum
 template <typename T>
 __device__ __forceinline__ T block_scan256(T v, T* s_w, T* total)
@@ -452,7 +460,7 @@ __device__ __forceinline__ T block_scan256(T v, T* s_w, T* total)
 }
 
 // stage_a_lists_kernel's work with 256 threads: thread t owns bins 8 t .. 8 t + 7 (nb <= 2048)
-__device__ __forceinline__ void stage_a_lists_body(int nb, const uint32_t* __restrict__ binlen, uint32_t* __restrict__ segB,
+__device__ __forceinline__ void stage_a_lists_body(int nb, const uint32_t* binlen, uint32_t* __restrict__ segB,
 						   uint32_t* __restrict__ chunk0B, uint32_t* __restrict__ grp0B)
 {
 	__shared__ uint32_t s_w32[4];
@@ -464,7 +472,7 @@ __device__ __forceinline__ void stage_a_lists_body(int nb, const uint32_t* __res
 	unsigned long long csum = 0;
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
-		v[i] = b0 + i < nb ? binlen[b0 + i] : 0u;
+		v[i] = b0 + i < nb ? ld_agent(&binlen[b0 + i]) : 0u;
 		const uint32_t nc = (v[i] + RCH - 1) / RCH;
 		cg[i] = ((unsigned long long)nc << 32) | (unsigned long long)((nc + RGRP - 1) / RGRP);
 		lsum += v[i];
@@ -492,7 +500,7 @@ __device__ __forceinline__ void stage_a_lists_body(int nb, const uint32_t* __res
 }
 
 // list_scan_kernel<true>'s work with 256 threads: rounds of 2048 lengths, 8 consecutive ones per thread
-__device__ __forceinline__ void list_scan_ranges_body(int n, const uint32_t* __restrict__ len, uint2* __restrict__ ranges,
+__device__ __forceinline__ void list_scan_ranges_body(int n, const uint32_t* len, uint2* __restrict__ ranges,
 						      uint32_t* __restrict__ starts, int gx, int major_x, int nb)
 {
 	__shared__ uint32_t s_w[4];
@@ -502,7 +510,7 @@ __device__ __forceinline__ void list_scan_ranges_body(int n, const uint32_t* __r
 		uint32_t v[8], sum = 0;
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
-			v[i] = t0 + i < n ? len[t0 + i] : 0u;
+			v[i] = t0 + i < n ? ld_agent(&len[t0 + i]) : 0u;
 			sum += v[i];
 		}
 		uint32_t tot;
@@ -565,17 +573,16 @@ __global__ __launch_bounds__(256) void span_scan_lists_fin_kernel(int nb, int ns
 				gtot[(size_t)(g0 + i) * nb + b] = run;
 				run += v;
 			}
-			if (lane == 63) listlen[s * seg_stride + b * bin_stride] = incl;
+			if (lane == 63) st_agent(&listlen[s * seg_stride + b * bin_stride], incl);
 		}
 	}
 	// ---- the last workgroup to get here scans the lengths every workgroup has written
 	__shared__ uint32_t s_last;
-	__threadfence();   // release: this workgroup's lengths are visible device-wide before its ticket is
-	__syncthreads();
-	if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
+	asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // this wave's length is acknowledged by the memory system ...
+	__syncthreads();                                      // ... and so is every wave's of this workgroup, before its ticket is taken
+	if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
 	__syncthreads();
 	if (!s_last) return;
-	__threadfence();   // acquire
 	if (STAGE_A) {
 		stage_a_lists_body(nb, listlen, segB, chunk0B, grp0B);
 	} else {

@@ -1504,7 +1504,7 @@ hipError_t launch_blend_forward_split(hipStream_t st, const BlendFwdArgs& a, cha
 			   a.H, a.C, a.gx, nc, seg, nseg, pxcd, items, a.pitch, g_sweep_trace, order_arg, dealt)
 		if (sweep3) {
 			const hipError_t e3 = launch_accum_sweep3(st, (split_mode >> 8) & 15, a, table, nbatches, act_id, (const char*)wgt, counter,
-								  nc, seg, nseg, pxcd, items, g_sweep_trace, order_arg, dealt, (split_mode >> 16) & 15, sweep3c ? 1 : (sweep3f ? 2 : 0));
+								  nc, seg, nseg, pxcd, items, g_sweep_trace, order_arg, dealt, (split_mode >> 16) & 15, sweep3c ? 1 : (sweep3f ? 2 : 0), (split_mode >> 20) & 3);
 			if (e3 != hipSuccess) return e3;
 		} else if (sweep2) {
 			const hipError_t e2 = launch_accum_sweep2(st, arith_nib == 7 ? 6 : arith_nib == 11 ? 0 : (arith_nib == 12 ? 2 : (arith_nib == 13 ? 3 : (arith_nib == 14 ? 4 : (arith_nib == 15 ? 5 : 1)))), a.norm_plane ? 32 : ((split_mode >> 8) & 15), a, table,

@@ -1142,7 +1142,14 @@ constexpr int S3_STAGE_OF(bool coop) { return 8192 + 2 * S3_WB(coop) + 8 * 256; 
 // bumped by every wave when its own pieces are in), and refills a stage when all eight waves have read the batch it held (a
 // consumption counter per stage).  Why: in lock step a half that is draining a tile pair's store burst keeps its partner at the
 // barrier (15-20 % of the step); free-running, the partner works on until the ring stops it.
-template <int DBG, int MM = 0, bool COOP = false, bool FREE = false>
+// STP (round 6, "store placement"; profiles/r06_sweep_phases.txt: the default form runs 1.02 ms with its stores and 0.70 without, and a finished
+// pair's 64 immediate stores per wave are a burst during which the wave does nothing else -- the cost is the DRAIN of 128 KB per CU, paid in
+// issue stalls): 0 = rounds 3-5 (blocks 0, 1 of both tiles at once when the pair completes, blocks 2, 3 in four chunks of 16 in the PREP phases
+// of the next left tile's steps); 1 = only pixel block 0 at once; pixel block 1 leaves in the MATRIX phase of the next left tile's first step,
+// behind its first twelve products -- for that the steps pair the pixel blocks (0, 2 | 1, 3) instead of (0, 1 | 2, 3), so that the first dense
+// statement of the new tile only needs the two accumulator blocks the first 32 stores have freed (the per-block product order is untouched:
+// bit-identical maps); 2 = as 1 with the four deferred chunks in that matrix-phase slot as well (no store in a PREP phase at all).
+template <int DBG, int MM = 0, bool COOP = false, bool FREE = false, int STP = 0>
 __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
@@ -1425,6 +1432,8 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint64_t plane = (uint64_t)HW * 4u;
 	uint32_t d_o0 = 0u;    // byte offset of [4 half][y0 + 8][xp] (block 2's first row)
 	int dprog = 4;         // chunks of 16 stores issued (4 = nothing pending)
+	uint32_t pb_o0 = 0u;   // (STP) byte offset of [4 half][y0 + 4][xp]: pixel block 1 of the finished pair, still to be written
+	bool pend_b = false;   // (STP) ... and whether it is (uniform)
 
 	Bundle nb;   // the bundle this step issues (j + LA)
 	// the step's table words: entry word of batch j (returned), slots of the bundle to issue
@@ -1507,7 +1516,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 // landed before the barrier this phase began with); the DMA pieces of bundle j + LA and the deferred stores (DEF_) are
 // issued while they land; the feature split; [second half: arrival check of bundle j + 1]; barrier; MFMA: 48 products;
 // [first half: arrival check of bundle j + 1]; barrier.
-#define S3_STEP(b0_, b1_, b2_, b3_, DEF_)                                                            \
+#define S3_STEP(b0_, b1_, b2_, b3_, DEF_, MID_)                                                      \
 	do {                                                                                             \
 		S3_STAMP(9);                                                                                 \
 		uint32_t fa_v_ = 0u, fc_v_ = 0u;                                                             \
@@ -1543,13 +1552,13 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		if (!(DBG & 2)) {                                                                            \
 			S2_READ8(f_, fa_);                                                                       \
 			S3_RDB(x_, 0);                                                                           \
-			S3_RDB(y_, 1);                                                                           \
+			S3_RDB(y_, (STP ? 2 : 1));   /* (STP: the dense statement takes pixel blocks 0 and 2) */  \
 		}                                                                                            \
 		if (!(DBG & 2)) {                                                                            \
 			asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f_[0]), "+v"(f_[1]), "+v"(f_[2]), "+v"(f_[3]), "+v"(f_[4]), "+v"(f_[5]), "+v"(f_[6]), "+v"(f_[7]) : : "memory"); \
 			__builtin_amdgcn_sched_barrier(0);                                                       \
 			split8(f_, A_);                                                                          \
-			S3_RDB(x2_, 2);                                                                          \
+			S3_RDB(x2_, (STP ? 1 : 2));                                                              \
 			S3_RDB(y2_, 3);                                                                          \
 			if (g && !FREE) poll_issue(stn_, pw_, pid_);   /* (second half) the arrival check's reads ride along */ \
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x_[0]), "+v"(x_[1]), "+v"(x_[2]), "+v"(y_[0]), "+v"(y_[1]), "+v"(y_[2]), \
@@ -1572,6 +1581,7 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 				mfma_dense<b0_, b1_>(A_, x_, y_);                                                    \
 				/* (FREE) the stage bundle j + LA goes into held batch j - 1: every wave must have read it */ \
 				if constexpr (FREE) flag_check(flag_a + 16u + ((j + 3u) & 3u) * 4u, fc_v_, 8u * ((j + 3u) >> 2)); \
+				MID_;                                                                                \
 				S3_HALF2(b2_, b3_, 0); S3_HALF2(b2_, b3_, 1); S3_HALF2(b2_, b3_, 2);                 \
 				S3_HALF2(b2_, b3_, 3); S3_HALF2(b2_, b3_, 4);                                        \
 				if (!g || FREE) poll_issue(stn_, pw_, pid_);   /* (first half) under the last four MFMAs */ \
@@ -1583,12 +1593,16 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 				if constexpr (MM == 1) mfma_dense_wide<b0_, b1_>(aw_, x_, y_);                        \
 				else mfma_dense_wide_sp<MM - 1, b0_, b1_>(aw_, x_, y_);                               \
 				if constexpr (FREE) flag_check(flag_a + 16u + ((j + 3u) & 3u) * 4u, fc_v_, 8u * ((j + 3u) >> 2)); \
+				MID_;                                                                                \
 				S3_HALF2W(b2_, b3_, 0); S3_HALF2W(b2_, b3_, 1); S3_HALF2W(b2_, b3_, 2);              \
 				S3_HALF2W(b2_, b3_, 3); S3_HALF2W(b2_, b3_, 4);                                      \
 				if (!g || FREE) poll_issue(stn_, pw_, pid_);                                         \
 				S3_HALF2W(b2_, b3_, 5);                                                              \
 			}                                                                                        \
-		} else if (!g || FREE) poll_issue(stn_, pw_, pid_);                                          \
+		} else {                                                                                     \
+			MID_;                                                                                    \
+			if (!g || FREE) poll_issue(stn_, pw_, pid_);                                             \
+		}                                                                                            \
 		S3_STAMP(6);                                                                                 \
 		if (!g || FREE) {                                                                            \
 			const uint32_t got_ = poll_finish(stn_, pw_, pid_);                                      \
@@ -1601,12 +1615,31 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		step_tail();                                                                                 \
 	} while (0)
 
+// (STP) pixel block 1 of the pair that finished under mapping MP_: its 32 stores, then the two blocks are the new tile's (pixel blocks 1 and 3's)
+#define S3_PART_B(MP_)                                                                               \
+	do {                                                                                             \
+		if (pend_b) {                                                                                \
+			s2_store_rows<LB(MP_, 1), RB(MP_, 1), 0, 16, SMODE>(ubase, pb_o0, pb_o0 + (uint32_t)(2 * PW) * 4u, plane, wdelta); \
+			acc_zero<LB(MP_, 1)>(); acc_zero<RB(MP_, 1)>();                                          \
+			asm volatile("s_nop 3" : : : "memory");   /* (the products that follow accumulate into these blocks) */ \
+			pend_b = false;                                                                          \
+		}                                                                                            \
+	} while (0)
+// what rides in the matrix phase of a left tile's step, behind its first dense statement
+#define S3_MID(MP_)                                                                                  \
+	do {                                                                                             \
+		if constexpr (STP == 1) S3_PART_B(MP_);                                                      \
+		if constexpr (STP == 2) { if (pend_b) S3_PART_B(MP_); else S2_DEFERRED_CHUNK(MP_); }          \
+	} while (0)
 #define S3_LEFT_TILE(M_, tx_)                                                                        \
 	do {                                                                                             \
 		uint32_t e_;                                                                                 \
 		do {                                                                                         \
-			S3_STEP(LB(M_, 0), LB(M_, 1), LB(M_, 2), LB(M_, 3), S2_DEFERRED_CHUNK(1 - (M_)));         \
+			if constexpr (STP == 0) S3_STEP(LB(M_, 0), LB(M_, 1), LB(M_, 2), LB(M_, 3), S2_DEFERRED_CHUNK(1 - (M_)), (void)0); \
+			else if constexpr (STP == 1) S3_STEP(LB(M_, 0), LB(M_, 2), LB(M_, 1), LB(M_, 3), S2_DEFERRED_CHUNK(1 - (M_)), S3_MID(1 - (M_))); \
+			else S3_STEP(LB(M_, 0), LB(M_, 2), LB(M_, 1), LB(M_, 3), (void)0, S3_MID(1 - (M_)));      \
 		} while ((e_ >> 16) == 0u);                                                                  \
+		if constexpr (STP != 0) S3_PART_B(1 - (M_));   /* (cannot be pending: every tile has a step; kept for the proof) */ \
 		while (dprog < 4) S2_DEFERRED_CHUNK(1 - (M_));                                               \
 		tx_ = tx0 + (int)((e_ >> 8) & 255u);                                                         \
 	} while (0)
@@ -1614,9 +1647,29 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	do {                                                                                             \
 		uint32_t e_;                                                                                 \
 		do {                                                                                         \
-			S3_STEP(RB(M_, 0), RB(M_, 1), RB(M_, 2), RB(M_, 3), (void)0);                            \
+			if constexpr (STP == 0) S3_STEP(RB(M_, 0), RB(M_, 1), RB(M_, 2), RB(M_, 3), (void)0, (void)0); \
+			else S3_STEP(RB(M_, 0), RB(M_, 2), RB(M_, 1), RB(M_, 3), (void)0, (void)0);               \
 		} while ((e_ >> 16) == 0u);                                                                  \
 		tx_ = tx0 + (int)((e_ >> 8) & 255u);                                                         \
+	} while (0)
+// (STP) a pair finished under mapping M_: pixel block 0 of both tiles now, pixel block 1 pending (S3_PART_B), blocks 2, 3 deferred as ever;
+// at the image's edge everything at once, as S2_PAIR_DONE does
+#define S3_PAIR_DONE(M_, tx_)                                                                        \
+	do {                                                                                             \
+		const bool inside_ = ((tx_) + 1) * SGS_TILE <= W && y0 + 14 < H;   /* (uniform) */           \
+		if (STP == 0 || skip_stores || !inside_) {                                                   \
+			S2_PAIR_DONE(M_, tx_);                                                                   \
+		} else {                                                                                     \
+			const uint32_t o0_ = S2_PAIR_OFF(y0, (tx_) - 1);                                          \
+			const uint32_t o1_ = o0_ + (uint32_t)(2 * PW) * 4u;                                      \
+			asm volatile("s_nop 15" : : : "memory");                                                 \
+			s2_store_rows<LB(M_, 0), RB(M_, 0), 0, 16, SMODE>(ubase, o0_, o1_, plane, wdelta);        \
+			acc_zero<LB(M_, 0)>(); acc_zero<RB(M_, 0)>();                                            \
+			pb_o0 = o0_ + (uint32_t)(4 * PW) * 4u;                                                   \
+			pend_b = true;                                                                           \
+			d_o0 = o0_ + (uint32_t)(8 * PW) * 4u;                                                    \
+			dprog = 0;                                                                               \
+		}                                                                                            \
 	} while (0)
 
 	constexpr bool NORM = false;
@@ -1634,13 +1687,13 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 		S3_LEFT_TILE(0, tx);
 		if (j >= J) { S2_STORE_SINGLE(LB(0, 0), LB(0, 1), LB(0, 2), LB(0, 3), tx); break; }
 		S3_RIGHT_TILE(0, tx);
-		S2_PAIR_DONE(0, tx);
-		if (j >= J) { while (dprog < 4) S2_DEFERRED_CHUNK(0); break; }
+		S3_PAIR_DONE(0, tx);
+		if (j >= J) { S3_PART_B(0); while (dprog < 4) S2_DEFERRED_CHUNK(0); break; }
 		S3_LEFT_TILE(1, tx);
 		if (j >= J) { S2_STORE_SINGLE(LB(1, 0), LB(1, 1), LB(1, 2), LB(1, 3), tx); break; }
 		S3_RIGHT_TILE(1, tx);
-		S2_PAIR_DONE(1, tx);
-		if (j >= J) { while (dprog < 4) S2_DEFERRED_CHUNK(1); break; }
+		S3_PAIR_DONE(1, tx);
+		if (j >= J) { S3_PART_B(1); while (dprog < 4) S2_DEFERRED_CHUNK(1); break; }
 	}
 	if (!g && !FREE) __builtin_amdgcn_s_barrier();   // (the first half's counterpart of the second half's extra barrier)
 	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // drain the dummy tail bundles before LDS is released
@@ -1667,6 +1720,9 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 #undef S3_STEP
 #undef S3_LEFT_TILE
 #undef S3_RIGHT_TILE
+#undef S3_PART_B
+#undef S3_MID
+#undef S3_PAIR_DONE
 #undef S3_RDB
 }
 
@@ -1705,6 +1761,8 @@ bool x16_kernel_owns_cu(const void* fn, const char* name)
 int sweep3_x16_ownership()   // 1: both x16 ping-pong sweeps own their CU; 0: they do not (the x8 form runs instead)
 {
 	static const int own = (x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1, false, true>, "blend_accum_sweep3_kernel<0, 1, false, true>") &&
+				x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1, false, true, 1>, "blend_accum_sweep3_kernel<0, 1, false, true, 1>") &&
+				x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1, false, true, 2>, "blend_accum_sweep3_kernel<0, 1, false, true, 2>") &&
 				x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1>, "blend_accum_sweep3_kernel<0, 1>")) ? 1 : 0;
 	return own;
 }
@@ -1712,12 +1770,14 @@ int sweep3_x16_ownership()   // 1: both x16 ping-pong sweeps own their CU; 0: th
 hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
-			       const uint32_t* order, int dealt, int tune, int form)
+			       const uint32_t* order, int dealt, int tune, int form, int stp)
 {
 	if (tune == 1 && !sweep3_x16_ownership()) {   // (said once on stderr; sgs_x16_cu_ownership() reports it)
 		tune = 0;   // the same products on v_mfma_f32_32x32x8_bf16: bit-identical maps
 		if (form == 2) form = 0;   // (the product library's x8 sweep is the lock-step form)
+		stp = 0;
 	}
+	if (stp != 0 && !(tune == 1 && form == 2)) return hipErrorInvalidValue;   // (the store placements exist for the default form only)
 	const bool coop = form == 1;   // (form: 0 = lock step, 1 = fp32 hand-over, 2 = free-running halves)
 #define S3_LAUNCH(D_)                                                                                \
 	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
@@ -1741,17 +1801,28 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 	}
 #endif
 	// the free-running halves (flags instead of barriers, nibble 4) on the x16 MFMA: round 5's default
-	if (tune == 1 && form == 2 && dbg == 0) {
-		hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, 1, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table,
-				   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg,
-				   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands);
+	if (tune == 1 && form == 2 && dbg == 0) {   // stp: where a finished pair's stores are issued (template argument STP of the kernel)
+#define S3_LAUNCH_FS(S_)                                                                             \
+	hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, 1, false, true, S_>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
+		if (stp == 1) S3_LAUNCH_FS(1);
+		else if (stp == 2) S3_LAUNCH_FS(2);
+		else S3_LAUNCH_FS(0);
+#undef S3_LAUNCH_FS
 		return hipGetLastError();
 	}
 #undef S3_LAUNCH_MM
 #ifdef SGS_WITH_EXPERIMENTS   // round 6: the ablations / phase clocks of the DEFAULT form (free-running halves on x16), for profiles/r06_sweep_phases.txt
 	if (tune == 1 && form == 2 && (dbg == 1 || dbg == 2 || dbg == 3 || dbg == 4)) {
 #define S3_LAUNCH_FX(D_)                                                                             \
-	hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+	if (stp == 2) hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true, 2>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands);                                \
+	else if (stp == 1) hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true, 1>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
+			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands);                                \
+	else hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
 		if (dbg == 1) S3_LAUNCH_FX(1);

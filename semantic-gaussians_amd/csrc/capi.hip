@@ -394,8 +394,9 @@ inline uint32_t grow_hint(uint32_t hint, uint32_t used)
 // that call, attributed to "forward" / "backward".  The reference synchronises after EVERY stage; its own render_chn
 // passes debug=True unconditionally (model/renderer.py:182), so that behaviour would put ~8 host round trips into
 // every production frame (+0.15 ms at the headline size).  SGS_DEBUG_SYNC_EVERY_STAGE=1 restores it for fault hunting.
-// SGS_NO_FIN_MERGE=1 (read once; A/B switch): the span partitions' one-workgroup scans as kernels of their own again (rounds 2-5)
-static const bool g_no_fin_merge = [] { const char* e = getenv("SGS_NO_FIN_MERGE"); return e && *e && *e != '0'; }();
+// SGS_FIN_MERGE=1 (read once; A/B switch, round 6): the span partitions' one-workgroup scans ride in the last workgroup of the kernel in front
+// of them (two launches less); default off until it measures faster than the two small kernels it replaces
+static const bool g_no_fin_merge = [] { const char* e = getenv("SGS_FIN_MERGE"); return !(e && *e && *e != '0'); }();
 static const bool g_sync_every_stage = [] { const char* e = getenv("SGS_DEBUG_SYNC_EVERY_STAGE"); return e && *e && *e != '0'; }();
 #define SGS_CHECK_STAGE(what)                                                             \
 	do {                                                                              \
@@ -830,7 +831,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		const int nib = variant & 15;
 		const bool plain = variant == 0 || variant == 6 || variant == 14 || variant == 15;
 		const int tune = (variant >> 16) & 15;
-		const bool word = variant >= 16 && (variant & ~0xF30FF) == 0 &&
+		const bool word = variant >= 16 && (variant & ~0x3F30FF) == 0 && (((variant >> 20) & 3) == 0 || ((variant & 15) == 4 && tune == 1)) &&
 				  ((tune == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11)) ||
 				   (tune == 1 && (nib == 6 || nib == 4)));   // bits [19:16] = 1: the ping-pong sweep on x16, lock step (6) / free running (4: what 0 selects)
 		if (!plain && !word && !want_fused)

@@ -150,7 +150,7 @@ hipError_t launch_accum_sweep2(hipStream_t st, int arith, int dbg, const BlendFw
 hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, const uint32_t* table,
 			       const uint32_t* nbatches, const uint32_t* act_id, const char* wgt, const uint32_t* counter,
 			       int nc, int seg, int nseg, int pxcd, int items, unsigned long long* trace,
-			       const uint32_t* order, int dealt, int tune, int form = 0);   // (a.bands is honoured by the x16 forms, tune == 1)   // form: 0 lock step, 1 fp32 hand-over (nibble 5), 2 free-running halves (nibble 4)
+			       const uint32_t* order, int dealt, int tune, int form = 0, int stp = 0);   // (a.bands is honoured by the x16 forms, tune == 1)   // form: 0 lock step, 1 fp32 hand-over (nibble 5), 2 free-running halves (nibble 4)
 
 // debug: 4 x uint64 per sweep workgroup (begin, end on the 100 MHz steady counter, HW_ID | XCC_ID << 32, batches | tiles << 32)
 void set_sweep_trace(void* device_words);

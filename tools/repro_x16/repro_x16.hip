@@ -135,6 +135,51 @@ __global__ __launch_bounds__(64) void victim_pk_kernel(int iters, uint32_t salt,
 	}
 }
 
+// Round 6: a victim that is NOTHING but packed-fp32 chains, each checked against the SAME arithmetic in scalar
+// instructions (v_pk_fma_f32 and v_fma_f32 round identically per component), at the register footprint of the library's victim
+// (preprocess: 96 VGPRs -- two such waves fit beside one aggressor wave on a SIMD), 256 threads per workgroup.
+__global__ __launch_bounds__(256) void victim_pk_vs_scalar_kernel(int iters, uint32_t salt, uint32_t* bad)
+{
+	asm volatile("" : : : "v95");   // 96 registers per wave, like the library's victim
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x + salt * 977u;
+	f32x2 a[6];
+	float sx[6], sy[6];
+#pragma unroll
+	for (int i = 0; i < 6; i++) {
+		a[i] = f32x2{(float)((t * (2 * i + 3)) & 1023u) * 0.001f + 0.5f, (float)((t * (2 * i + 5)) & 511u) * 0.002f + 0.25f};
+		sx[i] = a[i].x;
+		sy[i] = a[i].y;
+	}
+	const f32x2 k0 = {0.999f, 0.998f}, k1 = {0.0007f, 0.0011f};
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int i = 0; i < 6; i++) {
+			const int j = (i + 1) % 6, l = (i + 2) % 6;
+			// packed: a_i = fma(a_i, k0, a_j * k1) + a_l * k1   (v_pk_mul, v_pk_fma, v_pk_mul, v_pk_add)
+			const f32x2 m1 = a[j] * k1;
+			const f32x2 f1 = __builtin_elementwise_fma(a[i], k0, m1);
+			const f32x2 m2 = a[l] * k1;
+			f32x2 r = f1 + m2;
+			asm volatile("" : "+v"(r));
+			// scalar twin, component by component
+			float rx = __builtin_fmaf(sx[i], 0.999f, sx[j] * 0.0007f) + sx[l] * 0.0007f;
+			float ry = __builtin_fmaf(sy[i], 0.998f, sy[j] * 0.0011f) + sy[l] * 0.0011f;
+			asm volatile("" : "+v"(rx), "+v"(ry));
+			a[i] = r;
+			sx[i] = rx;
+			sy[i] = ry;
+		}
+	}
+	uint32_t nbad = 0;
+#pragma unroll
+	for (int i = 0; i < 6; i++) nbad += (__float_as_uint(a[i].x) != __float_as_uint(sx[i]) ? 1u : 0u) + (__float_as_uint(a[i].y) != __float_as_uint(sy[i]) ? 1u : 0u);
+	if (nbad) {
+		atomicAdd(&bad[126], nbad);
+		const uint32_t slot = atomicAdd(&bad[127], 1u);
+		if (slot < 1) { bad[125] = threadIdx.x | (blockIdx.x << 8); }
+	}
+}
+
 // The library's real victim arithmetic: the 3-D covariance of a Gaussian from its scale and quaternion
 // (semantic-gaussians_amd/csrc/sgs_device.h, cov3d_from_scale_rot), which hipcc's SLP vectoriser turns into a chain of
 // v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 with op_sel and neg modifiers.  Results are written out and compared, after
@@ -176,7 +221,7 @@ __global__ void compare_kernel(size_t n, const uint32_t* a, const uint32_t* b, u
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void aggressor_kernel(const float* __restrict__ src, size_t nfloat, float* __restrict__ sink, int iters)
 {
-	__shared__ float4 ring[4 * 16384 / 16];   // 4 stages x 16 KB
+	__shared__ float4 ring[((MODE & 128) ? 96 * 1024 : 4 * 16384) / 16];   // 4 stages x 16 KB (+ padding to 96 KB with bit 128: one workgroup per CU, i.e. ONE aggressor wave per SIMD)
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)ring;
 	for (int i = threadIdx.x; i < 4 * 16384 / 16; i += 256) ring[i] = make_float4(1.f, 0.5f, 0.25f, 0.125f);
@@ -294,9 +339,28 @@ int main(int argc, char** argv)
 	hipLaunchKernelGGL(victim_cov_kernel, dim3(NCOV / 256), dim3(256), 0, 0, NCOV, cscale, crot, cref);
 	CK(hipDeviceSynchronize());
 	hipStream_t sv, sa;
-	CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
-	CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
-	const Config cfgs[] = {
+	const int ncus = argc > 2 ? atoi(argv[2]) : 0;   // > 0: BOTH streams confined to the same `ncus` compute units (victim and aggressor always share CUs)
+	if (ncus > 0) {
+		hipDeviceProp_t pr;
+		CK(hipGetDeviceProperties(&pr, 0));
+		std::vector<uint32_t> mask((pr.multiProcessorCount + 31) / 32, 0u);
+		for (int b = 0; b < ncus && b < pr.multiProcessorCount; b++) mask[b >> 5] |= 1u << (b & 31);
+		CK(hipExtStreamCreateWithCUMask(&sv, (uint32_t)mask.size(), mask.data()));
+		CK(hipExtStreamCreateWithCUMask(&sa, (uint32_t)mask.size(), mask.data()));
+		printf("both streams confined to compute units [0, %d) of %d\n", ncus, pr.multiProcessorCount);
+	} else {
+		CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+		CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+	}
+	const bool r6 = argc > 3;   // round 6's short list: the bisect's shape (one dense-x16 wave per SIMD, foreign packed-fp32 waves beside it) + controls
+	const Config cfgs6[] = {
+		{"no aggressor", 0},
+		{"ring + 24 dense x16 MFMAs per step, ONE workgroup per CU", 1 | 32 | 128},
+		{"ring + 48 dense x8 MFMAs per step, ONE workgroup per CU (control)", 1 | 64 | 128},
+		{"ring + 24 dense x16 MFMAs per step + stores, two workgroups per CU", 1 | 32 | 8},
+		{"24 dense x16 MFMAs per step, no memory, ONE workgroup per CU", 32 | 128},
+	};
+	const Config cfgs5[] = {
 		{"no aggressor", 0},
 		{"ring + x8 MFMA + stores (what ships)", 1 | 4 | 8},
 		{"ring + x16 MFMA + stores (round 2's form)", 1 | 2 | 8},
@@ -309,7 +373,10 @@ int main(int argc, char** argv)
 		{"ring + 48 dense x8 MFMAs per step on AGPRs", 1 | 64},
 	};
 	printf("%-56s %10s %12s %s\n", "aggressor", "victims", "aggr launches", "corrupt words (load victim / valu victim)");
-	for (const Config& c : cfgs) {
+	const Config* cfgs = r6 ? cfgs6 : cfgs5;
+	const int ncfg = r6 ? (int)(sizeof(cfgs6) / sizeof(Config)) : (int)(sizeof(cfgs5) / sizeof(Config));
+	for (int ci = 0; ci < ncfg; ci++) {
+		const Config& c = cfgs[ci];
 		CK(hipMemset(bad, 0, 4096));
 		const auto t0 = std::chrono::steady_clock::now();
 		long nv = 0, na = 0;
@@ -326,6 +393,10 @@ int main(int argc, char** argv)
 				case 32: launch_aggr<32>(sa, asrc, NW, sink, 2000); break;
 				case 1 | 32: launch_aggr<1 | 32>(sa, asrc, NW, sink, 2000); break;
 				case 1 | 64: launch_aggr<1 | 64>(sa, asrc, NW, sink, 2000); break;
+				case 1 | 32 | 128: launch_aggr<1 | 32 | 128>(sa, asrc, NW, sink, 2000); break;
+				case 1 | 64 | 128: launch_aggr<1 | 64 | 128>(sa, asrc, NW, sink, 2000); break;
+				case 1 | 32 | 8: launch_aggr<1 | 32 | 8>(sa, asrc, NW, sink, 2000); break;
+				case 32 | 128: launch_aggr<32 | 128>(sa, asrc, NW, sink, 2000); break;
 				}
 				na++;
 			}
@@ -334,6 +405,7 @@ int main(int argc, char** argv)
 				hipLaunchKernelGGL(victim_valu_kernel, dim3(16384), dim3(64), 0, sv, 256, salt++, bad);
 				hipLaunchKernelGGL(victim_trans_kernel, dim3(16384), dim3(64), 0, sv, 96, salt++, bad);
 				hipLaunchKernelGGL(victim_pk_kernel, dim3(16384), dim3(64), 0, sv, 256, salt++, bad);
+				hipLaunchKernelGGL(victim_pk_vs_scalar_kernel, dim3(4096), dim3(256), 0, sv, 256, salt++, bad);
 				hipLaunchKernelGGL(victim_cov_kernel, dim3(NCOV / 256), dim3(256), 0, sv, NCOV, cscale, crot, cout);
 				hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, sv, (size_t)NCOV * 6, (const uint32_t*)cout, (const uint32_t*)cref, bad);
 				nv++;
@@ -344,7 +416,7 @@ int main(int argc, char** argv)
 		CK(hipDeviceSynchronize());
 		uint32_t h[128];
 		CK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
-		printf("%-56s %10ld %12ld %8u loads %8u valu %8u trans %8u packed %8u cov3d\n", c.name, nv, na, h[0], h[2], h[112], h[96], h[120]);
+		printf("%-70s %8ld %8ld %6u loads %6u valu %6u trans %6u packed %6u packed-vs-scalar %6u cov3d\n", c.name, nv, na, h[0], h[2], h[112], h[96], h[126], h[120]);
 		if (h[120]) printf("      cov3d word %u: got %08x want %08x\n", h[122], h[123], h[124]);
 		for (uint32_t i = 0; i < h[97] && i < 3; i++)
 			printf("      packed chain: lane %u block %u a0 %08x b0 %08x\n", h[100 + 4 * i], h[103 + 4 * i], h[101 + 4 * i], h[102 + 4 * i]);
