@@ -414,185 +414,12 @@ __global__ __launch_bounds__(1024) void stage_a_lists_kernel(int nb, const uint3
 	}
 }
 
-// ---- round 6: the single-workgroup steps ride in the kernel in front of them --------------------------------------------------------------
-// span_scan_lists_kernel was followed, in both stages, by a one-workgroup kernel that scans the list lengths it had just written
-// (stage A: stage_a_lists_kernel, stage B: list_scan_kernel<true>): two launches of ~5 + ~9 us that exist only because a scan over ALL
-// lists needs every list's length.  span_scan_lists_fin_kernel is span_scan_lists_kernel whose LAST workgroup to finish (one device-scope
-// counter per stage in the frame's cleared 128-byte block; release / acquire fences around it) runs that scan with its 256 threads.
-
-// The hand-over inside span_scan_lists_fin_kernel is made of single words, so it needs no fence: the lengths are written and read with
-// device-scope relaxed atomics (write-through / L2-bypassing accesses: an XCD's L2 is not coherent with the other seven), the writer waits
-// for its stores to be acknowledged (s_waitcnt vmcnt(0)) before it takes its ticket.  (First form, measured in call C of round 6: a
-// __threadfence() pair around the ticket -- a whole-L2 write-back + invalidate per workgroup -- made the 1 236-workgroup stage-B kernel
-// 129 us instead of 14.)
-__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// exclusive scan of one value per thread over the 256 threads of the workgroup (all of them call it); *total = the sum
-template <typename T>
-__device__ __forceinline__ T block_scan256(T v, T* s_w, T* total)
-{
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	T incl = v;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		T u;
-		if constexpr (sizeof(T) == 8) {
-			const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o), hi = (uint32_t)__shfl_up((int)(uint32_t)((unsigned long long)incl >> 32), o);
-			u = (T)(((unsigned long long)hi << 32) | lo);
-		} else {
-			u = (T)__shfl_up((int)incl, o);
-		}
-		if (lane >= o) incl += u;
-	}
-	__syncthreads();   // (s_w may still be read from the previous call)
-	if (lane == 63) s_w[wave] = incl;
-	__syncthreads();
-	T base = 0, tot = 0;
-#pragma unroll
-	for (int w = 0; w < 4; w++) {
-		const T x = s_w[w];
-		if (w < wave) base += x;
-		tot += x;
-	}
-	if (total) *total = tot;
-	return base + incl - v;
-}
-
-// stage_a_lists_kernel's work with 256 threads: thread t owns bins 8 t .. 8 t + 7 (nb <= 2048)
-__device__ __forceinline__ void stage_a_lists_body(int nb, const uint32_t* binlen, uint32_t* __restrict__ segB,
-						   uint32_t* __restrict__ chunk0B, uint32_t* __restrict__ grp0B)
-{
-	__shared__ uint32_t s_w32[4];
-	__shared__ unsigned long long s_w64[4];
-	const int b0 = 8 * (int)threadIdx.x;
-	uint32_t v[8];
-	unsigned long long cg[8];
-	uint32_t lsum = 0;
-	unsigned long long csum = 0;
-#pragma unroll
-	for (int i = 0; i < 8; i++) {
-		v[i] = b0 + i < nb ? ld_agent(&binlen[b0 + i]) : 0u;
-		const uint32_t nc = (v[i] + RCH - 1) / RCH;
-		cg[i] = ((unsigned long long)nc << 32) | (unsigned long long)((nc + RGRP - 1) / RGRP);
-		lsum += v[i];
-		csum += cg[i];
-	}
-	uint32_t ltot;
-	unsigned long long ctot;
-	uint32_t lrun = block_scan256<uint32_t>(lsum, s_w32, &ltot);
-	unsigned long long crun = block_scan256<unsigned long long>(csum, s_w64, &ctot);
-#pragma unroll
-	for (int i = 0; i < 8; i++) {
-		if (b0 + i < nb) {
-			segB[b0 + i] = lrun;
-			chunk0B[b0 + i] = (uint32_t)(crun >> 32);
-			grp0B[b0 + i] = (uint32_t)crun;
-		}
-		lrun += v[i];
-		crun += cg[i];
-	}
-	if (threadIdx.x == 0) {
-		segB[nb] = ltot;
-		chunk0B[nb] = (uint32_t)(ctot >> 32);
-		grp0B[nb] = (uint32_t)ctot;
-	}
-}
-
-// list_scan_kernel<true>'s work with 256 threads: rounds of 2048 lengths, 8 consecutive ones per thread
-__device__ __forceinline__ void list_scan_ranges_body(int n, const uint32_t* len, uint2* __restrict__ ranges,
-						      uint32_t* __restrict__ starts, int gx, int major_x, int nb)
-{
-	__shared__ uint32_t s_w[4];
-	uint32_t carry = 0;
-	for (int base = 0; base < n; base += 2048) {
-		const int t0 = base + 8 * (int)threadIdx.x;
-		uint32_t v[8], sum = 0;
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			v[i] = t0 + i < n ? ld_agent(&len[t0 + i]) : 0u;
-			sum += v[i];
-		}
-		uint32_t tot;
-		uint32_t run = carry + block_scan256<uint32_t>(sum, s_w, &tot);
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			const int t = t0 + i;
-			if (t < n) {
-				const uint32_t m = v[i];
-				ranges[t] = m ? make_uint2(run, run + m) : make_uint2(0u, 0u);
-				const int x = t % gx, y = t / gx;
-				starts[(major_x ? x : y) * nb + (major_x ? y : x)] = run;
-				run += m;
-			}
-		}
-		carry += tot;
-	}
-}
-
-// STAGE_A: the lists are stage A's bins (then: stage B's segment starts and tables); else the tiles (then: ranges, the segment-major list
-// starts, the blend's work-list counter).
-template <bool STAGE_A>
-__global__ __launch_bounds__(256) void span_scan_lists_fin_kernel(int nb, int nseg, const uint32_t* __restrict__ grp0,
-								    uint32_t* __restrict__ gtot, int seg_stride, int bin_stride,
-								    uint32_t* __restrict__ listlen, const uint32_t* __restrict__ abort,
-								    uint32_t* __restrict__ done,
-								    // stage A's finish
-								    uint32_t* __restrict__ segB, uint32_t* __restrict__ chunk0B, uint32_t* __restrict__ grp0B,
-								    // stage B's finish
-								    uint2* __restrict__ ranges, uint32_t* __restrict__ tstart, int gx, int major_x,
-								    uint32_t* __restrict__ arena_counter, uint32_t first_free)
-{
-	if (abort && *abort != 0u) {   // (aborted frame: every blend kernel exits on the counter's second word)
-		if (!STAGE_A && arena_counter && blockIdx.x == 0 && threadIdx.x == 0) {
-			arena_counter[0] = first_free;
-			arena_counter[1] = 2u;
-		}
-		return;
-	}
-	{   // span_scan_lists_kernel: one wave per list
-		const int lane = threadIdx.x & 63;
-		const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-		if (t < nb * nseg) {
-			const int s = t / nb, b = t - s * nb;
-			const uint32_t g0 = grp0[s], n = grp0[s + 1] - g0;
-			const uint32_t per = (n + 63) / 64;
-			const uint32_t beg = (uint32_t)lane * per < n ? (uint32_t)lane * per : n;
-			const uint32_t end = beg + per < n ? beg + per : n;
-			uint32_t sum = 0;
-			for (uint32_t i = beg; i < end; i++) sum += gtot[(size_t)(g0 + i) * nb + b];
-			uint32_t incl = sum;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) {
-				const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
-				if (lane >= o) incl += u;
-			}
-			uint32_t run = incl - sum;
-			for (uint32_t i = beg; i < end; i++) {
-				const uint32_t v = gtot[(size_t)(g0 + i) * nb + b];
-				gtot[(size_t)(g0 + i) * nb + b] = run;
-				run += v;
-			}
-			if (lane == 63) st_agent(&listlen[s * seg_stride + b * bin_stride], incl);
-		}
-	}
-	// ---- the last workgroup to get here scans the lengths every workgroup has written
-	__shared__ uint32_t s_last;
-	asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // this wave's length is acknowledged by the memory system ...
-	__syncthreads();                                      // ... and so is every wave's of this workgroup, before its ticket is taken
-	if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
-	__syncthreads();
-	if (!s_last) return;
-	if (STAGE_A) {
-		stage_a_lists_body(nb, listlen, segB, chunk0B, grp0B);
-	} else {
-		if (arena_counter && threadIdx.x == 0) {
-			arena_counter[0] = first_free;
-			arena_counter[1] = 0u;
-		}
-		list_scan_ranges_body(nb * nseg, listlen, ranges, tstart, gx, major_x, nb);
-	}
-}
+// (Round 6, measured and removed -- git history has the code: the two one-workgroup steps -- stage A's stage_a_lists_kernel, stage B's
+// list_scan_kernel<true> -- riding in the LAST workgroup of the span_scan_lists_kernel in front of them (a device-scope ticket per stage).  With a
+// __threadfence() pair around the ticket the 1 236-workgroup stage-B kernel took 129 us instead of 5 + 9 (an XCD's L2 is not coherent with the other
+// seven: an agent-scope fence is a whole-L2 write-back + invalidate per workgroup); with the hand-over on device-scope word atomics instead of fences it
+// still cost 8 us MORE than the two kernels it replaced -- the tail workgroup's 256 threads scan 4 941 lengths with L2-bypassing loads where the dedicated
+// kernel has 1 024 threads and a warm L2, and two launches of back-to-back kernels on one stream cost almost nothing.  profiles/r06_front_end_ab.txt.)
 
 // the ballot sweep: every covering item is written to its final position in the list of
 // (segment, bin).  OUT_ITEMS: stage A (the item with its payload span); else the Gaussian id.
@@ -732,7 +559,7 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
 			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort,
-			      uint32_t* arena_counter, uint32_t arena_first_free, const uint32_t* stage_a_tab, uint32_t* done2)
+			      uint32_t* arena_counter, uint32_t arena_first_free, const uint32_t* stage_a_tab)
 {
 	const int ntiles = gx * gy;
 	if (R == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st);
@@ -772,15 +599,10 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 		hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grA * nbA + 255) / 256)), dim3(256), 0, st,
 				   nbA, 1, chunk0A, grp0A, cmat, gtot, abort);
 	}
-	if (done2) {   // (round 6) the bin lengths' scan -- stage B's segment starts and tables -- rides in the last workgroup of the per-list prefix
-		hipLaunchKernelGGL(span_scan_lists_fin_kernel<true>, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1, binlen, abort,
-				   done2, segB, chunk0B, grp0B, (uint2*)nullptr, (uint32_t*)nullptr, gx, major_x, (uint32_t*)nullptr, 0u);
-	} else {
-		hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
-				   binlen, abort);
-		// (the bin lengths' scan = stage B's segment starts, and stage B's chunk / group tables: one launch)
-		hipLaunchKernelGGL(stage_a_lists_kernel, dim3(1), dim3(1024), 0, st, nbA, binlen, segB, chunk0B, grp0B, abort);
-	}
+	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
+			   binlen, abort);
+	// (the bin lengths' scan = stage B's segment starts, and stage B's chunk / group tables: one launch)
+	hipLaunchKernelGGL(stage_a_lists_kernel, dim3(1), dim3(1024), 0, st, nbA, binlen, segB, chunk0B, grp0B, abort);
 #define SGS_SCATTER_A(NW_)                                                                                          \
 	hipLaunchKernelGGL((span_scatter_kernel<true, NW_>), dim3((chA + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)),  \
 			   dim3(64 * NW_), ldsSA, st, nbA, 1, segA, chunk0A, grp0A, (const uint2*)nullptr, rrec,    \
@@ -802,16 +624,10 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 		hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grB * nbB + 255) / 256)), dim3(256), 0, st,
 				   nbB, nbA, chunk0B, grp0B, cmat, gtot, abort);
 	}
-	if (done2) {   // (round 6) ranges, the segment-major list starts and the work-list counter ride in the last workgroup of the per-list prefix
-		hipLaunchKernelGGL(span_scan_lists_fin_kernel<false>, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot, seg_stride,
-				   bin_stride, lens, abort, done2 + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ranges, tstart,
-				   gx, major_x, arena_counter, arena_first_free);
-	} else {
-		hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
-				   seg_stride, bin_stride, lens, abort);
-		hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB,
-				   arena_counter, arena_first_free);
-	}
+	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
+			   seg_stride, bin_stride, lens, abort);
+	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB,
+			   arena_counter, arena_first_free);
 #define SGS_SCATTER_B(NW_)                                                                                          \
 	hipLaunchKernelGGL((span_scatter_kernel<false, NW_>), dim3((chB + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)), \
 			   dim3(64 * NW_), ldsSB, st, nbB, nbA, segB, chunk0B, grp0B, items, rrec, cmat, gtot,      \
