@@ -827,7 +827,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		const int nib = variant & 15;
 		const bool plain = variant == 0 || variant == 6 || variant == 14 || variant == 15;
 		const int tune = (variant >> 16) & 15;
-		const bool word = variant >= 16 && (variant & ~0x3F30FF) == 0 && (((variant >> 20) & 3) == 0 || ((variant & 15) == 4 && tune == 1)) &&
+		const bool word = variant >= 16 && (variant & ~0x3F30FF) == 0 && (((variant >> 20) & 3) == 0 || (((variant >> 20) & 3) < 3 && (variant & 15) == 4 && tune == 1)) &&   /* [21:20]: store placement of the free-running x16 sweep */
 				  ((tune == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11)) ||
 				   (tune == 1 && (nib == 6 || nib == 4)));   // bits [19:16] = 1: the ping-pong sweep on x16, lock step (6) / free running (4: what 0 selects)
 		if (!plain && !word && !want_fused)
@@ -991,9 +991,15 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		// The default of the default: its FREE-RUNNING form (word 0x10004: the two halves of the workgroup hand the ring stages over through LDS
 		// counters instead of two barriers per step) -- on x8 that form lost (the lock step kept the halves' matrix phases apart);
 		// with the products at half the time it wins: sweep 1.05 -> 1.01 ms alone, equal with four views in flight, bit-identical maps.
-		// SGS_DEFAULT_SWEEP = 16: the lock-step x16 form (0x10006), 6: lock step on x8 (round 4's default), 14: round 3's kernel (EXPERIMENTS).
-		static const int default_sweep = !getenv("SGS_DEFAULT_SWEEP") ? 0x10004
-						 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 14 ? 14 : (atoi(getenv("SGS_DEFAULT_SWEEP")) == 16 ? 0x10006 : 6));
+		// Round 6: ... with store placement 1 (word 0x110004, bits [21:20] = 1: only pixel block 0 of a finished tile pair is stored at once, pixel block
+		// 1 leaves behind the first twelve products of the next tile's first matrix phase -- bit-identical maps, sweep -3 %, profiles/r06_sweep_store_placement.txt).
+		// SGS_DEFAULT_SWEEP = 4: round 5's default (0x10004), 16: lock step on x16, 6: lock step on x8, 14: round 3's kernel (EXPERIMENTS).
+		static const int default_sweep = [] {
+			const char* e = getenv("SGS_DEFAULT_SWEEP");
+			if (!e) return 0x110004;
+			const int v = atoi(e);
+			return v == 14 ? 14 : (v == 16 ? 0x10006 : (v == 4 ? 0x10004 : 6));
+		}();
 		const int split_word = variant >= 16 ? variant : (variant == 15 ? 11 : (variant == 14 ? 8 : default_sweep));
 		if (a.bands && (split_word & 15) != 4 && (split_word & 15) != 6)   // (the word the default resolves to: SGS_DEFAULT_SWEEP=14 selects a kernel without bands)
 			return fail(SGS_EINVAL, "SGS_OPT_OUT_BANDS needs the ping-pong sweep (the default)");

@@ -31,11 +31,11 @@ def test_random_shapes(orc, i):
 @pytest.mark.parametrize("H", [16400, 32768])   # (32768 = 2048 tile rows: the longest axis the span partitions take)
 def test_sweep_plan_many_segments(H):
     """The sweep's workgroup order (sweep_plan_kernel): more than 1024 segments take the bitonic sort, more than 4096
-    the unsorted deal -- the feature map must be the row-major order's, bit for bit (variant 0x11004: the default kernels, row-major)."""
+    the unsorted deal -- the feature map must be the row-major order's, bit for bit (variant 0x111004: the default kernels, row-major)."""
     import torch
     from test_parity_gpu import _hip_forward
     scene, cam = small_scene(P=30000, C=128, W=272, H=H, fx=300.0, seed=H)
-    a = _hip_forward(scene, cam, variant=0x11004)
+    a = _hip_forward(scene, cam, variant=0x111004)
     ref_n, ref = a[0], a[1].clone()
     del a
     b = _hip_forward(scene, cam, variant=0)

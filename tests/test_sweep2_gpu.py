@@ -22,8 +22,8 @@ DEV = "cuda:0"
 V_X6, V_EXACT, V_X6W, V_X6S, V_X6P, V_X6PW = 0x6A, 0x6B, 0x6C, 0x6D, 0x6E, 0x6F
 V_PP = 0x66       # round 4: ping-pong sweep on the x8 MFMA (0x6_ pins 48-tile segments like the others)
 V_PP16 = 0x10066  # round 5: the ping-pong sweep on the double-rate v_mfma_f32_32x32x16_bf16 (same products, 16 k per instruction), lock step
-V_FR16 = 0x10064  # round 5, THE DEFAULT kernel: the same with the halves free-running on per-stage LDS counters instead of two barriers per step (bit-identical to V_PP16)
-V_FR16_S1 = 0x110064   # round 6: V_FR16 with store placement 1 (bits [21:20] of the word): pixel block 1 of a finished pair leaves in the next tile's first matrix phase
+V_FR16 = 0x10064  # round 5's default kernel: the same with the halves free-running on per-stage LDS counters instead of two barriers per step (bit-identical to V_PP16)
+V_FR16_S1 = 0x110064   # round 6, THE DEFAULT kernel: V_FR16 with store placement 1 (bits [21:20] of the word): pixel block 1 of a finished pair leaves in the next tile's first matrix phase
 V_FR16_S2 = 0x210064   # round 6: placement 2: the deferred chunks ride in the matrix phases too (no store in a PREP phase); both bit-identical to V_FR16
 V_X6C = 0x67      # six products, fp32 weights handed over, split once per workgroup into LDS: bit-identical to V_X6P
 SHIPS = (0, 14, 15, V_EXACT, V_PP, V_PP16, V_FR16, V_FR16_S1, V_FR16_S2)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
