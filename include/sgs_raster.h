@@ -344,8 +344,8 @@ int sgs_x16_cu_ownership(void);
  *      | [13:12] workgroup order (0 / 3 = segments sorted by work and dealt to the XCDs, 1 = row-major, 2 = dealt unsorted)
  *      | [19:16] with sweeps 4 / 6: 1 = on the x16 MFMA, 0 = on the x8 MFMA (sweep 6 only: round 4's default, bit-identical).
  *      | [21:20] with the word's sweep 4 on x16 only: where a finished tile pair's stores are issued (0 = rounds 3-5: blocks 0, 1 of both tiles at
- *      once, blocks 2, 3 in four chunks behind the next tile's steps; 1 = pixel block 1 in the next tile's first matrix phase; 2 = the chunks
- *      there as well) -- the same sums in the same order, bit-identical maps.
+ *      once, blocks 2, 3 in four chunks behind the next tile's steps; 1 = pixel block 1 in the next tile's first matrix phase) -- the same
+ *      sums in the same order, bit-identical maps.
  *      What 0 selects is the word 0x110004 (free-running halves on x16, store placement 1; 0x10004 = round 5's default, 0x10006 = the same in
  *      lock step: all bit-identical).
  * Everything else -- sweep nibble 4 with bits [19:16] = 0, nibbles 5 / 7 / 9 / 10 / 13 / 14, ablation bits [11:8], pre-pass switches

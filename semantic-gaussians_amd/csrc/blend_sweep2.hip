@@ -1148,7 +1148,9 @@ constexpr int S3_STAGE_OF(bool coop) { return 8192 + 2 * S3_WB(coop) + 8 * 256; 
 // of the next left tile's steps); 1 = only pixel block 0 at once; pixel block 1 leaves in the MATRIX phase of the next left tile's first step,
 // behind its first twelve products -- for that the steps pair the pixel blocks (0, 2 | 1, 3) instead of (0, 1 | 2, 3), so that the first dense
 // statement of the new tile only needs the two accumulator blocks the first 32 stores have freed (the per-block product order is untouched:
-// bit-identical maps); 2 = as 1 with the four deferred chunks in that matrix-phase slot as well (no store in a PREP phase at all).
+// bit-identical maps).  Sweep 1.017 -> 0.983 ms, order-balanced over three boxes (profiles/r06_sweep_store_placement*.txt).  Two more placements were built
+// on this hook, measured and removed: the four deferred chunks in that matrix-phase slot as well (no store in a PREP phase at all): +2 %; the chunks behind
+// the step's LAST products, in front of the arrival check's wait: +10 % (1.10 ms) -- stores at the end of a matrix phase delay the wave's own DMA pieces' arrival check.
 template <int DBG, int MM = 0, bool COOP = false, bool FREE = false, int STP = 0>
 __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
@@ -1625,19 +1627,12 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 			pend_b = false;                                                                          \
 		}                                                                                            \
 	} while (0)
-// what rides in the matrix phase of a left tile's step, behind its first dense statement
-#define S3_MID(MP_)                                                                                  \
-	do {                                                                                             \
-		if constexpr (STP == 1) S3_PART_B(MP_);                                                      \
-		if constexpr (STP == 2) { if (pend_b) S3_PART_B(MP_); else S2_DEFERRED_CHUNK(MP_); }          \
-	} while (0)
 #define S3_LEFT_TILE(M_, tx_)                                                                        \
 	do {                                                                                             \
 		uint32_t e_;                                                                                 \
 		do {                                                                                         \
 			if constexpr (STP == 0) S3_STEP(LB(M_, 0), LB(M_, 1), LB(M_, 2), LB(M_, 3), S2_DEFERRED_CHUNK(1 - (M_)), (void)0); \
-			else if constexpr (STP == 1) S3_STEP(LB(M_, 0), LB(M_, 2), LB(M_, 1), LB(M_, 3), S2_DEFERRED_CHUNK(1 - (M_)), S3_MID(1 - (M_))); \
-			else S3_STEP(LB(M_, 0), LB(M_, 2), LB(M_, 1), LB(M_, 3), (void)0, S3_MID(1 - (M_)));      \
+			else S3_STEP(LB(M_, 0), LB(M_, 2), LB(M_, 1), LB(M_, 3), S2_DEFERRED_CHUNK(1 - (M_)), S3_PART_B(1 - (M_))); \
 		} while ((e_ >> 16) == 0u);                                                                  \
 		if constexpr (STP != 0) S3_PART_B(1 - (M_));   /* (cannot be pending: every tile has a step; kept for the proof) */ \
 		while (dprog < 4) S2_DEFERRED_CHUNK(1 - (M_));                                               \
@@ -1721,7 +1716,6 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 #undef S3_LEFT_TILE
 #undef S3_RIGHT_TILE
 #undef S3_PART_B
-#undef S3_MID
 #undef S3_PAIR_DONE
 #undef S3_RDB
 }
@@ -1762,7 +1756,6 @@ int sweep3_x16_ownership()   // 1: both x16 ping-pong sweeps own their CU; 0: th
 {
 	static const int own = (x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1, false, true>, "blend_accum_sweep3_kernel<0, 1, false, true>") &&
 				x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1, false, true, 1>, "blend_accum_sweep3_kernel<0, 1, false, true, 1>") &&
-				x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1, false, true, 2>, "blend_accum_sweep3_kernel<0, 1, false, true, 2>") &&
 				x16_kernel_owns_cu((const void*)&blend_accum_sweep3_kernel<0, 1>, "blend_accum_sweep3_kernel<0, 1>")) ? 1 : 0;
 	return own;
 }
@@ -1807,8 +1800,8 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands)
 		if (stp == 1) S3_LAUNCH_FS(1);
-		else if (stp == 2) S3_LAUNCH_FS(2);
-		else S3_LAUNCH_FS(0);
+		else if (stp == 0) S3_LAUNCH_FS(0);
+		else return hipErrorInvalidValue;
 #undef S3_LAUNCH_FS
 		return hipGetLastError();
 	}
@@ -1816,10 +1809,7 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 #ifdef SGS_WITH_EXPERIMENTS   // round 6: the ablations / phase clocks of the DEFAULT form (free-running halves on x16), for profiles/r06_sweep_phases.txt
 	if (tune == 1 && form == 2 && (dbg == 1 || dbg == 2 || dbg == 3 || dbg == 4)) {
 #define S3_LAUNCH_FX(D_)                                                                             \
-	if (stp == 2) hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true, 2>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
-			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
-			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands);                                \
-	else if (stp == 1) hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true, 1>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
+	if (stp == 1) hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true, 1>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \
 			   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg, \
 			   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands);                                \
 	else hipLaunchKernelGGL((blend_accum_sweep3_kernel<D_, 1, false, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table, \

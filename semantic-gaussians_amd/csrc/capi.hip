@@ -827,7 +827,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 		const int nib = variant & 15;
 		const bool plain = variant == 0 || variant == 6 || variant == 14 || variant == 15;
 		const int tune = (variant >> 16) & 15;
-		const bool word = variant >= 16 && (variant & ~0x3F30FF) == 0 && (((variant >> 20) & 3) == 0 || (((variant >> 20) & 3) < 3 && (variant & 15) == 4 && tune == 1)) &&   /* [21:20]: store placement of the free-running x16 sweep */
+		const bool word = variant >= 16 && (variant & ~0x3F30FF) == 0 && (((variant >> 20) & 3) == 0 || (((variant >> 20) & 3) == 1 && (variant & 15) == 4 && tune == 1)) &&   /* [21:20]: store placement of the free-running x16 sweep */
 				  ((tune == 0 && (nib == 0 || nib == 6 || nib == 8 || nib == 11)) ||
 				   (tune == 1 && (nib == 6 || nib == 4)));   // bits [19:16] = 1: the ping-pong sweep on x16, lock step (6) / free running (4: what 0 selects)
 		if (!plain && !word && !want_fused)

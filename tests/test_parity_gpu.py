@@ -130,10 +130,10 @@ def test_development_forms_are_not_in_the_product_library():
     for v in (1, 2, 3, 4, 5, 0x6A, 0x6D, 0x6E, 0x67, 0x65, 0x64, 0x69, 0x166, 0x266, 0x466, 0x4066, 0x8066, 0xC066):
         with pytest.raises(RuntimeError, match="EXPERIMENTS"):
             _hip_forward(scene, cam, variant=v)
-    for v in (0x110006, 0x100066, 0x310004):   # store placements exist for the free-running x16 sweep only; placement 3 does not exist
+    for v in (0x110006, 0x100066, 0x210064, 0x310004):   # store placements exist for the free-running x16 sweep only
         with pytest.raises(RuntimeError):
             _hip_forward(scene, cam, variant=v)
-    for v in (0, 6, 14, 15, 0x66, 0x10066, 0x10006, 0x10064, 0x10004, 0x110004, 0x210064, 0x6B, 0x68, 0x16, 0x1066):   # what ships
+    for v in (0, 6, 14, 15, 0x66, 0x10066, 0x10006, 0x10064, 0x10004, 0x110004, 0x110064, 0x6B, 0x68, 0x16, 0x1066):   # what ships
         _hip_forward(scene, cam, variant=v)
     g = torch.Generator().manual_seed(1)
     dL = torch.randn(128, 48, 64, generator=g)

@@ -24,9 +24,8 @@ V_PP = 0x66       # round 4: ping-pong sweep on the x8 MFMA (0x6_ pins 48-tile s
 V_PP16 = 0x10066  # round 5: the ping-pong sweep on the double-rate v_mfma_f32_32x32x16_bf16 (same products, 16 k per instruction), lock step
 V_FR16 = 0x10064  # round 5's default kernel: the same with the halves free-running on per-stage LDS counters instead of two barriers per step (bit-identical to V_PP16)
 V_FR16_S1 = 0x110064   # round 6, THE DEFAULT kernel: V_FR16 with store placement 1 (bits [21:20] of the word): pixel block 1 of a finished pair leaves in the next tile's first matrix phase
-V_FR16_S2 = 0x210064   # round 6: placement 2: the deferred chunks ride in the matrix phases too (no store in a PREP phase); both bit-identical to V_FR16
 V_X6C = 0x67      # six products, fp32 weights handed over, split once per workgroup into LDS: bit-identical to V_X6P
-SHIPS = (0, 14, 15, V_EXACT, V_PP, V_PP16, V_FR16, V_FR16_S1, V_FR16_S2)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
+SHIPS = (0, 14, 15, V_EXACT, V_PP, V_PP16, V_FR16, V_FR16_S1)   # everything else is a development form (make EXPERIMENTS=1): its tests skip on the product library
 
 
 def _gate(variant):
@@ -73,7 +72,7 @@ def check(orc, scene, cam, variant, seg=None, **kw):
 SHAPES = [(128, 200, 120), (160, 208, 70), (512, 192, 100), (256, 48, 40), (128, 16, 16), (128, 400, 64), (128, 336, 48)]
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6S, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1, V_FR16_S2])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6S, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1])
 @pytest.mark.parametrize("C,W,H", SHAPES)
 def test_sweep2_shapes(orc, variant, C, W, H):
     """W % 32 == 16 (staggered pairs: a segment starts with an unpaired right half on odd rows), W % 32 == 0, ragged W
@@ -84,7 +83,7 @@ def test_sweep2_shapes(orc, variant, C, W, H):
     check(orc, scene, cam, variant, seg=1)   # 8-tile segments: many segment ends
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1, V_FR16_S2])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1])
 def test_sweep2_background_and_short_lists(orc, variant):
     """Non-zero background (the closing T * bg pseudo entry), tiles whose only entry is that pseudo entry."""
     _gate(variant)
@@ -96,7 +95,7 @@ def test_sweep2_background_and_short_lists(orc, variant):
     assert (r[:, 0] == r[:, 1]).any()   # empty tiles exist
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1, V_FR16_S2])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1])
 def test_sweep2_long_lists(orc, variant):
     """Dense scene, wide image: the batch-table window (1024 batches) slides, chunk tables run past one chunk per tile,
     deferred stores ride along tiles of very different lengths."""
@@ -109,7 +108,7 @@ def test_sweep2_long_lists(orc, variant):
     check(orc, scene, cam, variant, seg=6)   # one 49-tile segment: ~2900 batches
 
 
-@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1, V_FR16_S2])
+@pytest.mark.parametrize("variant", [V_EXACT, V_X6, V_X6P, V_X6C, V_PP, V_PP16, V_FR16, V_FR16_S1])
 def test_sweep2_padded_pitch(orc, variant):
     """Rows padded to 32 pixels (SGS_OPT_OUT_PITCH): every pair is interior, no stagger."""
     _gate(variant)
@@ -122,7 +121,7 @@ def test_sweep2_padded_pitch(orc, variant):
         raster.OUTPUT_PITCH_ALIGN = 0
 
 
-@pytest.mark.parametrize("V", [V_X6P, V_PP, V_PP16, V_FR16, V_FR16_S1, V_FR16_S2])
+@pytest.mark.parametrize("V", [V_X6P, V_PP, V_PP16, V_FR16, V_FR16_S1])
 def test_sweep2_deterministic_under_load(orc, V):
     """The same frame 300 times with two other views in flight on other streams: every feature map bit-identical
     (a stale ring stage -- a bundle consumed before it landed -- would show up as a differing map)."""
@@ -176,8 +175,8 @@ def test_x16_sweep_forms_agree_bitwise():
             assert torch.equal(d, _hip_forward(scene, cam, variant=0x10006 | (segn << 4))[1]), ("lock step", P, C, W, H, segn)
             assert torch.equal(d, _hip_forward(scene, cam, variant=0x10004 | (segn << 4))[1]), ("free running", P, C, W, H, segn)
             # round 6: where a finished pair's stores are issued (the steps then pair pixel blocks 0, 2 | 1, 3) changes no sum's order
-            assert torch.equal(d, _hip_forward(scene, cam, variant=0x110004 | (segn << 4))[1]), ("store placement 1", P, C, W, H, segn)
-            assert torch.equal(d, _hip_forward(scene, cam, variant=0x210004 | (segn << 4))[1]), ("store placement 2", P, C, W, H, segn)
+            assert torch.equal(d, _hip_forward(scene, cam, variant=0x110004 | (segn << 4))[1]), ("store placement 1 (the default word)", P, C, W, H, segn)
+            assert torch.equal(d, _hip_forward(scene, cam, variant=0x10004 | (segn << 4))[1]), ("round 5's default", P, C, W, H, segn)
 
 
 def test_cooperative_split_equals_presplit_bitwise():
