@@ -67,6 +67,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: its wheel ships its own libamdhip64.so (SONAME libamdhip64.so.7, requested by torch's libraries under the unversioned file
+    # name).  Loaded after it, libsgs_hip.so's DT_NEEDED libamdhip64.so.7 resolves to that same runtime; loaded BEFORE it, the loader would
+    # take /opt/rocm's copy for this library and torch would still bring its own -- two HIP runtimes in one process, and every stream or
+    # pointer torch hands to this library would belong to the other one ("no ROCm-capable device is detected" from the first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
