@@ -17,7 +17,7 @@ cd $R
 python bench.py 2> $O/bench_default.err > $O/bench_default.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/bench.py --views 1 --fixed-camera --no-cpu-baseline --no-extras --steps 100 --warmup 4 \
+rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/bench.py --views 1 --fixed-camera --no-cpu-baseline --no-extras --steps 600 --warmup 4 \
 	> $O/bench_views1_under_rocprof.json 2> $O/bench_views1_under_rocprof.err
 db=$(find /tmp/kt -name "*results.db" | head -1)
 python $R/tools/rocpd_summary.py $db > $O/kernel_stats_views1.txt
