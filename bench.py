@@ -668,12 +668,13 @@ def main():
         log(f"torch max allocated {mem['max_allocated_GB']:.2f} GB, reserved {mem['reserved_GB']:.2f} GB")
 
     # ---- one view in flight in STEADY STATE: the same leg as sv_cold, measured right behind the timed region (seconds of continuous GPU work).
-    # Round 6: the leg at the top of the process reads the sweep 5-6 % slower than every later one (1.003 vs 0.946 ms in one process,
-    # profiles/r06_bench_default.json of call G: clocks, page tables and allocator are still settling 0.4 s in); the roofline is quoted on
-    # the kernels' durations in the state the timed region runs in, the cold leg stays in the line as `single_view_cold`.
+    # Round 6: 24 forwards at the top of the process are a 40-ms window, and the sweep's duration wanders by +-3 % over a process's life on these
+    # boxes (call G: 1.003 ms there against 0.946 in the legs behind the headline; call I: 0.97 there against 1.00 right behind it -- clocks under
+    # a changing load).  The roofline is therefore quoted on 200 forwards right behind the timed region, the state the timed region runs in; the short
+    # leg at the top stays in the line as `single_view_cold`, and the rocprofv3 average over a whole process (profiles/) is the cross-check.
     for p_ in pools:
         p_.clear()
-    sv_default, stage_ms = single_view(args.variant)
+    sv_default, stage_ms = single_view(args.variant, n=200)   # (0.3 s of single-view work: a window long enough to average over the clock's excursions)
     api = api_path() if world == 1 or rank == 0 else None
     if api is not None:
         api["ratio_to_single_view"] = api["ms_median"] / sv_default["ms_median"]   # (both right behind the timed region)
