@@ -1165,7 +1165,8 @@ __global__ __launch_bounds__(512, 2) void blend_accum_sweep3_kernel(
 	// instruction (all eight waves are resident from dispatch; the last matrix phase lies before the final barrier every wave passes)
 	// (both halves of the count are pinned: the lock-step form happens to need 112 VGPRs, the free-running one 104 -- 248 would leave 16
 	// registers per SIMD lane for a foreign wave; tests/test_code_object.py reads the counts back from the built library)
-	if constexpr (MM != 0) asm volatile("" : : : "a143");
+	if constexpr (MM != 0 && !COOP) asm volatile("" : : : "a143");
+	if constexpr (MM != 0 && COOP) asm volatile("" : : : "a139");   // (experiment: the fp32 hand-over form needs 116 VGPRs: 140 + 116 = 256)
 	if constexpr (MM != 0 && FREE) asm volatile("" : : : "v111");
 	if (counter[1] != 0u) return;   // arena overflowed / frame aborted
 	(void)tune;   // (tuning word, bits [19:16] of the blend variant: unused -- call E's placement / priority experiments are settled,
@@ -1806,6 +1807,14 @@ hipError_t launch_accum_sweep3(hipStream_t st, int dbg, const BlendFwdArgs& a, c
 		return hipGetLastError();
 	}
 #undef S3_LAUNCH_MM
+#ifdef SGS_WITH_EXPERIMENTS   // round 6: round 4's fp32 hand-over (the sweep splits the weights one step ahead, sweep nibble 5) on the x16 MFMA, lock step
+	if (tune == 1 && form == 1 && dbg == 0) {
+		hipLaunchKernelGGL((blend_accum_sweep3_kernel<0, 1, true>), dim3(pxcd * 8), dim3(512), 0, st, a.ranges, table,
+				   nbatches, act_id, wgt, a.features, a.bg, a.out, counter, a.W, a.H, a.C, a.gx, nc, seg, nseg,
+				   pxcd, items, a.pitch, trace, order, dealt, tune, a.bands);
+		return hipGetLastError();
+	}
+#endif
 #ifdef SGS_WITH_EXPERIMENTS   // round 6: the ablations / phase clocks of the DEFAULT form (free-running halves on x16), for profiles/r06_sweep_phases.txt
 	if (tune == 1 && form == 2 && (dbg == 1 || dbg == 2 || dbg == 3 || dbg == 4)) {
 #define S3_LAUNCH_FX(D_)                                                                             \

@@ -67,6 +67,30 @@ def test_band_major_partials_equal_the_plain_partial(P, C, W, H, fx, nb, dense):
         raster.release_stream()
 
 
+@pytest.mark.parametrize("variant", [15, 14])
+def test_banded_partial_under_a_variant_without_band_output(variant):
+    """render_partial(bands = n) under a blend variant whose sweep has no band-major output (the exact fp32 sweep, round 2's two-term
+    sweep) used to raise (the library answers SGS_OPT_OUT_BANDS with SGS_EINVAL there); it now renders row-major and cuts the same bands."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import small_scene
+    from sgs_hip import raster, dist as sdist
+    C, W, H, nb = 128, 208, 160, 3
+    scene, cam = small_scene(P=4000, C=C, W=W, H=H, fx=170.0, seed=5)
+    s, c = scene.to(DEV), cam.to(DEV)
+    args = (s.means3D, s.features, s.opacities, s.scales, s.rotations, c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy,
+            H, W, c.camera_center)
+    raster.set_blend_variant(variant)
+    try:
+        bands, tb, rb = raster.render_partial(*args, bands=nb)
+        plain, tp, rp = raster.render_partial(*args)
+    finally:
+        raster.set_blend_variant(0)
+    assert isinstance(bands, list) and len(bands) == nb and torch.equal(tb, tp) and torch.equal(rb, rp)
+    for b in range(nb):
+        lo, hi = sdist.band_rows(H, b, nb)
+        assert bands[b].is_contiguous() and torch.equal(bands[b], plain[:, lo:hi])
+
+
 def test_band_major_partial_of_an_empty_shard():
     """A depth slab with nothing in front of the camera (num_rendered == 0: the forward takes its no-work-list path) still hands over
     band-major zeros with transmittance one -- the shape the exchange expects from every rank."""
