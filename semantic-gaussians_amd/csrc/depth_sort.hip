@@ -24,6 +24,7 @@ namespace {
 
 constexpr int DS_ITEMS = DS_TILE / 256;   // keys per thread of the counting kernels (256 threads)
 constexpr int DS_WAVES_DEFAULT = 16;
+constexpr bool DS_CHAIN_DEFAULT = false;
 
 // exclusive scan of one value per thread over the FIRST 256 threads of the workgroup (one per digit); *total = sum.  Every thread of the
 // workgroup calls it (two barriers); the result is meaningless for threads >= 256.
@@ -59,16 +60,31 @@ __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t* s_tmp, uint
 // NW = waves per workgroup (round 6).  A tile is 4096 keys whatever NW is; with 4 waves (rounds 2-5) a compute unit holds ONE workgroup of four
 // waves that walks through five barrier-separated phases of dependent latencies -- 17 us per pass for 8 MB of traffic.  16 waves x 4 keys per
 // lane shorten every phase (4 ballot rounds instead of 16, a quarter of the LDS reorder and of the scatter per wave) at the price of a 16-row wave prefix.
-template <int PASS, bool SPAN, int NW>
+// CHAIN (round 6, SGS_DS_CHAIN=1): the three counting kernels are gone.  Pass 0 (its own matrices still come from preprocess) also builds the GLOBAL
+// histograms of digits 1 .. 3 -- they do not depend on the order the later passes will see the keys in -- and a pass p >= 1 counts its own tile's digits
+// (the ballot ranking has them anyway), publishes the row as FLAG | count words (and n << 24 | sum into the group row) and reads the rows of the tiles
+// in front of it as they appear.  A single 32-bit word carries flag and value, so no fence is involved (device-scope relaxed atomics: an XCD's L2 is
+// not coherent with the other seven); a workgroup takes its tile from a ticket, so whatever it waits for belongs to a workgroup that is already running.
+constexpr uint32_t DS_FLAG = 0x80000000u;
+__device__ __forceinline__ uint32_t ds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int PASS, bool SPAN, int NW, bool CHAIN>
 __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 	int P, int groups, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-	uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ cnt,
-	const uint32_t* __restrict__ gcnt, DepthSortSpanOut so)
+	uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* cnt,
+	uint32_t* gcnt, DepthSortSpanOut so, uint32_t* chain)
 {
 	constexpr int SHIFT = 8 * PASS;
 	constexpr int NT = 64 * NW, ITEMS = DS_TILE / NT;
-	const int k = blockIdx.x;
+	constexpr bool WAITS = CHAIN && PASS > 0;   // this pass makes its own count matrix and waits for the rows in front of its tile
 	const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	int k = blockIdx.x;
+	if constexpr (WAITS) {
+		__shared__ int s_ticket;
+		if (t == 0) s_ticket = (int)__hip_atomic_fetch_add(&chain[3 * 256 + PASS - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+		k = s_ticket;
+	}
 	__shared__ uint32_t s_hist[NW][256];  // per wave: keys per digit, then the wave's start inside the tile's digit run
 	__shared__ uint32_t s_base[256];      // output position of the tile's first key of each digit
 	__shared__ uint32_t s_excl[256];      // start of each digit's run inside the reordered tile
@@ -90,7 +106,7 @@ __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 
 	// ---- where the tile's keys of digit d start in the output: all keys with a smaller digit, plus the keys of
 	// digit d in earlier tiles (whole groups from gcnt, the tiles of this tile's own group from cnt)
-	{
+	if constexpr (!WAITS) {
 		const int grp = k / DS_GRP;
 		uint32_t tot = 0, pre = 0;
 		if (t < 256) {
@@ -103,6 +119,23 @@ __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 		}
 		const uint32_t start = wg_scan256(tot, s_tmp, nullptr);
 		if (t < 256) s_base[t] = start + pre;
+	}
+	if constexpr (CHAIN && PASS == 0) {   // the global histograms of digits 1 .. 3, for the passes behind this one
+		__shared__ uint32_t s_gh[3][256];
+		for (int q = t; q < 3 * 256; q += NT) (&s_gh[0][0])[q] = 0u;
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < ITEMS; i++)
+			if (first + 64u * i < (uint32_t)P) {
+				atomicAdd(&s_gh[0][(key[i] >> 8) & 255u], 1u);
+				atomicAdd(&s_gh[1][(key[i] >> 16) & 255u], 1u);
+				atomicAdd(&s_gh[2][key[i] >> 24], 1u);
+			}
+		__syncthreads();
+		for (int q = t; q < 3 * 256; q += NT) {
+			const uint32_t c = (&s_gh[0][0])[q];
+			if (c) atomicAdd(&chain[q], c);
+		}
 	}
 	__syncthreads();   // s_hist zeroed (wg_scan256 has barriers too; this one is for clarity)
 
@@ -143,8 +176,48 @@ __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 				run += hv;
 			}
 		}
+		if constexpr (WAITS) {   // publish this tile's row first: the tiles behind it are waiting for it
+			if (t < 256) {
+				__hip_atomic_store(&cnt[(size_t)k * 256 + t], DS_FLAG | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_fetch_add(&gcnt[(size_t)(k / DS_GRP) * 256 + t], (1u << 24) | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
 		const uint32_t ex = wg_scan256(run, s_tmp, nullptr);
 		if (t < 256) s_excl[t] = ex;
+		if constexpr (WAITS) {
+			const uint32_t gh = t < 256 ? chain[(size_t)(PASS - 1) * 256 + t] : 0u;   // (complete: pass 0's kernel has ended)
+			const uint32_t start = wg_scan256(gh, s_tmp, nullptr);
+			if (t < 256) {
+				const int grp = k / DS_GRP;
+				uint32_t pre = 0;
+				// whole groups in front (each holds DS_GRP tiles: complete when its contribution count says so), then the tiles of this group
+				const int nitems = grp + (k - grp * DS_GRP);
+				for (int b = 0; b < nitems; b += 8) {
+					uint32_t w[8];
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						const int it = b + j;
+						const uint32_t* ptr = it < grp ? &gcnt[(size_t)it * 256 + t] : &cnt[(size_t)(grp * DS_GRP + (it - grp)) * 256 + t];
+						w[j] = it < nitems ? ds_ld(ptr) : 0u;
+					}
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						const int it = b + j;
+						if (it >= nitems) continue;
+						const bool is_grp = it < grp;
+						const uint32_t* ptr = is_grp ? &gcnt[(size_t)it * 256 + t] : &cnt[(size_t)(grp * DS_GRP + (it - grp)) * 256 + t];
+						int spins = 0;
+						while (is_grp ? (w[j] >> 24) != (uint32_t)DS_GRP : (w[j] & DS_FLAG) == 0u) {
+							if (++spins > (1 << 24)) __builtin_trap();   // (a protocol error must not hang the device)
+							__builtin_amdgcn_s_sleep(1);
+							w[j] = ds_ld(ptr);
+						}
+						pre += is_grp ? (w[j] & 0xFFFFFFu) : (w[j] & ~DS_FLAG);
+					}
+				}
+				s_base[t] = start + pre;
+			}
+		}
 	}
 	__syncthreads();
 
@@ -287,6 +360,7 @@ void depth_sort_layout(int P, DepthSortLayout* lay)
 	lay->tiles = tiles;
 	lay->groups = groups;
 	lay->counts = take((size_t)4 * ((size_t)tiles + groups) * 256 * 4);   // 4 passes x (tile rows | group rows)
+	lay->chain = take((size_t)(3 * 256 + 4) * 4);                         // ghist of digits 1 .. 3 | tickets of passes 1 .. 3 (cleared with the matrices)
 	lay->counts_bytes = off - lay->counts;
 	lay->keys[0] = take((size_t)P * 4);
 	lay->keys[1] = take((size_t)P * 4);
@@ -315,18 +389,22 @@ hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, 
 	const DepthSortSpanOut none{};
 	// waves per workgroup of the passes: SGS_DS_WAVES = 4 (rounds 2-5) | 8 | 16 (read once); default in DS_WAVES_DEFAULT
 	static const int nw = [] { const char* e = getenv("SGS_DS_WAVES"); const int v = e ? atoi(e) : DS_WAVES_DEFAULT; return (v == 4 || v == 8 || v == 16) ? v : DS_WAVES_DEFAULT; }();
+	// SGS_DS_CHAIN=1 (read once; round 6): the passes count their own digits and wait for the rows in front of their tile -- no counting kernels
+	static const bool chain_on = [] { const char* e = getenv("SGS_DS_CHAIN"); return e ? (*e && *e != '0') : DS_CHAIN_DEFAULT; }();
+	uint32_t* chain = (uint32_t*)(scratch + lay.chain);
 #define DS_PASS(PASS_, SPAN_, KI_, VI_, KO_, VO_, C_, G_, SO_)                                                                        \
 	do {                                                                                                                               \
-		if (nw == 16) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_); \
-		else if (nw == 8) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 8>), grid, dim3(512), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_); \
-		else hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 4>), grid, dim3(256), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_); \
+		if (chain_on) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, true>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
+		else if (nw == 16) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, false>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
+		else if (nw == 8) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 8, false>), grid, dim3(512), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
+		else hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 4, false>), grid, dim3(256), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
 	} while (0)
 	DS_PASS(0, false, depth_bits, (const uint32_t*)nullptr, kA, vA, cnt[0], gcnt[0], none);
-	hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1]);
+	if (!chain_on) hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1]);
 	DS_PASS(1, false, kA, vA, kB, vB, cnt[1], gcnt[1], none);
-	hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2]);
+	if (!chain_on) hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2]);
 	DS_PASS(2, false, kB, vB, kA, vA, cnt[2], gcnt[2], none);
-	hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3]);
+	if (!chain_on) hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3]);
 	if (span) DS_PASS(3, true, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], *span);
 	else DS_PASS(3, false, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], none);
 #undef DS_PASS

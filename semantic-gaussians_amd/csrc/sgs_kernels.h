@@ -25,6 +25,7 @@ struct DepthSortLayout {        // byte offsets inside the sort's scratch
 	size_t counts, counts_bytes;   // 4 passes x (tiles + groups) rows of 256 counters; must be ZERO before pass 0's
 	                               // matrices are filled (preprocess.hip does that, with atomics)
 	size_t keys[2], vals[2], total;
+	size_t chain;                  // (round 6, inside the zeroed counts region) ghist[3][256] | ticket[4]: the chained passes' global digit histograms and tile tickets
 	int tiles, groups;
 };
 struct DepthSortSpanOut {   // optional by-product of the last pass: what binning_rows.hip's span_counts_kernel writes
