@@ -183,7 +183,7 @@ struct Carver {
 struct GeomLayout {
 	sgs_geometry_layout pub;
 	size_t scan_temp, scan_temp_bytes, trap_flag, count_rec, total;
-	size_t totals64, stage_a_tab;   // inside trap_flag's 128-byte block (geom_layout)
+	size_t totals64, stage_a_tab, span_tickets;   // inside trap_flag's 128-byte block (geom_layout)
 	size_t ds;                     // depth_sort.hip scratch, directly behind trap_flag's 128 bytes (one memset clears both)
 	sgs::DepthSortLayout ds_lay;
 	// depth presort of the Gaussians (binning modes 0 and 2)
@@ -212,7 +212,8 @@ GeomLayout geom_layout(int P)
 	g.trap_flag = c.take(128);   // one 128-byte block, cleared by one memset: [0] trap word | [64] 64-bit totals (major instances << 32 | instances) | [80] stage A's six table words
 	g.totals64 = g.trap_flag + 64;
 	g.stage_a_tab = g.trap_flag + 80;
-	static_assert(80 + 6 * 4 <= 128 && 64 + 8 <= 80, "the trap block's fields overlap");
+	g.span_tickets = g.trap_flag + 104;   // (round 6) the span partitions' two role tickets
+	static_assert(80 + 6 * 4 <= 104 && 104 + 2 * 4 <= 128 && 64 + 8 <= 80, "the trap block's fields overlap");
 	sgs::depth_sort_layout(P, &g.ds_lay);
 	g.ds = c.take(g.ds_lay.total);   // (128-aligned: starts right behind trap_flag; its count matrices come first)
 	g.perm = c.take(p * 4);
@@ -393,6 +394,8 @@ inline uint32_t grow_hint(uint32_t hint, uint32_t used)
 // that call, attributed to "forward" / "backward".  The reference synchronises after EVERY stage; its own render_chn
 // passes debug=True unconditionally (model/renderer.py:182), so that behaviour would put ~8 host round trips into
 // every production frame (+0.15 ms at the headline size).  SGS_DEBUG_SYNC_EVERY_STAGE=1 restores it for fault hunting.
+// SGS_SPAN_CHAIN=0 (read once; A/B switch): the span partitions' one-workgroup scans as kernels of their own (rounds 2-5)
+static const bool g_span_chain = [] { const char* e = getenv("SGS_SPAN_CHAIN"); return e ? (*e && *e != '0') : true; }();
 static const bool g_sync_every_stage = [] { const char* e = getenv("SGS_DEBUG_SYNC_EVERY_STAGE"); return e && *e && *e != '0'; }();
 #define SGS_CHECK_STAGE(what)                                                             \
 	do {                                                                              \
@@ -881,7 +884,8 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
 					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list,
 					    abort_word, use_split ? (uint32_t*)(bchunk + bl.arena + bl.arena_lay.counter) : nullptr,
-					    (uint32_t)ntiles * 128u, (const uint32_t*)(gchunk + gl.stage_a_tab));
+					    (uint32_t)ntiles * 128u, (const uint32_t*)(gchunk + gl.stage_a_tab),
+					    g_span_chain ? (uint32_t*)(gchunk + gl.span_tickets) : nullptr);
 		counter_reset_done = use_split && Rrows != 0;   // (launch_row_binning with R == 0 is just a memset)
 		if (e != hipSuccess) return fail_hip(e, "row binning");
 		SGS_CHECK_STAGE("row binning");

@@ -5,6 +5,7 @@
 //
 // Why not the library sort.  rocPRIM's onesweep on 1M keys is 5 kernels + 9 buffer fills = 0.19 ms of a 1.7 ms
 // frame, all of it launch / latency bound (profiles/r02h_kernel_stats_views1.txt).  This one is seven small kernels
+// (round 6: FOUR -- the passes count their own digits and chain on flagged count words, see CHAIN below)
 // and no fill of its own, built for this size class (P ~ 10^5 .. 10^7):
 //   * least-significant-digit radix sort, 8-bit digits, a workgroup per tile of 4096 keys;
 //   * where a workgroup's keys go needs, per digit, the number of keys with that digit in all EARLIER tiles.  There is
@@ -24,7 +25,7 @@ namespace {
 
 constexpr int DS_ITEMS = DS_TILE / 256;   // keys per thread of the counting kernels (256 threads)
 constexpr int DS_WAVES_DEFAULT = 16;
-constexpr bool DS_CHAIN_DEFAULT = false;
+constexpr bool DS_CHAIN_DEFAULT = true;   // (SGS_DS_CHAIN=0: rounds 2-5's form with its three counting kernels)
 
 // exclusive scan of one value per thread over the FIRST 256 threads of the workgroup (one per digit); *total = sum.  Every thread of the
 // workgroup calls it (two barriers); the result is meaningless for threads >= 256.

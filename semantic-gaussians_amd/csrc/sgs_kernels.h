@@ -72,7 +72,7 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
 			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort = nullptr,
 			      uint32_t* arena_counter = nullptr, uint32_t arena_first_free = 0,
-			      const uint32_t* stage_a_tab = nullptr);   // stage_a_tab: DepthSortSpanOut::stage_a_tab, already written (else a table kernel runs)
+			      const uint32_t* stage_a_tab = nullptr, uint32_t* tickets2 = nullptr);   // tickets2: two ZEROED words -> the chained one-launch-per-stage form of the list scans (round 6)   // stage_a_tab: DepthSortSpanOut::stage_a_tab, already written (else a table kernel runs)
 // chunks / scan groups of stage A (the P ranked Gaussians as one segment): what DepthSortSpanOut::stage_a_chunks / _groups must hold
 void row_binning_stage_a_counts(int P, uint32_t* chunks, uint32_t* groups);   // optional: also reset the split blend's counter
 void launch_reconstruct_keys_ranges(hipStream_t st, int ntiles, const uint2* ranges, const uint32_t* point_list,

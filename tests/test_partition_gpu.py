@@ -98,6 +98,39 @@ def test_partitioned_forward_feeds_the_backward(orc):
         ps.close()
 
 
+@pytest.mark.parametrize("cus", [4, 32])
+@pytest.mark.parametrize("kind", ["random", "depth"])
+def test_chained_sort_passes_on_a_few_compute_units(cus, kind):
+    """Round 6: the depth sort's passes 1 .. 3 wait, inside the kernel, for the count rows of the tiles in front of theirs (csrc/depth_sort.hip CHAIN).
+    A workgroup takes its tile from a ticket, so what it waits for always belongs to a workgroup that is already running -- also when only a handful
+    of the 245 (1 M keys) / 733 (3 M keys) workgroups are resident at a time: here the sort runs on a stream confined to 4 / 32 compute units."""
+    import ctypes as C
+    from sgs_hip import _lib
+    lib = _lib.load()
+    st = C.c_void_p()
+    assert lib.sgs_stream_create_cu_range(0, cus, C.byref(st)) == 0
+    try:
+        for P in (1_000_000, 3_000_001):
+            g = torch.Generator(device=DEV).manual_seed(P + cus)
+            if kind == "random":
+                keys = torch.randint(0, 2 ** 32, (P,), device=DEV, generator=g, dtype=torch.int64)
+            else:
+                keys = (0.2 + 60.0 * torch.rand(P, device=DEV, generator=g)).view(torch.int32).to(torch.int64)
+                keys[torch.rand(P, device=DEV, generator=g) < 0.1] = 0xFFFFFFFF
+            want = torch.sort(keys, stable=True).indices.to(torch.int32)
+            k32 = torch.where(keys >= 2 ** 31, keys - 2 ** 32, keys).to(torch.int32)   # same bits as uint32
+            need = lib.sgs_debug_depth_sort(P, None, None, None, None)
+            scratch = torch.empty(need, dtype=torch.uint8, device=DEV)
+            perm = torch.full((P,), -1, dtype=torch.int32, device=DEV)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                assert lib.sgs_debug_depth_sort(P, k32.data_ptr(), perm.data_ptr(), scratch.data_ptr(), st) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(perm, want)
+    finally:
+        lib.sgs_stream_destroy(st)
+
+
 def test_cu_range_arguments():
     from sgs_hip import raster, _lib
     import ctypes as C
