@@ -190,12 +190,9 @@ __global__ __launch_bounds__(512) void span_hist_group_kernel(
 	int nb, int nseg, const uint32_t* __restrict__ segstart, const uint32_t* __restrict__ chunk0,
 	const uint2* __restrict__ items, const uint4* __restrict__ rrec, uint32_t* __restrict__ cmat,
 	const uint32_t* __restrict__ grp0, uint32_t* __restrict__ gtot, uint4* __restrict__ desc,
-	const uint32_t* __restrict__ abort, uint32_t* __restrict__ clear_ptr, int clear_n)
+	const uint32_t* __restrict__ abort)
 {
 	if (abort && *abort != 0u) return;
-	// (round 6, stage A's launch only) the list-length words the chained scans hand over as FLAG | length start the frame unflagged: the buffer
-	// is the caller's resident scratch and still holds the previous frame's
-	for (int q = blockIdx.x * 512 + threadIdx.x; q < clear_n; q += gridDim.x * 512) clear_ptr[q] = 0u;
 	extern __shared__ int s_cov[];   // [RGRP chunks][nb + 1]: difference arrays, then coverage counts
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -422,150 +419,11 @@ __global__ __launch_bounds__(1024) void stage_a_lists_kernel(int nb, const uint3
 // __threadfence() pair around the ticket the 1 236-workgroup stage-B kernel took 129 us instead of 5 + 9 (an XCD's L2 is not coherent with the other
 // seven: an agent-scope fence is a whole-L2 write-back + invalidate per workgroup); with the hand-over on device-scope word atomics instead of fences it
 // still cost 8 us MORE than the two kernels it replaced -- the tail workgroup's 256 threads scan 4 941 lengths with L2-bypassing loads where the dedicated
-// kernel has 1 024 threads and a warm L2, and two launches of back-to-back kernels on one stream cost almost nothing.  profiles/r06_front_end_ab.txt.)
-
-// ---- round 6: the one-workgroup scans ride in the kernel in front of them, CHAINED (the form that works; the two that did not are in the
-// comment above).  span_scan_lists_chain_kernel = span_scan_lists_kernel in 16-list workgroups + ONE more workgroup that does what
-// stage_a_lists_kernel (stage A) / list_scan_kernel<true> (stage B) did.  The roles are dealt by a ticket, the LAST ticket is the scanner: every
-// producer is running (or done) when it starts, so it waits for nothing that could wait for it.  A length is handed over as ONE word,
-// DS-style: SPAN_FLAG | length, written and polled with device-scope relaxed atomics -- no fence, no last-block serialisation, and the scanner's
-// 1 024 threads poll while the producers are still working.  (lengths < 2^31: they are bounded by num_rendered.)
-constexpr uint32_t SPAN_FLAG = 0x80000000u;
-constexpr int CHAIN_MAX_LISTS = 8192;   // the scanner keeps the lengths in LDS (32 KB); larger grids take the two-kernel form
-__device__ __forceinline__ uint32_t span_poll(const uint32_t* p)
-{
-	uint32_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	int spins = 0;
-	while ((w & SPAN_FLAG) == 0u) {
-		if (++spins > (1 << 24)) __builtin_trap();   // (a protocol error must not hang the device)
-		__builtin_amdgcn_s_sleep(1);
-		w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-	return w & ~SPAN_FLAG;
-}
-
-template <bool STAGE_A>
-__global__ __launch_bounds__(1024) void span_scan_lists_chain_kernel(int nb, int nseg, const uint32_t* __restrict__ grp0,
-								      uint32_t* __restrict__ gtot, int seg_stride, int bin_stride,
-								      uint32_t* listlen, const uint32_t* __restrict__ abort, uint32_t* ticket,
-								      // stage A's scanner
-								      uint32_t* __restrict__ segB, uint32_t* __restrict__ chunk0B, uint32_t* __restrict__ grp0B,
-								      // stage B's scanner
-								      uint2* __restrict__ ranges, uint32_t* __restrict__ tstart, int gx, int major_x,
-								      uint32_t* __restrict__ arena_counter, uint32_t first_free)
-{
-	if (abort && *abort != 0u) {   // (aborted frame: every blend kernel exits on the counter's second word)
-		if (!STAGE_A && arena_counter && blockIdx.x == 0 && threadIdx.x == 0) {
-			arena_counter[0] = first_free;
-			arena_counter[1] = 2u;
-		}
-		return;
-	}
-	__shared__ uint32_t s_role;
-	if (threadIdx.x == 0) s_role = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__syncthreads();
-	const uint32_t role = s_role;
-	const int nlists = nb * nseg;
-	const uint32_t nprod = (uint32_t)((nlists + 15) / 16);
-	const int lane = threadIdx.x & 63;
-	if (role < nprod) {   // ---- producer: one wave per list (span_scan_lists_kernel)
-		const int t = (int)role * 16 + (int)(threadIdx.x >> 6);
-		if (t >= nlists) return;
-		const int s = t / nb, b = t - s * nb;
-		const uint32_t g0 = grp0[s], n = grp0[s + 1] - g0;
-		const uint32_t per = (n + 63) / 64;
-		const uint32_t beg = (uint32_t)lane * per < n ? (uint32_t)lane * per : n;
-		const uint32_t end = beg + per < n ? beg + per : n;
-		uint32_t sum = 0;
-		for (uint32_t i = beg; i < end; i++) sum += gtot[(size_t)(g0 + i) * nb + b];
-		uint32_t incl = sum;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
-			if (lane >= o) incl += u;
-		}
-		uint32_t run = incl - sum;
-		for (uint32_t i = beg; i < end; i++) {
-			const uint32_t v = gtot[(size_t)(g0 + i) * nb + b];
-			gtot[(size_t)(g0 + i) * nb + b] = run;
-			run += v;
-		}
-		if (lane == 63) __hip_atomic_store(&listlen[s * seg_stride + b * bin_stride], SPAN_FLAG | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		return;
-	}
-	// ---- the scanner (the last ticket): the lengths as they appear, into LDS
-	__shared__ uint32_t s_len[CHAIN_MAX_LISTS];
-	__shared__ uint32_t s_part[1024];
-	for (int t = threadIdx.x; t < nlists; t += 1024) s_len[t] = span_poll(&listlen[t]);
-	__syncthreads();
-	if (STAGE_A) {   // stage_a_lists_kernel: nb <= 2048 bins, thread t owns bins 2 t, 2 t + 1
-		const int b0 = 2 * (int)threadIdx.x;
-		const uint32_t v0 = b0 < nb ? s_len[b0] : 0u, v1 = b0 + 1 < nb ? s_len[b0 + 1] : 0u;
-		s_part[threadIdx.x] = v0 + v1;
-		__syncthreads();
-		for (int off = 1; off < 1024; off <<= 1) {
-			const uint32_t a = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
-			__syncthreads();
-			s_part[threadIdx.x] += a;
-			__syncthreads();
-		}
-		const uint32_t start = s_part[threadIdx.x] - (v0 + v1);
-		if (b0 < nb) segB[b0] = start;
-		if (b0 + 1 < nb) segB[b0 + 1] = start + v0;
-		if (threadIdx.x == 1023) segB[nb] = s_part[1023];
-		__shared__ unsigned long long s_cg[1024];
-		const uint32_t nc0 = (v0 + RCH - 1) / RCH, nc1 = (v1 + RCH - 1) / RCH;
-		const unsigned long long cg0 = ((unsigned long long)nc0 << 32) | (unsigned long long)((nc0 + RGRP - 1) / RGRP);
-		const unsigned long long cg1 = ((unsigned long long)nc1 << 32) | (unsigned long long)((nc1 + RGRP - 1) / RGRP);
-		s_cg[threadIdx.x] = cg0 + cg1;
-		__syncthreads();
-		for (int off = 1; off < 1024; off <<= 1) {
-			const unsigned long long a = (int)threadIdx.x >= off ? s_cg[threadIdx.x - off] : 0ull;
-			__syncthreads();
-			s_cg[threadIdx.x] += a;
-			__syncthreads();
-		}
-		const unsigned long long cgs = s_cg[threadIdx.x] - (cg0 + cg1);
-		if (b0 < nb) {
-			chunk0B[b0] = (uint32_t)(cgs >> 32);
-			grp0B[b0] = (uint32_t)cgs;
-		}
-		if (b0 + 1 < nb) {
-			chunk0B[b0 + 1] = (uint32_t)((cgs + cg0) >> 32);
-			grp0B[b0 + 1] = (uint32_t)(cgs + cg0);
-		}
-		if (threadIdx.x == 1023) {
-			chunk0B[nb] = (uint32_t)(s_cg[1023] >> 32);
-			grp0B[nb] = (uint32_t)s_cg[1023];
-		}
-	} else {   // list_scan_kernel<true>: ranges, the segment-major list starts, the blend's work-list counter
-		if (arena_counter && threadIdx.x == 0) {
-			arena_counter[0] = first_free;
-			arena_counter[1] = 0u;
-		}
-		const int n = nlists;
-		const int per = (n + 1023) / 1024;
-		const int t0 = (int)threadIdx.x * per < n ? (int)threadIdx.x * per : n, t1 = (t0 + per < n) ? t0 + per : n;
-		uint32_t sum = 0;
-		for (int t = t0; t < t1; t++) sum += s_len[t];
-		s_part[threadIdx.x] = sum;
-		__syncthreads();
-		for (int off = 1; off < 1024; off <<= 1) {
-			const uint32_t v = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
-			__syncthreads();
-			s_part[threadIdx.x] += v;
-			__syncthreads();
-		}
-		uint32_t run = s_part[threadIdx.x] - sum;
-		for (int t = t0; t < t1; t++) {
-			const uint32_t m = s_len[t];
-			ranges[t] = m ? make_uint2(run, run + m) : make_uint2(0u, 0u);
-			const int x = t % gx, y = t / gx;
-			tstart[(major_x ? x : y) * nb + (major_x ? y : x)] = run;
-			run += m;
-		}
-	}
-}
+// kernel has 1 024 threads and a warm L2, and two launches of back-to-back kernels on one stream cost almost nothing.  profiles/r06_front_end_ab.txt.
+// A third form -- the depth sort's recipe, which DID pay there: roles dealt by a ticket, the last ticket a dedicated 1 024-thread scanner workgroup that polls
+// the lengths as FLAG | length words while the producers are still working -- was correct (141 tests) and 15 us slower per frame than the four small
+// kernels (stage A 23.7 us instead of 9.0 + 5.3, stage B 15.1 instead of 4.9 + 9.0, profiles/r06_span_chain.txt): the producers' ticket and the scanner's
+// polls are L2-bypassing round trips in front of work that takes a few microseconds.  Removed as well.)
 
 // the ballot sweep: every covering item is written to its final position in the list of
 // (segment, bin).  OUT_ITEMS: stage A (the item with its payload span); else the Gaussian id.
@@ -705,7 +563,7 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
 			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort,
-			      uint32_t* arena_counter, uint32_t arena_first_free, const uint32_t* stage_a_tab, uint32_t* tickets2)
+			      uint32_t* arena_counter, uint32_t arena_first_free, const uint32_t* stage_a_tab)
 {
 	const int ntiles = gx * gy;
 	if (R == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st);
@@ -735,28 +593,20 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	const size_t ldsSA = nwA * ldsWA, ldsSB = nwB * ldsWB;
 
 	// ---- stage A: ranked Gaussians -> major instances grouped by major bin
-	// tickets2 (two ZEROED words): the chained form -- the per-list prefix and the one-workgroup scan behind it in ONE launch per stage
-	const bool chain = tickets2 != nullptr && ntiles <= CHAIN_MAX_LISTS && nbA <= HG_NB_MAX && nbB <= HG_NB_MAX;
 	if (!stage_a_tab) hipLaunchKernelGGL(seg_tables_kernel, dim3(1), dim3(64), 0, st, 1, (uint32_t)P, segA, true, chunk0A, grp0A, abort);
 	if (nbA <= HG_NB_MAX) {
 		hipLaunchKernelGGL(span_hist_group_kernel<true>, dim3(grA), dim3(512), (size_t)RGRP * (nbA + 1) * 4, st, nbA, 1,
-				   segA, chunk0A, (const uint2*)nullptr, rrec, cmat, grp0A, gtot, desc, abort, chain ? lens : (uint32_t*)nullptr,
-				   chain ? ntiles + nbA + 2 : 0);
+				   segA, chunk0A, (const uint2*)nullptr, rrec, cmat, grp0A, gtot, desc, abort);
 	} else {
 		hipLaunchKernelGGL(span_hist_kernel<true>, dim3((chA + 3) / 4), dim3(256), ldsA, st, nbA, 1, segA, chunk0A,
 				   (const uint2*)nullptr, rrec, cmat, grp0A, desc, abort);
 		hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grA * nbA + 255) / 256)), dim3(256), 0, st,
 				   nbA, 1, chunk0A, grp0A, cmat, gtot, abort);
 	}
-	if (chain) {
-		hipLaunchKernelGGL(span_scan_lists_chain_kernel<true>, dim3((nbA + 15) / 16 + 1), dim3(1024), 0, st, nbA, 1, grp0A, gtot, 0, 1, binlen, abort,
-				   tickets2, segB, chunk0B, grp0B, (uint2*)nullptr, (uint32_t*)nullptr, gx, major_x, (uint32_t*)nullptr, 0u);
-	} else {
-		hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
-				   binlen, abort);
-		// (the bin lengths' scan = stage B's segment starts, and stage B's chunk / group tables: one launch)
-		hipLaunchKernelGGL(stage_a_lists_kernel, dim3(1), dim3(1024), 0, st, nbA, binlen, segB, chunk0B, grp0B, abort);
-	}
+	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((nbA + 3) / 4), dim3(256), 0, st, nbA, 1, grp0A, gtot, 0, 1,
+			   binlen, abort);
+	// (the bin lengths' scan = stage B's segment starts, and stage B's chunk / group tables: one launch)
+	hipLaunchKernelGGL(stage_a_lists_kernel, dim3(1), dim3(1024), 0, st, nbA, binlen, segB, chunk0B, grp0B, abort);
 #define SGS_SCATTER_A(NW_)                                                                                          \
 	hipLaunchKernelGGL((span_scatter_kernel<true, NW_>), dim3((chA + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)),  \
 			   dim3(64 * NW_), ldsSA, st, nbA, 1, segA, chunk0A, grp0A, (const uint2*)nullptr, rrec,    \
@@ -771,23 +621,17 @@ hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy,
 	const int seg_stride = major_x ? 1 : gx, bin_stride = major_x ? gx : 1;          // tile = y * gx + x
 	if (nbB <= HG_NB_MAX) {
 		hipLaunchKernelGGL(span_hist_group_kernel<false>, dim3(grB), dim3(512), (size_t)RGRP * (nbB + 1) * 4, st, nbB, nbA,
-				   segB, chunk0B, items, rrec, cmat, grp0B, gtot, desc, abort, (uint32_t*)nullptr, 0);
+				   segB, chunk0B, items, rrec, cmat, grp0B, gtot, desc, abort);
 	} else {
 		hipLaunchKernelGGL(span_hist_kernel<false>, dim3((chB + 3) / 4), dim3(256), ldsB, st, nbB, nbA, segB, chunk0B, items,
 				   rrec, cmat, grp0B, desc, abort);
 		hipLaunchKernelGGL(span_scan_groups_kernel, dim3((unsigned)(((size_t)grB * nbB + 255) / 256)), dim3(256), 0, st,
 				   nbB, nbA, chunk0B, grp0B, cmat, gtot, abort);
 	}
-	if (chain) {
-		hipLaunchKernelGGL(span_scan_lists_chain_kernel<false>, dim3((ntiles + 15) / 16 + 1), dim3(1024), 0, st, nbB, nbA, grp0B, gtot, seg_stride,
-				   bin_stride, lens, abort, tickets2 + 1, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ranges, tstart,
-				   gx, major_x, arena_counter, arena_first_free);
-	} else {
-		hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
-				   seg_stride, bin_stride, lens, abort);
-		hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB,
-				   arena_counter, arena_first_free);
-	}
+	hipLaunchKernelGGL(span_scan_lists_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, nbB, nbA, grp0B, gtot,
+			   seg_stride, bin_stride, lens, abort);
+	hipLaunchKernelGGL(list_scan_kernel<true>, dim3(1), dim3(1024), 0, st, ntiles, lens, ranges, tstart, abort, gx, major_x, nbB,
+			   arena_counter, arena_first_free);
 #define SGS_SCATTER_B(NW_)                                                                                          \
 	hipLaunchKernelGGL((span_scatter_kernel<false, NW_>), dim3((chB + NW_ * SCAT_CPW - 1) / (NW_ * SCAT_CPW)), \
 			   dim3(64 * NW_), ldsSB, st, nbB, nbA, segB, chunk0B, grp0B, items, rrec, cmat, gtot,      \

@@ -183,7 +183,7 @@ struct Carver {
 struct GeomLayout {
 	sgs_geometry_layout pub;
 	size_t scan_temp, scan_temp_bytes, trap_flag, count_rec, total;
-	size_t totals64, stage_a_tab, span_tickets;   // inside trap_flag's 128-byte block (geom_layout)
+	size_t totals64, stage_a_tab, cc_done;   // inside trap_flag's 128-byte block (geom_layout)
 	size_t ds;                     // depth_sort.hip scratch, directly behind trap_flag's 128 bytes (one memset clears both)
 	sgs::DepthSortLayout ds_lay;
 	// depth presort of the Gaussians (binning modes 0 and 2)
@@ -212,8 +212,8 @@ GeomLayout geom_layout(int P)
 	g.trap_flag = c.take(128);   // one 128-byte block, cleared by one memset: [0] trap word | [64] 64-bit totals (major instances << 32 | instances) | [80] stage A's six table words
 	g.totals64 = g.trap_flag + 64;
 	g.stage_a_tab = g.trap_flag + 80;
-	g.span_tickets = g.trap_flag + 104;   // (round 6) the span partitions' two role tickets
-	static_assert(80 + 6 * 4 <= 104 && 104 + 2 * 4 <= 128 && 64 + 8 <= 80, "the trap block's fields overlap");
+	g.cc_done = g.trap_flag + 104;        // (round 6) workgroups of the sort's last pass that have added their counts
+	static_assert(80 + 6 * 4 <= 104 && 104 + 4 <= 128 && 64 + 8 <= 80, "the trap block's fields overlap");
 	sgs::depth_sort_layout(P, &g.ds_lay);
 	g.ds = c.take(g.ds_lay.total);   // (128-aligned: starts right behind trap_flag; its count matrices come first)
 	g.perm = c.take(p * 4);
@@ -356,28 +356,10 @@ struct StageTimer {
 	}
 };
 
-// Deferred-count forward: the instance counts stay on the device.  rec = {num_rendered, major instances, trap flag,
-// abort}; abort != 0 (a count exceeds the capacity the buffers were sized for, or the prefiltered trap fired) makes
-// every later kernel of the frame exit.
-// `host` is the stream's pinned record (device-accessible): the kernel writes it directly -- a copy would be one
-// more launch on the frame's critical path.
-__global__ void count_check_kernel(const uint64_t* __restrict__ offs_last, const int* __restrict__ trap_flag,
-				   uint32_t L_cap, uint32_t R_cap, uint32_t* __restrict__ rec, volatile uint32_t* host)
-{
-	const uint64_t rl = *offs_last;
-	const uint64_t L = rl & 0xffffffffull, R = rl >> 32;
-	const uint32_t trap = (uint32_t)*trap_flag;
-	const uint32_t abort = (L > (uint64_t)L_cap || R > (uint64_t)R_cap || trap != 0u) ? 1u : 0u;
-	rec[0] = (uint32_t)L;
-	rec[1] = (uint32_t)R;
-	rec[2] = trap;
-	rec[3] = abort;
-	host[0] = (uint32_t)L;
-	host[1] = (uint32_t)R;
-	host[2] = trap;
-	host[3] = abort;
-	__threadfence_system();
-}
+// Deferred-count forward: the instance counts stay on the device.  rec = {num_rendered, major instances, trap flag, abort}; abort != 0 (a count
+// exceeds the capacity the buffers were sized for, or the prefiltered trap fired) makes every later kernel of the frame exit.  Round 6: the record --
+// on the device and in the stream's pinned host words -- is written by the LAST workgroup of the depth sort's last pass (depth_sort.hip, DepthSortSpanOut::cc_*),
+// which is where the totals are added up; rounds 2-5 had a one-thread kernel for it (one more launch on the frame's critical path).
 
 // capacity guess for a count: 1.25 x what the last frame needed, 64k granularity (stable buffer sizes)
 inline uint32_t grow_hint(uint32_t hint, uint32_t used)
@@ -394,8 +376,6 @@ inline uint32_t grow_hint(uint32_t hint, uint32_t used)
 // that call, attributed to "forward" / "backward".  The reference synchronises after EVERY stage; its own render_chn
 // passes debug=True unconditionally (model/renderer.py:182), so that behaviour would put ~8 host round trips into
 // every production frame (+0.15 ms at the headline size).  SGS_DEBUG_SYNC_EVERY_STAGE=1 restores it for fault hunting.
-// SGS_SPAN_CHAIN=0 (read once; A/B switch): the span partitions' one-workgroup scans as kernels of their own (rounds 2-5)
-static const bool g_span_chain = [] { const char* e = getenv("SGS_SPAN_CHAIN"); return e ? (*e && *e != '0') : true; }();
 static const bool g_sync_every_stage = [] { const char* e = getenv("SGS_DEBUG_SYNC_EVERY_STAGE"); return e && *e && *e != '0'; }();
 #define SGS_CHECK_STAGE(what)                                                             \
 	do {                                                                              \
@@ -717,10 +697,33 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// so absurdly long grid axes (> 32k pixels) take the mode-2 path
 	const bool rows = (bmode == 0 || bmode == 3) && gx <= 2048 && gy <= 2048;   // span partitions (binning_rows.hip)
 	uint32_t* perm = presort ? (uint32_t*)(gchunk + gl.perm) : nullptr;
+	// (the deferred-count decision: made HERE, in front of the sort, because the sort's last pass writes the count record itself -- round 6)
+	const uint64_t* totals64 = (const uint64_t*)(gchunk + gl.totals64);   // (rows)
+	const int defer_opt = cx->option(SGS_OPT_DEFER_COUNT);
+	if (cx->count_pending && cx->count_ev && hipEventQuery(cx->count_ev) == hipSuccess) {
+		// a deferred frame nobody asked about: still learn from it
+		cx->L_hint = grow_hint(cx->L_hint, cx->count_host[0]);
+		cx->R_hint = grow_hint(cx->R_hint, cx->count_host[1]);
+		cx->count_pending = false;
+	}
+	(void)hipGetLastError();
+	const bool defer = defer_opt > 0 && rows && !(debug && g_sync_every_stage) && (defer_opt == 2 || (cx->L_hint > 0 && cx->R_hint > 0)) &&
+			   cx->ensure(cx->count_host, cx->count_ev);
+	const uint32_t defer_L = defer ? (defer_opt == 2 ? 4096u : cx->L_hint) : 0u;   // (2: tests -- a capacity no real frame fits, exercises the abort)
+	const uint32_t defer_R = defer ? (defer_opt == 2 ? 4096u : cx->R_hint) : 0u;
 	if (presort) {
 		sgs::DepthSortSpanOut span{radii, means2D, gx, gy, gx >= gy, (uint64_t*)(gchunk + gl.counts64),
 					   (uint4*)(gchunk + gl.rrec), (unsigned long long*)(gchunk + gl.totals64),
-					   (uint32_t*)(gchunk + gl.stage_a_tab), 0u, 0u};
+					   (uint32_t*)(gchunk + gl.stage_a_tab), 0u, 0u,
+					   nullptr, 0u, 0u, nullptr, nullptr, nullptr};
+		if (defer) {   // (defer implies rows, i.e. the span form of the last pass)
+			span.cc_done = (uint32_t*)(gchunk + gl.cc_done);
+			span.cc_L_cap = defer_L;
+			span.cc_R_cap = defer_R;
+			span.cc_trap = trap_flag;
+			span.cc_rec = (uint32_t*)(gchunk + gl.count_rec);
+			span.cc_host = cx->count_host;
+		}
 		sgs::row_binning_stage_a_counts(P, &span.stage_a_chunks, &span.stage_a_groups);
 		e = sgs::launch_depth_sort(fs, P, gl.ds_lay, gchunk + gl.ds, (const uint32_t*)depths, perm, rows ? &span : nullptr);
 		if (e != hipSuccess) return fail_hip(e, "gaussian depth sort");
@@ -742,31 +745,19 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 	// The instance counts.  Default: the one blocking read-back of the forward (rasterizer_impl.cu:283).
 	// SGS_OPT_DEFER_COUNT (binning mode 0; not with debug + SGS_DEBUG_SYNC_EVERY_STAGE): nothing is read back.  The buffers and grids are sized
 	// from this stream's capacity guesses (1.25 x what its previous frame needed), the true counts are checked
-	// against them on the device (count_check_kernel: a frame that does not fit aborts itself), copied to a pinned
+	// against them on the device (by the sort's last workgroup: a frame that does not fit aborts itself), copied to a pinned
 	// record and reported by sgs_forward_result().  The host never waits for the GPU inside the call, so one host
 	// thread can keep several streams fed.  The return value is then the CAPACITY the binning buffer was laid out
 	// for, not num_rendered -- such a forward cannot be handed to sgs_rasterize_backward.
 	// sum over the Gaussians of (major instances << 32 | instances): the scan's last element, or the own sort's total
-	const uint64_t* totals64 = (const uint64_t*)(gchunk + gl.totals64);   // (rows)
-	const int defer_opt = cx->option(SGS_OPT_DEFER_COUNT);
-	if (cx->count_pending && cx->count_ev && hipEventQuery(cx->count_ev) == hipSuccess) {
-		// a deferred frame nobody asked about: still learn from it
-		cx->L_hint = grow_hint(cx->L_hint, cx->count_host[0]);
-		cx->R_hint = grow_hint(cx->R_hint, cx->count_host[1]);
-		cx->count_pending = false;
-	}
-	(void)hipGetLastError();
-	const bool defer = defer_opt > 0 && rows && !(debug && g_sync_every_stage) && (defer_opt == 2 || (cx->L_hint > 0 && cx->R_hint > 0)) &&
-			   cx->ensure(cx->count_host, cx->count_ev);
 	uint32_t L = 0, Rrows = 0;
 	const uint32_t* abort_word = nullptr;
 	if (defer) {
-		L = defer_opt == 2 ? 4096u : cx->L_hint;   // (2: tests -- a capacity no real frame fits, exercises the abort)
-		Rrows = defer_opt == 2 ? 4096u : cx->R_hint;
+		L = defer_L;
+		Rrows = defer_R;
 		uint32_t* rec = (uint32_t*)(gchunk + gl.count_rec);
-		hipLaunchKernelGGL(count_check_kernel, dim3(1), dim3(1), 0, fs, totals64, trap_flag, L, Rrows, rec, cx->count_host);
-		e = hipGetLastError();
-		if (e == hipSuccess) e = hipEventRecord(cx->count_ev, fs);
+		// (the record itself was written by the sort's last pass)
+		e = hipEventRecord(cx->count_ev, fs);
 		if (e != hipSuccess) return fail_hip(e, "deferred count record");
 		cx->count_pending = true;
 		cx->stat[SGS_STAT_DEFERRED_FORWARDS]++;
@@ -884,8 +875,7 @@ int sgs_rasterize_forward(sgs_alloc_fn geometry_buffer, void* geometry_user,
 					    (uint32_t*)(bchunk + bl.rowtab), (uint32_t*)(bchunk + bl.cmat),
 					    (uint32_t*)(bchunk + bl.gtot), (uint32_t*)(bchunk + bl.tilelen), ranges, point_list,
 					    abort_word, use_split ? (uint32_t*)(bchunk + bl.arena + bl.arena_lay.counter) : nullptr,
-					    (uint32_t)ntiles * 128u, (const uint32_t*)(gchunk + gl.stage_a_tab),
-					    g_span_chain ? (uint32_t*)(gchunk + gl.span_tickets) : nullptr);
+					    (uint32_t)ntiles * 128u, (const uint32_t*)(gchunk + gl.stage_a_tab));
 		counter_reset_done = use_split && Rrows != 0;   // (launch_row_binning with R == 0 is just a memset)
 		if (e != hipSuccess) return fail_hip(e, "row binning");
 		SGS_CHECK_STAGE("row binning");

@@ -293,7 +293,27 @@ __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 			unsigned long long tot = 0;
 #pragma unroll
 			for (int w = 0; w < NW; w++) tot += s_sum[w];
-			atomicAdd(so.total, tot);
+			const unsigned long long before = atomicAdd(so.total, tot);
+			if (so.cc_done) {
+				// the count record (capi.hip count_check_kernel) by whichever workgroup is last: its ticket is taken only when its own add has
+				// RETURNED (the data dependence on `before`), so the last ticket sees every workgroup's add in the total it then reads
+				const uint32_t mine = __hip_atomic_fetch_add(so.cc_done, 1u + (uint32_t)(before & 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (mine == gridDim.x - 1u) {
+					const unsigned long long rl = __hip_atomic_load(so.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const unsigned long long L = rl & 0xffffffffull, R = rl >> 32;
+					const uint32_t trap = (uint32_t)*so.cc_trap;
+					const uint32_t abort = (L > (unsigned long long)so.cc_L_cap || R > (unsigned long long)so.cc_R_cap || trap != 0u) ? 1u : 0u;
+					so.cc_rec[0] = (uint32_t)L;
+					so.cc_rec[1] = (uint32_t)R;
+					so.cc_rec[2] = trap;
+					so.cc_rec[3] = abort;
+					so.cc_host[0] = (uint32_t)L;
+					so.cc_host[1] = (uint32_t)R;
+					so.cc_host[2] = trap;
+					so.cc_host[3] = abort;
+					__threadfence_system();
+				}
+			}
 		}
 	}
 }

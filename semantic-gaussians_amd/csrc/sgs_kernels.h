@@ -39,6 +39,13 @@ struct DepthSortSpanOut {   // optional by-product of the last pass: what binnin
 	// workgroup writes, so that the span partitions start without a table kernel of their own (nullptr: not wanted)
 	uint32_t* stage_a_tab;
 	uint32_t stage_a_chunks, stage_a_groups;
+	// (round 6, deferred-count forwards) the count record written by the LAST workgroup of the sort's last pass instead of a kernel of its own
+	// (capi.hip count_check_kernel): cc_done = a zeroed word (nullptr: not wanted); capacities, the trap flag, the device and the pinned host record
+	uint32_t* cc_done;
+	uint32_t cc_L_cap, cc_R_cap;
+	const int* cc_trap;
+	uint32_t* cc_rec;
+	volatile uint32_t* cc_host;
 };
 void depth_sort_layout(int P, DepthSortLayout* lay);
 hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, char* scratch,
@@ -72,7 +79,7 @@ void row_binning_scratch(int P, uint32_t R, int gx, int gy, size_t* tab_words, s
 hipError_t launch_row_binning(hipStream_t st, int P, uint32_t R, int gx, int gy, const uint4* rrec, uint2* items, uint32_t* tabs, uint32_t* cmat,
 			      uint32_t* gtot, uint32_t* lens, uint2* ranges, uint32_t* point_list, const uint32_t* abort = nullptr,
 			      uint32_t* arena_counter = nullptr, uint32_t arena_first_free = 0,
-			      const uint32_t* stage_a_tab = nullptr, uint32_t* tickets2 = nullptr);   // tickets2: two ZEROED words -> the chained one-launch-per-stage form of the list scans (round 6)   // stage_a_tab: DepthSortSpanOut::stage_a_tab, already written (else a table kernel runs)
+			      const uint32_t* stage_a_tab = nullptr);   // stage_a_tab: DepthSortSpanOut::stage_a_tab, already written (else a table kernel runs)
 // chunks / scan groups of stage A (the P ranked Gaussians as one segment): what DepthSortSpanOut::stage_a_chunks / _groups must hold
 void row_binning_stage_a_counts(int P, uint32_t* chunks, uint32_t* groups);   // optional: also reset the split blend's counter
 void launch_reconstruct_keys_ranges(hipStream_t st, int ntiles, const uint2* ranges, const uint32_t* point_list,
