@@ -53,8 +53,8 @@ const char *sgs_last_error(void);
  * Replaces CudaRasterizer::Rasterizer::forward
  *   (CR/cuda_rasterizer/rasterizer_impl.cu:198-341, declared rasterizer.h:30-53;
  *    RR/cuda_rasterizer/rasterizer_impl.cu:198-339 when out_depth != NULL).
- * Pipeline (default, binning mode 0): preprocess -> depth presort of the P Gaussians (own LSD radix sort; its last
- * pass also writes the per-rank span counts and adds up their totals) -> (8-byte D2H: row instances | num_rendered)
+ * Pipeline (default, binning mode 0): preprocess -> depth presort of the P Gaussians (own LSD radix sort, four launches; its last
+ * pass also writes the per-rank span counts, adds up their totals and -- deferred counts -- the count record) -> (8-byte D2H: row instances | num_rendered)
  * -> two span partitions that write every tile's depth-ordered list and `ranges` with no sort of the tile instances
  * -> blend (weights pre-pass + accumulate sweep for num_channels >= 128).  Binning mode 1 keeps the
  * reference's order of operations (inclusive scan -> 4-byte D2H -> duplicateWithKeys -> stable 64-bit radix sort
