@@ -413,19 +413,22 @@ hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, 
 	// SGS_DS_CHAIN=1 (read once; round 6): the passes count their own digits and wait for the rows in front of their tile -- no counting kernels
 	static const bool chain_on = [] { const char* e = getenv("SGS_DS_CHAIN"); return e ? (*e && *e != '0') : DS_CHAIN_DEFAULT; }();
 	uint32_t* chain = (uint32_t*)(scratch + lay.chain);
+	// (a chained tile sums <= groups + 31 flagged rows with device-scope loads, eight at a time: past 64 groups -- 8.4 M keys -- that walk is longer than
+	// a counting kernel; BASELINE config 5's 50 M keys, 382 groups, keep the three counting kernels)
+	const bool use_chain = chain_on && lay.groups <= 64;
 #define DS_PASS(PASS_, SPAN_, KI_, VI_, KO_, VO_, C_, G_, SO_)                                                                        \
 	do {                                                                                                                               \
-		if (chain_on) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, true>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
+		if (use_chain) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, true>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
 		else if (nw == 16) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, false>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
 		else if (nw == 8) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 8, false>), grid, dim3(512), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
 		else hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 4, false>), grid, dim3(256), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
 	} while (0)
 	DS_PASS(0, false, depth_bits, (const uint32_t*)nullptr, kA, vA, cnt[0], gcnt[0], none);
-	if (!chain_on) hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1]);
+	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1]);
 	DS_PASS(1, false, kA, vA, kB, vB, cnt[1], gcnt[1], none);
-	if (!chain_on) hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2]);
+	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2]);
 	DS_PASS(2, false, kB, vB, kA, vA, cnt[2], gcnt[2], none);
-	if (!chain_on) hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3]);
+	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3]);
 	if (span) DS_PASS(3, true, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], *span);
 	else DS_PASS(3, false, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], none);
 #undef DS_PASS
