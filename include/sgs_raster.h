@@ -317,7 +317,10 @@ int sgs_stream_release(void *stream);
  *                                  record / read-back) on `front_stream` and only the blend on `stream`; the two are ordered by events
  *                                  inside the call (front end behind the stream's earlier work, blend behind the front end), so the
  *                                  caller keeps addressing ONE stream.  front_stream NULL (or == stream): one stream again.
- * Typical use (bench.py, sgs_hip.raster.partitioned_streams): per view slot a blend stream on CUs [f, n) and a front stream on [0, f). */
+ *                                  The library keeps the pointer: detach (sgs_stream_set_front(stream, NULL)) or release / destroy `stream`
+ *                                  BEFORE front_stream is destroyed.
+ * Typical use (sgs_hip.raster.PartitionedStreams, bench.py --front-cus): per view slot a blend stream on CUs [f, n) and a front stream on [0, f).
+ * Measured on MI355X: not a win for this pipeline -- the sweep slows in proportion to the compute units it loses. */
 int sgs_device_cu_count(void);
 int sgs_stream_create_cu_range(int cu_first, int cu_count, void **stream_out);
 int sgs_stream_destroy(void *stream);
