@@ -73,7 +73,7 @@ template <int PASS, bool SPAN, int NW, bool CHAIN>
 __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 	int P, int groups, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
 	uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* cnt,
-	uint32_t* gcnt, DepthSortSpanOut so, uint32_t* chain)
+	uint32_t* gcnt, DepthSortSpanOut so, uint32_t* chain, const uint32_t* __restrict__ sgcnt, int sgroups)
 {
 	constexpr int SHIFT = 8 * PASS;
 	constexpr int NT = 64 * NW, ITEMS = DS_TILE / NT;
@@ -111,10 +111,20 @@ __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 		const int grp = k / DS_GRP;
 		uint32_t tot = 0, pre = 0;
 		if (t < 256) {
-			for (int g = 0; g < groups; g++) {
-				const uint32_t c = gcnt[(size_t)g * 256 + t];
-				tot += c;
-				pre += g < grp ? c : 0u;
+			if (sgcnt) {   // three levels (more than 64 groups): <= sgroups + 31 + 31 rows instead of groups + 31
+				const int sg = grp / DS_GRP;
+				for (int q = 0; q < sgroups; q++) {
+					const uint32_t c = sgcnt[(size_t)q * 256 + t];
+					tot += c;
+					pre += q < sg ? c : 0u;
+				}
+				for (int g = sg * DS_GRP; g < grp; g++) pre += gcnt[(size_t)g * 256 + t];
+			} else {
+				for (int g = 0; g < groups; g++) {
+					const uint32_t c = gcnt[(size_t)g * 256 + t];
+					tot += c;
+					pre += g < grp ? c : 0u;
+				}
 			}
 			for (int kk = grp * DS_GRP; kk < k; kk++) pre += cnt[(size_t)kk * 256 + t];
 		}
@@ -324,7 +334,8 @@ __global__ __launch_bounds__(64 * NW) void depth_sort_pass_kernel(
 // 2.3 ms per pass, against 16 us for the pass itself.)
 template <int SHIFT>
 __global__ __launch_bounds__(256) void depth_sort_count_kernel(int P, const uint32_t* __restrict__ keys,
-								uint32_t* __restrict__ cnt, uint32_t* __restrict__ gcnt)
+								uint32_t* __restrict__ cnt, uint32_t* __restrict__ gcnt,
+								uint32_t* __restrict__ sgcnt)
 {
 	__shared__ uint32_t s_h[256];
 	const int k = blockIdx.x, t = threadIdx.x;
@@ -339,6 +350,16 @@ __global__ __launch_bounds__(256) void depth_sort_count_kernel(int P, const uint
 	const uint32_t c = s_h[t];
 	cnt[(size_t)k * 256 + t] = c;
 	if (c) atomicAdd(&gcnt[(size_t)(k / DS_GRP) * 256 + t], c);
+	if (c && sgcnt) atomicAdd(&sgcnt[(size_t)(k / (DS_GRP * DS_GRP)) * 256 + t], c);
+}
+
+// pass 0's super-group rows from its group rows (those come from the kernel that made the keys): sgcnt0[q][d] = sum of <= 32 group rows
+__global__ __launch_bounds__(256) void depth_sort_sg0_kernel(int groups, const uint32_t* __restrict__ gcnt0, uint32_t* __restrict__ sgcnt0)
+{
+	const int q = blockIdx.x, t = threadIdx.x;
+	uint32_t s = 0;
+	for (int g = q * DS_GRP; g < (q + 1) * DS_GRP && g < groups; g++) s += gcnt0[(size_t)g * 256 + t];
+	sgcnt0[(size_t)q * 256 + t] = s;
 }
 
 // pass 0's count matrices from an array of keys (the forward gets them from preprocess.hip; this is for
@@ -382,6 +403,8 @@ void depth_sort_layout(int P, DepthSortLayout* lay)
 	lay->groups = groups;
 	lay->counts = take((size_t)4 * ((size_t)tiles + groups) * 256 * 4);   // 4 passes x (tile rows | group rows)
 	lay->chain = take((size_t)(3 * 256 + 4) * 4);                         // ghist of digits 1 .. 3 | tickets of passes 1 .. 3 (cleared with the matrices)
+	lay->sgroups = (groups + DS_GRP - 1) / DS_GRP;
+	lay->sg = take((size_t)4 * (size_t)lay->sgroups * 256 * 4);           // 4 passes x super-group rows (used past 64 groups)
 	lay->counts_bytes = off - lay->counts;
 	lay->keys[0] = take((size_t)P * 4);
 	lay->keys[1] = take((size_t)P * 4);
@@ -416,19 +439,24 @@ hipError_t launch_depth_sort(hipStream_t st, int P, const DepthSortLayout& lay, 
 	// (a chained tile sums <= groups + 31 flagged rows with device-scope loads, eight at a time: past 64 groups -- 8.4 M keys -- that walk is longer than
 	// a counting kernel; BASELINE config 5's 50 M keys, 382 groups, keep the three counting kernels)
 	const bool use_chain = chain_on && lay.groups <= 64;
+	// past 64 groups: a third level of count rows (round 6: 50 M keys 9.0 -> ? ms, profiles/r06_depth_sort_sizes.txt)
+	const bool three = !use_chain && lay.groups > 64;
+	uint32_t* sg[4];
+	for (int p = 0; p < 4; p++) sg[p] = three ? (uint32_t*)(scratch + lay.sg) + (size_t)p * lay.sgroups * 256 : nullptr;
+	if (three) hipLaunchKernelGGL(depth_sort_sg0_kernel, dim3(lay.sgroups), dim3(256), 0, st, lay.groups, gcnt[0], sg[0]);
 #define DS_PASS(PASS_, SPAN_, KI_, VI_, KO_, VO_, C_, G_, SO_)                                                                        \
 	do {                                                                                                                               \
-		if (use_chain) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, true>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
-		else if (nw == 16) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, false>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
-		else if (nw == 8) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 8, false>), grid, dim3(512), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
-		else hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 4, false>), grid, dim3(256), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain); \
+		if (use_chain) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, true>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain, sg[PASS_], lay.sgroups); \
+		else if (nw == 16) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 16, false>), grid, dim3(1024), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain, sg[PASS_], lay.sgroups); \
+		else if (nw == 8) hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 8, false>), grid, dim3(512), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain, sg[PASS_], lay.sgroups); \
+		else hipLaunchKernelGGL((depth_sort_pass_kernel<PASS_, SPAN_, 4, false>), grid, dim3(256), 0, st, P, lay.groups, KI_, VI_, KO_, VO_, C_, G_, SO_, chain, sg[PASS_], lay.sgroups); \
 	} while (0)
 	DS_PASS(0, false, depth_bits, (const uint32_t*)nullptr, kA, vA, cnt[0], gcnt[0], none);
-	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1]);
+	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<8>, grid, block, 0, st, P, kA, cnt[1], gcnt[1], sg[1]);
 	DS_PASS(1, false, kA, vA, kB, vB, cnt[1], gcnt[1], none);
-	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2]);
+	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<16>, grid, block, 0, st, P, kB, cnt[2], gcnt[2], sg[2]);
 	DS_PASS(2, false, kB, vB, kA, vA, cnt[2], gcnt[2], none);
-	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3]);
+	if (!use_chain) hipLaunchKernelGGL(depth_sort_count_kernel<24>, grid, block, 0, st, P, kA, cnt[3], gcnt[3], sg[3]);
 	if (span) DS_PASS(3, true, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], *span);
 	else DS_PASS(3, false, kA, vA, (uint32_t*)nullptr, perm, cnt[3], gcnt[3], none);
 #undef DS_PASS

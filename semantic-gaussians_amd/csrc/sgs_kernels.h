@@ -26,7 +26,8 @@ struct DepthSortLayout {        // byte offsets inside the sort's scratch
 	                               // matrices are filled (preprocess.hip does that, with atomics)
 	size_t keys[2], vals[2], total;
 	size_t chain;                  // (round 6, inside the zeroed counts region) ghist[3][256] | ticket[4]: the chained passes' global digit histograms and tile tickets
-	int tiles, groups;
+	size_t sg;                     // (round 6, inside the zeroed counts region) 4 passes x sgroups rows: a third level of count rows (32 groups each) for more than 64 groups
+	int tiles, groups, sgroups;
 };
 struct DepthSortSpanOut {   // optional by-product of the last pass: what binning_rows.hip's span_counts_kernel writes
 	const int* radii;
