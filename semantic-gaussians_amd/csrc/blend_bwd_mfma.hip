@@ -638,27 +638,44 @@ constexpr int GROW = 260;                   // dwords per channel row of the tra
 constexpr int GTILE = 32 * GROW + 32;       // rows 16 .. 31 start 32 dwords later: the two lane halves of a transposing store hit different banks
 __device__ __forceinline__ int g_row(int c) { return c * GROW + (c >> 4) * 32; }
 
-template <bool FP32, int DBG = 0>   // DBG (development, wrong results): 2 no global atomics, 4 no products, 8 no transposing stores, 16 phase stamps
+// PERSIST (round 6): one workgroup per compute unit that takes its tiles from a per-XCD ticket and requests the NEXT tile's first round
+// trip -- slab 0 of the gradient, the entry ids, the count words, then the weight rows -- during the current tile's tail (phase clocks on x16,
+// profiles/r06_backward_phases.txt: that round trip and the wait for the slowest wave's are 10 % of an iteration, the tail another 6 %: with one workgroup
+// per CU nothing hides either).  The ticket after next is requested a tile ahead, so the dynamic balance of separately dispatched workgroups is kept.
+template <bool FP32, int DBG = 0, bool PERSIST = false>   // DBG (development, wrong results): 2 no global atomics, 4 no products, 8 no transposing stores, 16 phase stamps
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_fused_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
 	const uint32_t* __restrict__ nact, const uint32_t* __restrict__ act_id,
 	const float* Wrows, const float* __restrict__ features, const float* __restrict__ bg,
 	const float* __restrict__ dL_dpix, float* Drows, float* __restrict__ dL_dcolors,
 	const uint32_t* __restrict__ counter, uint32_t capacity, int W, int H, int C, int gx, int per_xcd, int ntiles,
-	unsigned long long* __restrict__ trace)
+	unsigned long long* __restrict__ trace, uint32_t* tickets)
 {
 	// (split form: double-rate MFMAs) 256 registers per wave, pinned: with two waves per SIMD the workgroup owns its compute unit's register
 	// files outright -- no foreign wave can be resident beside its matrix instructions; all eight waves are resident from
 	// dispatch, and the last products of a tile lie before a barrier that every wave passes before it can leave
 	if constexpr (!FP32) asm volatile("" : : : "v255");
 	const int b = blockIdx.x;
+	const int t = threadIdx.x;
 	// (XCD bands, not the forward's longest-first order: measured, that order is 1.5 % slower here too -- neighbouring tiles share
 	// feature rows in an XCD's L2 -- profiles/r05_backward_fused.txt)
-	const int tile = (b & 7) * per_xcd + (b >> 3);
+	int tile = (b & 7) * per_xcd + (b >> 3);
+	// PERSIST: the tiles of this XCD's band by ticket (tickets[x]: zeroed by the arena's reset kernel)
+	__shared__ int s_tk;
+	const int band_lo = (b & 7) * per_xcd;
+	const int band_n = (ntiles - band_lo) < per_xcd ? (ntiles - band_lo) : per_xcd;
+	if constexpr (PERSIST) {
+		if (band_n <= 0) return;
+		if (t == 0) s_tk = (int)__hip_atomic_fetch_add(&tickets[b & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+		const int tk = __builtin_amdgcn_readfirstlane(s_tk);
+		__syncthreads();   // (s_tk is written again below)
+		if (tk >= band_n) return;
+		tile = band_lo + tk;
+	}
 	// (the overflow word is NOT tested here: a dependent load in front of everything costs every workgroup a memory round trip;
 	// it travels with the first chunk's loads below.  A first chunk beyond the arena's capacity means overflow without asking.)
 	if (tile >= ntiles || ((uint32_t)tile + 1u) * 128u > capacity) return;
-	const int t = threadIdx.x;
 	const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 	const int l31 = lane & 31, h = lane >> 5;
 	// DBG & 16 (tools/bwd_phases.py): shader-clock stamps at the phase boundaries of an iteration, summed per wave.  s_memtime is an
@@ -666,6 +683,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	constexpr bool PH = (DBG & 16) != 0;
 	uint32_t ph[20] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 	uint32_t ph_prev = PH ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
+	uint32_t ph_iters = 0u, ph_total = 0u;   // (phase stamps) slab iterations and entries of this workgroup's tiles
 #define SGS_PH(K_)                                                          \
 	if (PH) {                                                           \
 		const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); \
@@ -673,7 +691,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		ph_prev = now_;                                             \
 	}
 	const int mblk = wave & 3, kh = wave >> 2;   // W g^T: this wave's block of 32 entries and its half of the 256 px' (= row parity)
-	const int tx = tile % gx, ty = tile / gx;
 	const uint32_t HW = (uint32_t)H * (uint32_t)W;
 	const int nsl = C >> 5;
 
@@ -684,11 +701,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 	// this lane's pixel px' = 32 wave + l31 and its sixteen channels 16 h .. 16 h + 15 of every slab
 	const int gp = 32 * wave + l31;
-	const int g_y = ty * SGS_TILE + 2 * ((gp & 127) >> 4) + (gp >> 7), g_x = tx * SGS_TILE + (gp & 15);
-	const bool g_ok = g_y < H && g_x < W;
-	const uint32_t g_okm = g_ok ? 0xFFFFFFFFu : 0u;
-	const uint32_t g_offb = 4u * ((uint32_t)(16 * h) * HW + (uint32_t)(g_y < H ? g_y : H - 1) * (uint32_t)W +
-				      (uint32_t)(g_x < W ? g_x : W - 1));   // (eligibility: 128 planes * 4 B < 2^32)
+	// (of the CURRENT tile; PERSIST moves them on to the next tile once the current tile's last slab has been taken)
+	bool g_ok;
+	uint32_t g_okm, g_offb;
+	auto set_tile = [&](int tl) __attribute__((always_inline)) {
+		// (from an opaque copy of the thread index: the lane terms are a dozen instructions a tile -- hoisted out of the tile loop they were held
+		// in registers the slab loop does not have, and spilled)
+		int tq = t;
+		if constexpr (PERSIST) asm volatile("" : "+v"(tq));
+		const int gq = ((tq >> 6) << 5) | (tq & 31), hq = (tq >> 5) & 1;
+		const int tx = tl % gx, ty = tl / gx;
+		const int g_y = ty * SGS_TILE + 2 * ((gq & 127) >> 4) + (gq >> 7), g_x = tx * SGS_TILE + (gq & 15);
+		g_ok = g_y < H && g_x < W;
+		g_okm = g_ok ? 0xFFFFFFFFu : 0u;
+		g_offb = 4u * ((uint32_t)(16 * hq) * HW + (uint32_t)(g_y < H ? g_y : H - 1) * (uint32_t)W +
+			       (uint32_t)(g_x < W ? g_x : W - 1));   // (eligibility: 128 planes * 4 B < 2^32)
+	};
+	set_tile(tile);
 	const int wr16 = 2 * g_row(16 * h) + gp;             // transposing store, 16-bit units: element (c = 16 h, px' = gp), hi term
 	const int wr32 = g_row(16 * h) + gp;                 // (FP32) in floats
 	const int rd = g_row(l31) + 64 * kh + 8 * h;         // W g^T's B operand, dwords: row c = l31, px' 128 kh + 16 h .. of block 0 (+ 16 j)
@@ -707,30 +736,80 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	// first chunk needs -- the gradient's first slab, the entry ids, the weight rows -- is requested in ONE round trip, beside the
 	// entry count itself (masks are applied when it has arrived).  Written the obvious way (count, then ids, then pointers, then
 	// rows) a workgroup spent four dependent round trips, 13 us, before its first product: 16 % of the kernel.
-	int total = 0x7fffffff;
-	uint32_t chunk_base = 0u;
-	for (int ci = 0; ci * CHUNK < total; ci++) {
-		const uint32_t cstart = ci == 0 ? (uint32_t)tile * 128u : table[chunk_base + (uint32_t)ci];
-		SGS_PH(9)
-		fetch_g(0);
-		const uint32_t my_id = act_id[cstart + (uint32_t)(t & (CHUNK - 1))];   // (slots beyond the count: this chunk's own, unused memory)
-		uint32_t f_id[2];
+	// The loads a chunk starts with (ids, weight rows; fetch_g(0) goes with them) are issued at the chunk's top, or -- PERSIST, a tile's first chunk -- during the
+	// previous tile's tail (`pre`).
+	uint32_t my_id = 0u, f_id[2] = {0u, 0u};
+	float4 wraw[4][4];
+	auto load_ids = [&](uint32_t cs) __attribute__((always_inline)) {
+		my_id = act_id[cs + (uint32_t)(t & (CHUNK - 1))];   // (slots beyond the count: this chunk's own, unused memory)
 #pragma unroll
-		for (int i = 0; i < 2; i++) f_id[i] = act_id[cstart + (uint32_t)((t + 512 * i) >> 3)];
-		// ---- the chunk's weights for W g^T: entries 32 mblk + l31, px' 128 kh + 32 j + 16 h .. + 15 (j = 0 .. 3), resident all chunk
-		float4 wraw[4][4];
-		{
-			const float* wr = Wrows + (size_t)(cstart + (uint32_t)(32 * mblk + l31)) * 256 + 128 * kh + 16 * h;
+		for (int i = 0; i < 2; i++) f_id[i] = act_id[cs + (uint32_t)((t + 512 * i) >> 3)];
+	};
+	// the chunk's weights for W g^T: entries 32 mblk + l31, px' 128 kh + 32 j + 16 h .. + 15 (j = 0 .. 3), resident all chunk
+	// (n: the chunk's entry count where it is known when the rows are requested -- every chunk but a workgroup's first; rows beyond it, a quarter of a
+	// chunk's 128 KB on average, are then not requested at all.  They are masked after arrival either way.)
+	auto load_w = [&](uint32_t cs, int n) __attribute__((always_inline)) {
+		const float* wr = Wrows + (size_t)(cs + (uint32_t)(32 * mblk + l31)) * 256 + 128 * kh + 16 * h;
+		if (32 * mblk + l31 < n) {
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 #pragma unroll
 				for (int i = 0; i < 4; i++) wraw[j][i] = *reinterpret_cast<const float4*>(wr + 32 * j + 4 * i);
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) wraw[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+	};
+	// the feature rows of the chunk's entries (A of D): thread t stages pieces (t + 512 i) & 7 of entries (t + 512 i) >> 3
+	const float* frow[2];
+	bool fvalid[2];
+	float4 pf[2];
+	auto set_rows = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			const int q = t + 512 * i, e = q >> 3, f = q & 7;
+			fvalid[i] = e < n;
+			const uint32_t id = fvalid[i] ? f_id[i] : NO_ID;
+			frow[i] = ((id == BG_ID || id == NO_ID) ? bg : features + (size_t)id * C) + 4 * f;
+		}
+	};
+	auto fetch_f = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+		for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
+	};
+	bool pre = false;
+	uint32_t total_pre_v = 0u, cb_pre_v = 0u;   // (the next tile's count words: vector loads -- scalar ones would put a memory round trip in front of the tail's first LDS wait)
+	for (;;) {   // (PERSIST: this workgroup's tiles; otherwise once)
+	int total = 0x7fffffff;
+	uint32_t chunk_base = 0u;
+	int next_tile = -1;
+	for (int ci = 0; ci * CHUNK < total; ci++) {
+		const uint32_t cstart = ci == 0 ? (uint32_t)tile * 128u : table[chunk_base + (uint32_t)ci];
+		SGS_PH(9)
+		// (PERSIST) the ticket behind this tile's, requested a whole tile before it is needed: the balance of separately dispatched workgroups without their start-up
+		uint32_t tk_nx = 0u;
+		if constexpr (PERSIST) {
+			if (ci == 0 && t == 0) tk_nx = __hip_atomic_fetch_add(&tickets[b & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		const bool was_pre = PERSIST && pre && ci == 0;
+		if (!was_pre) {
+			fetch_g(0);
+			load_ids(cstart);
+			load_w(cstart, ci == 0 ? CHUNK : total - ci * CHUNK);
 		}
 		if (ci == 0) {
-			const uint32_t overflow = counter[1];
-			total = (int)nact[tile];
-			chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
-			if (overflow != 0u) return;   // (uniform; nothing has been written yet) the per-chunk kernel behind this one does the work
+			if (PERSIST && pre) {
+				total = (int)__builtin_amdgcn_readfirstlane(total_pre_v);
+				chunk_base = __builtin_amdgcn_readfirstlane(cb_pre_v);
+				pre = false;
+			} else {
+				const uint32_t overflow = counter[1];
+				total = (int)nact[tile];
+				chunk_base = (ranges[tile].x >> 7) + (uint32_t)tile;
+				if (overflow != 0u) return;   // (uniform; nothing has been written yet) the per-chunk kernel behind this one does the work
+			}
 		}
 		const int cnt = (total - ci * CHUNK) < CHUNK ? (total - ci * CHUNK) : CHUNK;
 		const int mb = (cnt + 31) >> 5;
@@ -739,21 +818,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		SGS_PH(10)   // first round trip (count, ids, weights, gradient slab 0)
 		__syncthreads();   // the previous chunk is done with s_id, sF, sG, sX
 		if (t < CHUNK) s_id[t] = t < cnt ? my_id : NO_ID;
-		const float* frow[2];
-		bool fvalid[2];
-#pragma unroll
-		for (int i = 0; i < 2; i++) {
-			const int q = t + 512 * i, e = q >> 3, f = q & 7;
-			fvalid[i] = e < cnt;
-			const uint32_t id = fvalid[i] ? f_id[i] : NO_ID;
-			frow[i] = ((id == BG_ID || id == NO_ID) ? bg : features + (size_t)id * C) + 4 * f;
+		if (!was_pre) {   // (PERSIST: a prefetched tile's first pieces were requested in the previous tile's tail)
+			set_rows(cnt);
+			fetch_f(0);
 		}
-		float4 pf[2];
-		auto fetch_f = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-			for (int i = 0; i < 2; i++) pf[i] = *reinterpret_cast<const float4*>(frow[i] + c0);
-		};
-		fetch_f(0);
 		SGS_PH(11)   // barrier, ids, row pointers
 		uint32_t wh[4][8], wl[4][8];   // (split) bf16 pairs of positions 2 i, 2 i + 1
 		float wv[4][16];               // (FP32)
@@ -957,6 +1025,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		SGS_PH(12)   // weights split
 		stage_f(0);
 		SGS_PH(13)   // second round trip (feature pieces) + staging
+		if constexpr (PERSIST) {
+			if (ci == 0 && t == 0) s_tk = (int)tk_nx;   // every thread reads it in the tail of the tile's last chunk
+		}
 		__syncthreads();
 		SGS_PH(14)
 		// iteration s: slab s is taken and multiplied into D, W g^T of slab s - 1 runs from the tile the last barrier published,
@@ -994,10 +1065,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 			SGS_PH(8)
 		}
 		SGS_PH(9)
+		// PERSIST, the tile's last chunk: the next tile's first round trip goes out HERE, behind the last slab's barrier -- the gradient's slab 0 (this
+		// tile's last slab has been taken, its geometry is done with), the ids, the count words; the weight rows follow once this chunk's are dead
+		uint32_t cs_next = 0u;
+		if constexpr (PERSIST) {
+			if ((ci + 1) * CHUNK >= total) {
+				const int tk2 = __builtin_amdgcn_readfirstlane(s_tk);
+				const int nt = band_lo + tk2;
+				if (tk2 < band_n && ((uint32_t)nt + 1u) * 128u <= capacity) {
+					next_tile = nt;
+					cs_next = (uint32_t)nt * 128u;
+					set_tile(nt);
+					fetch_g(0);
+					load_ids(cs_next);
+					{
+						const uint32_t* np = nact + nt;
+						const uint2* rp = ranges + nt;
+						asm volatile("" : "+v"(np), "+v"(rp));
+						total_pre_v = *np;
+						cb_pre_v = (rp->x >> 7) + (uint32_t)nt;
+					}
+				}
+			}
+		}
 		if (nsl >= 2) finish_e(nsl & 1, 32 * (nsl - 2));
 		SGS_PH(15)
 		prod_e((nsl & 1) ^ 1);
 		SGS_PH(16)
+		if constexpr (PERSIST) {
+			if (next_tile >= 0) {
+				const int n_next = (int)__builtin_amdgcn_readfirstlane(total_pre_v);
+				load_w(cs_next, n_next);
+				set_rows(n_next < CHUNK ? n_next : CHUNK);   // (the ids have been under way for a slab's W g^T)
+				fetch_f(0);
+				pre = true;
+			} else {
+				// (no prefetch: the next chunk's top loads everything.  Written out so that the chunk's old values END here -- left to the
+				// merge, the dead weight rows stayed live through the whole slab loop and the kernel spilled)
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+#pragma unroll
+					for (int i = 0; i < 4; i++) wraw[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+				for (int j = 0; j < 16; j++) pg[j] = 0.f;
+				my_id = f_id[0] = f_id[1] = 0u;
+				pf[0] = pf[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+		}
 		__syncthreads();
 		SGS_PH(17)
 		finish_e((nsl & 1) ^ 1, 32 * (nsl - 1));
@@ -1011,6 +1125,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 					if (e < cnt) Drows[(size_t)(cstart + e) * 256 + 32 * wave + l31] = acc[m][r];
 				}
 	}
+	if (PH) {
+		ph_iters += (uint32_t)(((total + CHUNK - 1) / CHUNK) * nsl);
+		ph_total += (uint32_t)total;
+	}
+	if (!PERSIST || next_tile < 0) break;
+	tile = next_tile;
+	}
 	if (PH && trace) {
 		if (PH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		SGS_PH(19)   // D rows written
@@ -1018,8 +1139,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 			unsigned long long* o = trace + ((size_t)b * 8 + wave) * 24;
 #pragma unroll
 			for (int k = 0; k < 20; k++) o[k] = ph[k];
-			o[20] = (unsigned long long)(((total + CHUNK - 1) / CHUNK) * nsl);   // iterations with a slab
-			o[21] = (unsigned long long)wave | ((unsigned long long)total << 8);
+			o[20] = (unsigned long long)ph_iters;   // iterations with a slab
+			o[21] = (unsigned long long)wave | ((unsigned long long)ph_total << 8);
 			o[22] = wall_clock64();
 		}
 	}
@@ -1220,10 +1341,26 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 #ifdef SGS_WITH_EXPERIMENTS
 static const int g_bwd_dbg = getenv("SGS_BWD_DBG") ? atoi(getenv("SGS_BWD_DBG")) : 0;   // ablations / phase stamps of the fused kernel (tools/bwd_phases.py)
 #endif
+// the fused kernel as persistent workgroups that prefetch the next tile's first round trip (SGS_BWD_PERSIST=0: one workgroup per tile)
+static const bool g_bwd_persist = getenv("SGS_BWD_PERSIST") ? atoi(getenv("SGS_BWD_PERSIST")) != 0 : true;
+static int bwd_persist_groups()   // one 8-wave workgroup per compute unit, a multiple of the 8 XCDs
+{
+	static const int n = [] {
+		int dev = 0;
+		hipDeviceProp_t pr;
+		if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+		const int cu = pr.multiProcessorCount;
+		return cu >= 8 ? (cu / 8) * 8 : 8;
+	}();
+	return n;
+}
 
 int bwd_fused_x16_ownership()   // (blend_sweep2.hip: x16_kernel_owns_cu)
 {
-	static const int own = x16_kernel_owns_cu((const void*)&bwd_fused_kernel<false>, "bwd_fused_kernel<false>") ? 1 : 0;
+	static const int own = (x16_kernel_owns_cu((const void*)&bwd_fused_kernel<false>, "bwd_fused_kernel<false>") &&
+				x16_kernel_owns_cu((const void*)&bwd_fused_kernel<false, 0, true>, "bwd_fused_kernel<false,0,true>"))
+				       ? 1
+				       : 0;
 	return own;
 }
 
@@ -1258,20 +1395,24 @@ hipError_t launch_blend_backward_mfma(hipStream_t st, const BlendBwdArgs& a, cha
 	(void)vec; (void)ixcd; (void)items;
 	if (!two_kernels) {   // round 5: one kernel, one read of the gradient for both products
 		const dim3 grid(txcd * 8), block(512);
+		uint32_t* tickets = (uint32_t*)(arena + lay.counter) + 2;
 #define SGS_FUSED_ARGS a.ranges, table, nact, act_id, rows, a.colors, a.bg, a.dL_dpix, rows, a.dL_dcolors, counter, lay.capacity, a.W, a.H, a.C, a.gx, txcd, ntiles, \
-		       get_sweep_trace()
+		       get_sweep_trace(), tickets
 #ifdef SGS_WITH_EXPERIMENTS
 		if (g_bwd_dbg != 0 && !fp32_products) {
 			switch (g_bwd_dbg) {
 #define SGS_DBG_CASE(D_) case D_: hipLaunchKernelGGL((bwd_fused_kernel<false, D_>), grid, block, 0, st, SGS_FUSED_ARGS); break;
 			SGS_DBG_CASE(2) SGS_DBG_CASE(4) SGS_DBG_CASE(8) SGS_DBG_CASE(15) SGS_DBG_CASE(16)
 #undef SGS_DBG_CASE
+			case 48: hipLaunchKernelGGL((bwd_fused_kernel<false, 16, true>), dim3(bwd_persist_groups()), block, 0, st, SGS_FUSED_ARGS); break;   // stamps, persistent form
 			default: break;
 			}
 		} else
 #endif
 		if (fp32_products || !bwd_fused_x16_ownership()) {   // (fp32 products: backward mode 3; also what runs when the x16 form would not own its CU)
 			hipLaunchKernelGGL((bwd_fused_kernel<true>), grid, block, 0, st, SGS_FUSED_ARGS);
+		} else if (g_bwd_persist && (int)grid.x > bwd_persist_groups()) {
+			hipLaunchKernelGGL((bwd_fused_kernel<false, 0, true>), dim3(bwd_persist_groups()), block, 0, st, SGS_FUSED_ARGS);
 		} else {
 			hipLaunchKernelGGL((bwd_fused_kernel<false>), grid, block, 0, st, SGS_FUSED_ARGS);
 		}

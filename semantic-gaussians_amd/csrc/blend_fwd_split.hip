@@ -1343,6 +1343,8 @@ __global__ void arena_reset_kernel(uint32_t* __restrict__ counter, const uint32_
 {
 	counter[0] = first_free;   // slots [0, ntiles * 128) are the tiles' pre-assigned first chunks
 	counter[1] = (abort && *abort != 0u) ? 2u : 0u;
+#pragma unroll
+	for (int x = 0; x < 8; x++) counter[2 + x] = 0u;   // the per-XCD tile tickets of the backward's persistent kernel (blend_bwd_mfma.hip)
 }
 
 // The exact-format work list alone (fp32 weight rows + ids + list positions): the backward's first step.
@@ -1369,7 +1371,7 @@ size_t split_arena_bytes(uint32_t capacity, size_t L, int ntiles, SplitArena* la
 	auto take = [&](size_t bytes) { off = (off + 127) & ~(size_t)127; const size_t o = off; off += bytes; return o; };
 	SplitArena a;
 	a.capacity = capacity;
-	a.counter = take(8);
+	a.counter = take(64);   // slots handed out, overflow word, 8 tile tickets (the backward)
 	a.nbatches = take((size_t)ntiles * 4);                       // nact[tile]
 	a.table = take(((L >> 7) + (size_t)ntiles + 1) * 4);           // chunk starts
 	a.act_id = take((size_t)capacity * 4);

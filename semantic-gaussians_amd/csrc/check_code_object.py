@@ -115,7 +115,7 @@ def violations(kernels, product):
     x16 = sorted(n for n, k in kernels.items() if k["x16_instructions"])
     owners = [n for n in x16 if any(o in n for o in OWNERS)]
     if not product:   # the development instantiations (ablations, phase stamps: template argument DBG != 0) are not held to the invariant
-        owners = [n for n in owners if re.search(r"blend_accum_sweep3_kernelILi0E|bwd_fused_kernelILb[01]ELi0EE", n)]
+        owners = [n for n in owners if re.search(r"blend_accum_sweep3_kernelILi0E|bwd_fused_kernelILb[01]ELi0ELb[01]EE", n)]
     for o in OWNERS:
         if not any(o in n for n in owners):
             bad.append(f"no {o} instantiation issues {X16}: the check has lost its subject")

@@ -11,7 +11,7 @@ from sgs_hip import raster, _lib
 from sgs_hip.synthetic import CONFIGS, make_scene
 from sgs_hip.camera import pinhole
 
-assert os.environ.get("SGS_BWD_DBG") == "16", "run with SGS_BWD_DBG=16"
+assert os.environ.get("SGS_BWD_DBG") in ("16", "48"), "run with SGS_BWD_DBG=16 (one workgroup per tile) or 48 (persistent workgroups)"
 dev = "cuda:0"
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 P, C, W, H, fx = CONFIGS["cfg3"]
