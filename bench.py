@@ -393,6 +393,11 @@ def main():
                          "blend stream on the other CUs and a front stream on these); 0 (default) = ordinary streams, every kernel anywhere.  Measured "
                          "(profiles/r06_cu_partition.txt): the sweep slows in proportion to the CUs it loses -- 1.02 ms on 256, 1.17 on 224, 1.33 on 208 -- "
                          "which costs more than the front end's interference it removes (465 vs 477 Gpx.ch/s at 32 front CUs, four views in flight)")
+    ap.add_argument("--blend-everywhere", action="store_true",
+                    help="with --front-cus: only the front ends are confined; the blend streams may use every compute unit")
+    ap.add_argument("--stream-priority", choices=("none", "split", "blend", "front"), default=os.environ.get("SGS_BENCH_STREAM_PRIORITY", "none"),
+                    help="experiment (profiles/r06_stream_priority.txt): every view slot's front end on a second ordinary stream (split), with the blend "
+                         "stream (blend) or the front stream (front) at high priority; none (default) = one stream per slot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-arithmetic / backward legs")
     args = ap.parse_args()
@@ -451,7 +456,18 @@ def main():
     plain_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(V - 1)]
     streams = plain_streams
     # the headline's streams: per view slot a blend stream on CUs [front_cus, n) with its front end on CUs [0, front_cus)
-    part = raster.PartitionedStreams(dev, args.front_cus, V) if args.front_cus > 0 else None
+    part = raster.PartitionedStreams(dev, args.front_cus, V, blend_everywhere=args.blend_everywhere) if args.front_cus > 0 else None
+    if part is None and args.stream_priority != "none":
+        class _PriorityStreams:
+            def __init__(self, high):
+                import ctypes
+                from sgs_hip import _lib
+                pb, pf = {"split": (0, 0), "blend": (-1, 0), "front": (0, -1)}[high]
+                self.streams = [torch.cuda.Stream(dev, priority=pb) for _ in range(V)]
+                self.front = [torch.cuda.Stream(dev, priority=pf) for _ in range(V)]
+                for b_, f_ in zip(self.streams, self.front):
+                    _lib.check(_lib.load().sgs_stream_set_front(ctypes.c_void_p(b_.cuda_stream), ctypes.c_void_p(f_.cuda_stream)), "set front")
+        part = _PriorityStreams(args.stream_priority)
 
     def render(i, deferred=False, k=0):
         c = cams[i][k % NCAM]
@@ -909,7 +925,8 @@ def main():
             "cu_partition": ({"front_cus": part.front_cus, "blend_cus": part.cu_count - part.front_cus, "device_cus": part.cu_count,
                               "note": "every view slot: blend stream confined to the blend CUs, front end (preprocess, depth sort, span partitions) "
                                       "on a second stream confined to the front CUs (hipExtStreamCreateWithCUMask; sgs_stream_set_front); "
-                                      "shared_cus below = the same headline on ordinary streams"} if part is not None else None),
+                                      "shared_cus below = the same headline on ordinary streams"} if (part is not None and hasattr(part, "front_cus")) else
+                             ({"stream_priority": args.stream_priority, "note": "experiment: front ends on second ordinary streams (--stream-priority)"} if part is not None else None)),
             "shared_cus": shared_cus,
             "classic_count": classic,
             "deferred_count": deferred,

@@ -548,7 +548,8 @@ class PartitionedStreams:
     front-end kernels of one view never hold the 8-wave sweep workgroups of another off their compute units.  streams[i] is a
     torch.cuda.ExternalStream: use it with torch.cuda.stream(...) like any other.  close() destroys the HIP streams."""
 
-    def __init__(self, device, front_cus, slots):
+    def __init__(self, device, front_cus, slots, blend_everywhere=False):
+        """blend_everywhere: the blend streams are not confined (all n CUs); only the front ends are kept on [0, front_cus)."""
         lib = _lib.load()
         self.device = torch.device(device)
         self.streams, self.front, self._raw = [], [], []
@@ -559,7 +560,10 @@ class PartitionedStreams:
             self.cu_count, self.front_cus = n, int(front_cus)
             for _ in range(int(slots)):
                 b, f = C.c_void_p(), C.c_void_p()
-                _lib.check(lib.sgs_stream_create_cu_range(self.front_cus, n - self.front_cus, C.byref(b)), "blend stream")
+                if blend_everywhere:
+                    _lib.check(lib.sgs_stream_create_cu_range(0, n, C.byref(b)), "blend stream")
+                else:
+                    _lib.check(lib.sgs_stream_create_cu_range(self.front_cus, n - self.front_cus, C.byref(b)), "blend stream")
                 _lib.check(lib.sgs_stream_create_cu_range(0, self.front_cus, C.byref(f)), "front stream")
                 _lib.check(lib.sgs_stream_set_front(b, f), "set front")
                 self._raw.append((b, f))
