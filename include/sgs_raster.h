@@ -382,7 +382,10 @@ int sgs_set_binning_mode(int mode);
  * 1 = always the per-chunk VALU kernel (blend_bwd.hip); 2 = as 0 with a deliberately undersized work-list arena
  * (exercises the overflow fallback; tests only); 4 / 5 = rounds 2-4's form of 0 / 3 (one kernel per product, each
  * streaming the gradient; `make EXPERIMENTS=1` builds only, SGS_EINVAL otherwise).  All within 1e-4 of the largest gradient entry of the float64 oracle
- * (tests, also at the headline configuration's full size).  Returns the previous mode. */
+ * (tests, also at the headline configuration's full size).  Returns the previous mode.
+ * Mode 0 with more tiles than the device has compute units launches the kernel as PERSISTENT workgroups (round 6): one per compute unit, tiles by
+ * ticket, the next tile's first loads requested in the current tile's tail; same arithmetic, same results up to the order of the colour gradient's
+ * atomics.  SGS_BWD_PERSIST=0 in the environment (read once, at load) keeps one workgroup per tile. */
 int sgs_set_backward_mode(int mode);
 /* Which optional parts this libsgs_hip.so was built with: bit 0 `make FUSED=1` (blend variants 32-35), bit 1 `make X16=1` (the
  * double-rate-MFMA reproducers), bit 2 `make EXPERIMENTS=1` (development forms of the blend kernels: ablations, superseded sweeps and

@@ -1076,15 +1076,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 					next_tile = nt;
 					cs_next = (uint32_t)nt * 128u;
 					set_tile(nt);
-					fetch_g(0);
-					load_ids(cs_next);
-					{
+					{   // (count words and ids FIRST: loads return in order, and the weight rows / feature pieces below wait for these, not for the gradient)
 						const uint32_t* np = nact + nt;
 						const uint2* rp = ranges + nt;
 						asm volatile("" : "+v"(np), "+v"(rp));
 						total_pre_v = *np;
 						cb_pre_v = (rp->x >> 7) + (uint32_t)nt;
 					}
+					load_ids(cs_next);
+					fetch_g(0);
 				}
 			}
 		}
