@@ -841,7 +841,7 @@ def main():
                                  "note": "4 C H W (dL/dpixel once) + 2 x 4 C sum n_t_eff (feature rows in, colour-gradient rows "
                                          "out) + 28 sum n_t_eff + 8 H W + 104 P_vis; since round 5 one kernel reads the gradient once per "
                                          "128 entries of a tile for BOTH products (DESIGN.md 5.5, 5.14); fabric bytes by PMC: "
-                                         "profiles/r05_backward_pmc.txt"},
+                                         "profiles/r06_backward_pmc.txt"},
                     "includes": "output / gradient allocation through the caching allocator (no resident pool: the "
                                 "state buffers belong to the autograd graph)"}
         del dL
@@ -950,7 +950,7 @@ def main():
                                      "bf16 products (all 256 pixels of every active entry, ~55 % of sum n_t_eff) against the "
                                      "dense bf16 peak: since round 5 the sweep issues the double-rate 32x32x16 instruction "
                                      "(1024 FLOP/clk/SIMD; DESIGN.md 5.10 for why that needed eight-wave workgroups that own "
-                                     "their compute unit) -- PMC: profiles/r05_blend_pmc.txt (SQ_VALU_MFMA_BUSY_CYCLES)"},
+                                     "their compute unit) -- PMC: profiles/r06_blend_pmc.txt (SQ_VALU_MFMA_BUSY_CYCLES)"},
                          "measured": f"hipEvents on the launch stream over {sv_default['forwards']} forwards with one view "
                                      f"in flight, right behind the timed region (steady state; the same leg at the top of the process: "
                                      f"single_view_cold); the timed region keeps {V} in flight (stage_ms_timed_region)"},

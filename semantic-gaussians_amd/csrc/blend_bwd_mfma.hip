@@ -638,10 +638,11 @@ constexpr int GROW = 260;                   // dwords per channel row of the tra
 constexpr int GTILE = 32 * GROW + 32;       // rows 16 .. 31 start 32 dwords later: the two lane halves of a transposing store hit different banks
 __device__ __forceinline__ int g_row(int c) { return c * GROW + (c >> 4) * 32; }
 
-// PERSIST (round 6): one workgroup per compute unit that takes its tiles from a per-XCD ticket and requests the NEXT tile's first round
-// trip -- slab 0 of the gradient, the entry ids, the count words, then the weight rows -- during the current tile's tail (phase clocks on x16,
-// profiles/r06_backward_phases.txt: that round trip and the wait for the slowest wave's are 10 % of an iteration, the tail another 6 %: with one workgroup
-// per CU nothing hides either).  The ticket after next is requested a tile ahead, so the dynamic balance of separately dispatched workgroups is kept.
+// PERSIST (round 6): one workgroup per compute unit that takes its tiles from a per-XCD ticket and requests the NEXT tile's first loads
+// -- the count words, the entry ids, slab 0 of the gradient, then (once the registers of the split weights are dead) the weight rows and the first feature
+// pieces -- during the current tile's tail (phase clocks on x16, profiles/r06_backward_phases.txt: that round trip and the wait for the slowest wave's are
+// 10 % of an iteration with one workgroup per tile, and with one workgroup per CU nothing hides it).  The ticket behind the current tile's is requested at
+// the tile's top and read in its tail: the dynamic balance of separately dispatched workgroups without their start-up.  Kernel: -3.9 %.
 template <bool FP32, int DBG = 0, bool PERSIST = false>   // DBG (development, wrong results): 2 no global atomics, 4 no products, 8 no transposing stores, 16 phase stamps
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_fused_kernel(
 	const uint2* __restrict__ ranges, const uint32_t* __restrict__ table,
