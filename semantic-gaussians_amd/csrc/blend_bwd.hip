@@ -32,19 +32,19 @@ struct StagedEntryB {
 	float pad0, pad1;
 };
 
+// one (tile, channel chunk) of the walk: the whole workgroup
 template <int CC>
-__global__ __launch_bounds__(256) void blend_bwd_kernel(
-	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+__device__ __forceinline__ void blend_bwd_block(
+	const int blk, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const float* __restrict__ bg, const float2* __restrict__ means2D,
 	const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
 	const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
 	const float* __restrict__ dL_dpixels, float* __restrict__ dL_dmean2D,
 	float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
-	int W, int H, int C, int gx, int nchunks, const uint32_t* __restrict__ gate)
+	int W, int H, int C, int gx, int nchunks)
 {
-	if (gate && gate[1] == 0u) return;   // the work-list path did the job
-	const int tile = blockIdx.x / nchunks;
-	const int chunk = blockIdx.x - tile * nchunks;
+	const int tile = blk / nchunks;
+	const int chunk = blk - tile * nchunks;
 	const int c0 = chunk * CC;
 	const int cn = (C - c0) < CC ? (C - c0) : CC;
 	const int tx = tile % gx, ty = tile / gx;
@@ -222,21 +222,47 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 	}
 }
 
+// gate == nullptr: one workgroup per (tile, chunk).  gate != nullptr (the fallback behind the work-list path: it runs only if that path's arena
+// overflowed): a strided grid -- 79 056 workgroups that each read the gate word and leave were 21 us of every cfg3 backward; 2 048 are 2.
+template <int CC>
+__global__ __launch_bounds__(256) void blend_bwd_kernel(
+	const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+	const float* __restrict__ bg, const float2* __restrict__ means2D,
+	const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
+	const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+	const float* __restrict__ dL_dpixels, float* __restrict__ dL_dmean2D,
+	float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
+	int W, int H, int C, int gx, int nchunks, int nblocks, const uint32_t* __restrict__ gate)
+{
+	if (gate) {
+		if (gate[1] == 0u) return;   // the work-list path did the job
+		for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+			blend_bwd_block<CC>(blk, ranges, point_list, bg, means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D,
+					    dL_dconic, dL_dopacity, dL_dcolors, W, H, C, gx, nchunks);
+			__syncthreads();   // (the block's LDS is the next block's)
+		}
+	} else {
+		blend_bwd_block<CC>(blockIdx.x, ranges, point_list, bg, means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D,
+				    dL_dconic, dL_dopacity, dL_dcolors, W, H, C, gx, nchunks);
+	}
+}
+
 hipError_t launch_blend_backward(hipStream_t st, const BlendBwdArgs& a, const uint32_t* gate)
 {
 	const int ntiles = a.gx * a.gy;
 	if (ntiles == 0 || a.C == 0) return hipSuccess;
 	if (a.C <= 4) {
-		hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(ntiles), dim3(256), 0, st, a.ranges,
+		hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(gate && ntiles > 2048 ? 2048 : ntiles), dim3(256), 0, st, a.ranges,
 				   a.point_list, a.bg, a.means2D, a.conic_opacity, a.colors, a.final_T,
 				   a.n_contrib, a.dL_dpix, a.dL_dmean2D, a.dL_dconic, a.dL_dopacity,
-				   a.dL_dcolors, a.W, a.H, a.C, a.gx, 1, gate);
+				   a.dL_dcolors, a.W, a.H, a.C, a.gx, 1, ntiles, gate);
 	} else {
 		const int nch = (a.C + 31) / 32;
-		hipLaunchKernelGGL((blend_bwd_kernel<32>), dim3(ntiles * nch), dim3(256), 0, st, a.ranges,
+		const int nblocks = ntiles * nch;
+		hipLaunchKernelGGL((blend_bwd_kernel<32>), dim3(gate && nblocks > 2048 ? 2048 : nblocks), dim3(256), 0, st, a.ranges,
 				   a.point_list, a.bg, a.means2D, a.conic_opacity, a.colors, a.final_T,
 				   a.n_contrib, a.dL_dpix, a.dL_dmean2D, a.dL_dconic, a.dL_dopacity,
-				   a.dL_dcolors, a.W, a.H, a.C, a.gx, nch, gate);
+				   a.dL_dcolors, a.W, a.H, a.C, a.gx, nch, nblocks, gate);
 	}
 	return hipGetLastError();
 }

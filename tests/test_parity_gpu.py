@@ -412,6 +412,35 @@ def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
     assert np.abs(outs[0][1]).max() > 0
 
 
+def test_backward_overflow_fallback_on_a_strided_grid():
+    """The fallback behind the work-list path (blend_bwd.hip) is launched on a strided grid of 2 048 workgroups when it is gated -- 79 056
+    workgroups that only read the gate word were 21 us of every cfg3 backward.  3 800 (tile, chunk) blocks here: mode 2 (undersized arena: the
+    gate opens, every workgroup walks several blocks) against mode 1 (the same kernel, one workgroup per block, no gate)."""
+    from sgs_hip import raster
+    C, P, W, H, fx = 256, 20000, 400, 300, 350.0
+    scene, cam = small_scene(P=P, C=C, W=W, H=H, fx=fx, seed=77)
+    bg = np.linspace(0.1, 0.9, C).astype(np.float32)
+    dL = torch.randn(C, H, W, generator=torch.Generator().manual_seed(6))
+    from sgs_hip import _lib
+    outs = {}
+    overflows0 = raster.stream_stat(_lib.STAT_BWD_OVERFLOWS)
+    for mode in (2, 0, 1):   # (the overflow of a backward is read back by the stream's next work-list backward: mode 0 in the middle)
+        raster.set_backward_mode(mode)
+        try:
+            n, color, radii, geom, binn, img, _ = _hip_forward(scene, cam, bg=bg)
+            outs[mode] = [t.cpu().numpy() for t in _hip_backward(scene, cam, bg, dL, n, radii, geom, binn, img)]
+        finally:
+            raster.set_backward_mode(0)
+    assert raster.stream_stat(_lib.STAT_BWD_OVERFLOWS) - overflows0 >= 1   # the gate did open in mode 2
+    assert ((W + 15) // 16) * ((H + 15) // 16) * (C // 32) > 2048
+    for a, b in zip(outs[2], outs[1]):
+        if b.size == 0:
+            continue
+        ok, err = _grad_close(a, b, 1e-5)
+        assert ok, err
+    assert np.abs(outs[1][1]).max() > 0
+
+
 def test_channel_rasterization_call_pattern_matches_render_chn(orc):
     """Executes the exact kwargs of model/renderer.py:169-183,228-237 (render_chn) and of
     :54-69,111 (render) against the drop-in packages, with autograd through both."""
