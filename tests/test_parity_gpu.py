@@ -369,7 +369,8 @@ def _hip_backward(scene, cam, bg, dL, n, radii, geom, binn, img):
 @pytest.mark.parametrize("C,P,W,H,fx,dense", [(128, 1500, 96, 80, 85.0, False), (192, 2500, 100, 70, 90.0, False),
                                                (128, 12000, 150, 40, 300.0, True), (512, 1500, 64, 48, 60.0, False),
                                                (32, 2000, 101, 67, 90.0, False), (96, 1500, 64, 64, 70.0, False),
-                                               (128, 12000, 272, 256, 500.0, True), (64, 9000, 333, 290, 300.0, False)])
+                                               (128, 12000, 272, 256, 500.0, True), (64, 9000, 333, 290, 300.0, False),
+                                               (32, 8000, 331, 277, 300.0, False)])
 def test_backward_worklist_mfma_path(orc, C, P, W, H, fx, dense):
     """C >= 32, C % 32 == 0: the backward blend as matrix products over the work list (blend_bwd_mfma.hip)
     against the oracle AND against the per-chunk kernel; ragged image edges (also a width that is not a
