@@ -176,15 +176,23 @@ __device__ __forceinline__ void blend_bwd_block(
 			float dL_dalpha = S * T;
 			dL_dalpha += (-T_final / oma) * bg_dot;
 			if (!valid) dL_dalpha = 0.f;
-			const float dL_dG = e.o * dL_dalpha;
 			const float Gv = valid ? G : 0.f;   // keeps inf/NaN of rejected lanes out of the sums
-			const float gdx = Gv * dx, gdy = Gv * dy;
-			const float dG_ddelx = -gdx * e.ca - gdy * e.cb;
-			const float dG_ddely = -gdy * e.cc - gdx * e.cb;
-			// the six geometry sums (+ the first two colour sums of an RGB chunk) in one transposed reduction
-			const float u = wave_sum8(dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy, -0.5f * gdx * dx * dL_dG,
-						  -0.5f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG, Gv * dL_dalpha,
-						  COMBINE ? pc[0] : 0.f, COMBINE ? pc[1] : 0.f);
+			float u;
+			if constexpr (COMBINE) {
+				// (round 6, as blend_bwd_mfma.hip's geometry walk) the wave sums are the six MOMENTS of r = G dL/dalpha over the pixels -- r dx, r dy,
+				// r dx^2, r dx dy, r dy^2, r -- and meet the entry's opacity and conic once per entry where the four waves' sums are added up
+				const float r = Gv * dL_dalpha;
+				const float rx = r * dx, ry = r * dy;
+				u = wave_sum8(rx, ry, rx * dx, rx * dy, ry * dy, r, pc[0], pc[1]);   // (+ the first two colour sums of an RGB chunk)
+			} else {
+				const float dL_dG = e.o * dL_dalpha;
+				const float gdx = Gv * dx, gdy = Gv * dy;
+				const float dG_ddelx = -gdx * e.ca - gdy * e.cb;
+				const float dG_ddely = -gdy * e.cc - gdx * e.cb;
+				// the six geometry sums in one transposed reduction
+				u = wave_sum8(dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy, -0.5f * gdx * dx * dL_dG,
+					      -0.5f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG, Gv * dL_dalpha, 0.f, 0.f);
+			}
 			if (COMBINE) {
 				if (head) acc_row[comp] = u;   // slots 0-5 geometry, 6 / 7 = colour channels 0 / 1
 #pragma unroll
@@ -205,8 +213,16 @@ __device__ __forceinline__ void blend_bwd_block(
 			__syncthreads();
 			for (int q = threadIdx.x; q < (ke - kb) * NV; q += 256) {
 				const int e = q / NV, c = q - NV * e;
-				const float v = (s_acc[(0 * 64 + e) * NV + c] + s_acc[(1 * 64 + e) * NV + c]) +
-						(s_acc[(2 * 64 + e) * NV + c] + s_acc[(3 * 64 + e) * NV + c]);
+				auto tot = [&](int k) __attribute__((always_inline)) {
+					return (s_acc[(0 * 64 + e) * NV + k] + s_acc[(1 * 64 + e) * NV + k]) +
+					       (s_acc[(2 * 64 + e) * NV + k] + s_acc[(3 * 64 + e) * NV + k]);
+				};
+				const StagedEntryB& E = s_e[kb + e];
+				float v;   // slots 0 .. 5: the moments Rx, Ry, Rxx, Rxy, Ryy, R0
+				if (c == 0) v = -ddelx_dx * E.o * (E.ca * tot(0) + E.cb * tot(1));
+				else if (c == 1) v = -ddely_dy * E.o * (E.cc * tot(1) + E.cb * tot(0));
+				else if (c < 5) v = -0.5f * E.o * tot(c);
+				else v = tot(c);
 				if (v != 0.f) {
 					const size_t id = s_e[kb + e].id;
 					float* dst = c < 2 ? dL_dmean2D + 3 * id + c

@@ -1295,16 +1295,14 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 			if (valid) T = T * rinv;
 			float dL_dalpha = (Dk - R) * T;
 			dL_dalpha += (-T_final * rinv) * bg_dot;
-			if (!valid) dL_dalpha = 0.f;
 			if (valid) R = alpha * Dk + oma * R;
-			const float dL_dG = e.o * dL_dalpha;
-			const float Gv = valid ? G : 0.f;
-			const float gdx = Gv * dx, gdy = Gv * dy;
-			const float dG_ddelx = -gdx * e.ca - gdy * e.cb;
-			const float dG_ddely = -gdy * e.cc - gdx * e.cb;
-			// the six sums in one transposed reduction (sgs_device.h: 18 VALU instead of 6 x 11)
-			const float u = wave_sum8(dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy, -0.5f * gdx * dx * dL_dG,
-						  -0.5f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG, Gv * dL_dalpha, 0.f, 0.f);
+			// Round 6: the wave sums are the six MOMENTS of r = G dL/dalpha over the pixels -- sum r, r dx, r dy, r dx^2, r dx dy, r dy^2 -- and the
+			// entry's constants (opacity, conic) meet them once per entry behind the block: every one of the six gradient sums is a combination of these
+			//     dL/dmean.x = -W/2 o (ca Rx + cb Ry),  dL/dmean.y = -H/2 o (cc Ry + cb Rx),  dL/dconic = -o/2 (Rxx, Rxy, Ryy),  dL/do = R0
+			// (7 VALU per step in front of the reduction instead of 22).
+			const float r = valid ? G * dL_dalpha : 0.f;
+			const float rx = r * dx, ry = r * dy;
+			const float u = wave_sum8(rx, ry, rx * dx, rx * dy, ry * dy, r, 0.f, 0.f);
 			const int comp = wave_sum8_component(lane);
 			if ((lane & 7) == 0 && comp < 6) s_acc[wave][kslot][comp] = u;
 		};
@@ -1327,7 +1325,13 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 		__syncthreads();
 		for (int q = threadIdx.x; q < n * 6; q += 256) {
 			const int e = q / 6, c = q - 6 * e;
-			const float v = (s_acc[0][e][c] + s_acc[1][e][c]) + (s_acc[2][e][c] + s_acc[3][e][c]);
+			auto mom = [&](int k) __attribute__((always_inline)) { return (s_acc[0][e][k] + s_acc[1][e][k]) + (s_acc[2][e][k] + s_acc[3][e][k]); };
+			const StagedEntryG& E = s_e[e];
+			float v;
+			if (c == 0) v = -ddelx_dx * E.o * (E.ca * mom(0) + E.cb * mom(1));
+			else if (c == 1) v = -ddely_dy * E.o * (E.cc * mom(1) + E.cb * mom(0));
+			else if (c < 5) v = -0.5f * E.o * mom(c);
+			else v = mom(5);
 			if (v != 0.f) {
 				const size_t id = s_e[e].id;
 				float* dst = c < 2 ? dL_dmean2D + 3 * id + c : (c < 5 ? dL_dconic + 4 * id + (c == 4 ? 3 : c - 2) : dL_dopacity + id);
