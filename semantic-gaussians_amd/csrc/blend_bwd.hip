@@ -190,8 +190,8 @@ __device__ __forceinline__ void blend_bwd_block(
 				const float dG_ddelx = -gdx * e.ca - gdy * e.cb;
 				const float dG_ddely = -gdy * e.cc - gdx * e.cb;
 				// the six geometry sums in one transposed reduction
-				u = wave_sum8(dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy, -0.5f * gdx * dx * dL_dG,
-					      -0.5f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG, Gv * dL_dalpha, 0.f, 0.f);
+				u = wave_sum6(dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy, -0.5f * gdx * dx * dL_dG,
+					      -0.5f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG, Gv * dL_dalpha);
 			}
 			if (COMBINE) {
 				if (head) acc_row[comp] = u;   // slots 0-5 geometry, 6 / 7 = colour channels 0 / 1

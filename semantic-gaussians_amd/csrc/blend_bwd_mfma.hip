@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256) void bwd_geom_kernel(
 			// (7 VALU per step in front of the reduction instead of 22).
 			const float r = valid ? G * dL_dalpha : 0.f;
 			const float rx = r * dx, ry = r * dy;
-			const float u = wave_sum8(rx, ry, rx * dx, rx * dy, ry * dy, r, 0.f, 0.f);
+			const float u = wave_sum6(rx, ry, rx * dx, rx * dy, ry * dy, r);
 			const int comp = wave_sum8_component(lane);
 			if ((lane & 7) == 0 && comp < 6) s_acc[wave][kslot][comp] = u;
 		};

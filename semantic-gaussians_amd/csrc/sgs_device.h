@@ -93,20 +93,11 @@ __device__ __forceinline__ float wave_sum(float v)
 // halves / 16-lane rows between two registers so that one add folds two components at a time; from 8 lanes down, DPP.
 // Result: lane l with (l & 7) == 0 holds the total of component wave_sum8_component(l) (other lanes: partial sums).
 __device__ __forceinline__ int wave_sum8_component(int lane) { return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2); }
-__device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
+// (inline asm, not __builtin_amdgcn_permlane*_swap: hipcc 7.2 folds `s[0] + s[1]` of the builtin's result pair into `s[0] + s[0]`.  The s_nop in front covers
+// the VALU-write -> permlane-read distance the compiler cannot see into the asm for, the one behind the permlane-write -> VALU-read distance; the swaps of
+// one level are independent of each other and share ONE pair of them -- round 6: a pair per swap was 36 idle cycles of a ~340-cycle geometry step.)
+__device__ __forceinline__ float wave_sum8_tail(float s01, float s23)
 {
-	// (inline asm, not __builtin_amdgcn_permlane*_swap: hipcc 7.2 folds `s[0] + s[1]` of the builtin's result pair into
-	// `s[0] + s[0]`; the s_nop covers the VALU-write -> permlane-read distance the compiler cannot see into the asm for)
-	auto fold32 = [](float a, float b) __attribute__((always_inline)) {   // lanes < 32: sum of a's halves; >= 32: of b's
-		asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-		return a + b;
-	};
-	auto fold16 = [](float a, float b) __attribute__((always_inline)) {   // rows 0 / 2: a's row pairs; rows 1 / 3: b's
-		asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-		return a + b;
-	};
-	const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7);
-	const float s01 = fold16(r0, r1), s23 = fold16(r2, r3);
 	// 16 -> 8 lanes: lanes with bit 3 clear keep s01, the others s23; the partner's value arrives by a row rotation by 8
 	const bool up = (__lane_id() & 8) != 0;
 	const float keep = up ? s23 : s01, give = up ? s01 : s23;
@@ -116,6 +107,25 @@ __device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v
 	u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x1B, 0xF, 0xF, false));
 	u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, false));
 	return u;
+}
+__device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
+{
+	// lanes < 32: the sum of the first register's halves; >= 32: of the second's
+	asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+		     : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+	float r0 = v0 + v1, r1 = v2 + v3, r2 = v4 + v5, r3 = v6 + v7;
+	// rows 0 / 2: the first register's row pairs; rows 1 / 3: the second's
+	asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+	return wave_sum8_tail(r0 + r1, r2 + r3);
+}
+// six sums (components 6 and 7 of wave_sum8 zero): one swap and two moves fewer
+__device__ __forceinline__ float wave_sum6(float v0, float v1, float v2, float v3, float v4, float v5)
+{
+	asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\ts_nop 1"
+		     : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5));
+	float r0 = v0 + v1, r1 = v2 + v3, r2 = v4 + v5, r3 = 0.f;
+	asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+	return wave_sum8_tail(r0 + r1, r2 + r3);
 }
 
 // Blend exponential ("exp contract"): range reduction by the 1.5*2^23 magic
